@@ -1,0 +1,84 @@
+// api.hip — library-level entry points: version, error string, per-kernel HIP-event profiling.
+#include "common.h"
+#include <stdarg.h>
+#include <vector>
+#include <mutex>
+
+static thread_local char g_err[512] = "";
+
+void scl_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int scl_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        scl_set_error("%s: %s", what, hipGetErrorString(e));
+        return SCL_ELAUNCH;
+    }
+    return SCL_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+namespace {
+struct ProfPair { hipEvent_t a, b; };
+struct ProfState {
+    bool on = false;
+    std::vector<ProfPair> used;
+    std::vector<ProfPair> pool;
+    double flops = 0.0;
+};
+ProfState g_prof[SCL_KID_MAX];
+std::mutex g_prof_mu;
+}  // namespace
+
+SclProfScope::SclProfScope(int kid_, hipStream_t s_, double flops) : kid(kid_), s(s_), slot(nullptr) {
+    if (kid < 0 || kid >= SCL_KID_MAX || !g_prof[kid].on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    ProfPair p;
+    if (!st.pool.empty()) { p = st.pool.back(); st.pool.pop_back(); }
+    else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
+    st.used.push_back(p);
+    st.flops += flops;
+    slot = (void*)(uintptr_t)st.used.size();  // index + 1
+    hipEventRecord(p.a, s);
+}
+SclProfScope::~SclProfScope() {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    const size_t idx = (size_t)(uintptr_t)slot - 1;
+    if (idx < st.used.size()) hipEventRecord(st.used[idx].b, s);
+}
+
+extern "C" int scl_version(void) { return 100; }
+extern "C" const char* scl_last_error(void) { return g_err; }
+
+extern "C" int scl_prof_enable(int kid, int on) {
+    SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX, "prof: bad kernel id %d", kid);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[kid].on = on != 0;
+    return SCL_OK;
+}
+
+extern "C" int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops) {
+    SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX, "prof: bad kernel id %d", kid);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    double ms = 0.0;
+    for (auto& p : st.used) {
+        if (hipEventSynchronize(p.b) != hipSuccess) { scl_set_error("prof: event sync failed"); return SCL_ELAUNCH; }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms += t;
+        st.pool.push_back(p);
+    }
+    if (n_launches) *n_launches = (int64_t)st.used.size();
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = st.flops;
+    st.used.clear();
+    st.flops = 0.0;
+    return SCL_OK;
+}

@@ -1,0 +1,94 @@
+// common.h — shared device helpers for the gfx950 kernels (wave = 64 lanes, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/scl_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define SCL_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// exact (erf) GELU, as torch.nn.functional.gelu default / fairseq "gelu"
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+// activation ids shared with SCL_GEMM_ACT_SHIFT: 0 none, 1 gelu, 2 relu, 3 leaky_relu(0.01)
+__device__ __forceinline__ float act_f(int id, float x) {
+    switch (id) {
+        case 1: return gelu_f(x);
+        case 2: return x > 0.f ? x : 0.f;
+        case 3: return x > 0.f ? x : 0.01f * x;
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_grad_f(int id, float x) {
+    switch (id) {
+        case 1: return gelu_grad_f(x);
+        case 2: return x > 0.f ? 1.f : 0.f;
+        case 3: return x > 0.f ? 1.f : 0.01f;
+        default: return 1.f;
+    }
+}
+
+// counter-based dropout keep-mask: one 32-bit hash of (seed, element index); keep iff u >= p.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint64_t idx) {
+    uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += seed * 0xC2B2AE3Du; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint64_t idx, float p) {
+    const float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// host side ---------------------------------------------------------------------------------
+void scl_set_error(const char* fmt, ...);
+int  scl_check_launch(const char* what);
+
+struct SclProfScope {  // brackets a launch with two events when profiling of `kid` is on
+    int kid; hipStream_t s; void* slot;
+    SclProfScope(int kid, hipStream_t s, double flops);
+    ~SclProfScope();
+};
+
+#define SCL_REQUIRE(cond, ...)                     \
+    do {                                           \
+        if (!(cond)) {                             \
+            scl_set_error(__VA_ARGS__);            \
+            return SCL_EINVAL;                     \
+        }                                          \
+    } while (0)

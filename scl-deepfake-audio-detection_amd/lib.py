@@ -1,0 +1,87 @@
+"""ctypes binding of libscl_hip.so — the only way the Python host reaches the HIP kernels.
+
+The product path has no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, importing / calling raises immediately.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libscl_hip.so")
+FLAT = 0x7FFFFFFF
+
+_lib = None
+
+
+class SclError(RuntimeError):
+    pass
+
+
+class SclOperand(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("bs1", ctypes.c_int64), ("bs2", ctypes.c_int64),
+                ("rbstride", ctypes.c_int64), ("cout", ctypes.c_int64), ("rpb", ctypes.c_int32),
+                ("ld", ctypes.c_int32), ("cin", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+class SclGemmDesc(ctypes.Structure):
+    _fields_ = [("A", SclOperand), ("B", SclOperand), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
+                ("R", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("c_bs1", ctypes.c_int64), ("c_bs2", ctypes.c_int64), ("c_rbstride", ctypes.c_int64),
+                ("c_split_stride", ctypes.c_int64), ("bias_bs2", ctypes.c_int64),
+                ("c_rpb", ctypes.c_int32), ("ldc", ctypes.c_int32),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("nb1", ctypes.c_int32), ("nb2", ctypes.c_int32), ("splitk", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
+                ("drop_seed", ctypes.c_uint32), ("_pad", ctypes.c_int32)]
+
+
+# flags (include/scl_hip.h)
+GEMM_A_T, GEMM_B_T, GEMM_C_F32, GEMM_C2_F32, GEMM_R_F32 = 1, 2, 4, 8, 16
+GEMM_HAS_BIAS, GEMM_HAS_C2, GEMM_DROPOUT = 0x20, 0x40, 0x80
+ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
+KID_GEMM = 0
+
+_vp, _i32, _i64, _f32, _f64, _u32 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
+                                     ctypes.c_double, ctypes.c_uint32)
+
+
+def _protos():
+    """name -> argtypes.  Every symbol declared in include/scl_hip.h must appear here
+    (tests/test_abi.py checks both directions)."""
+    P = ctypes.POINTER
+    return {
+        "scl_version": ([], _i32),
+        "scl_last_error": ([], ctypes.c_char_p),
+        "scl_prof_enable": ([_i32, _i32], _i32),
+        "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
+        "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
+        "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
+    }
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SclError("libscl_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the product path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    protos = _protos()
+    for name, (argtypes, restype) in protos.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def all_symbol_names():
+    return sorted(_protos())
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().scl_last_error()
+        raise SclError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

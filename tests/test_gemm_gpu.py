@@ -1,0 +1,201 @@
+"""Parity of the generic bf16 MFMA contraction (scl_gemm_bf16) against torch fp32 matmul on the
+same bf16-rounded operands.  Tolerance: fp32 accumulation of bf16 products -> 2e-3 relative to the
+row scale for fp32 outputs, one bf16 ulp (8e-3 rel) for bf16 outputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from scl_amd import ops  # noqa: E402
+from scl_amd.lib import FLAT  # noqa: E402
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    denom = ref.abs().max().clamp_min(1e-6)
+    err = ((got - ref).abs().max() / denom).item()
+    assert err < tol, "%s: rel err %.3e >= %.1e" % (what, err, tol)
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (128, 128, 64), (257, 129, 199 + 1), (64, 72, 1000)])
+def test_layouts(dev, a_t, b_t, M, N, K):
+    # storage is padded to multiples of 8 along the contiguous dim
+    pad8 = lambda v: (v + 7) // 8 * 8
+    A = _rand((M, K), dev, 1)
+    B = _rand((N, K), dev, 2)
+    ref = A.float() @ B.float().t()
+    if a_t:
+        ldA = pad8(M)
+        At = torch.zeros(K, ldA, dtype=torch.bfloat16, device=dev)
+        At[:, :M] = A.t()
+        opA = ops.Op(At, ldA)
+    else:
+        ldA = pad8(K)
+        Ap = torch.zeros(M, ldA, dtype=torch.bfloat16, device=dev)
+        Ap[:, :K] = A
+        opA = ops.Op(Ap, ldA)
+    if b_t:
+        ldB = pad8(N)
+        Bt = torch.zeros(K, ldB, dtype=torch.bfloat16, device=dev)
+        Bt[:, :N] = B.t()
+        opB = ops.Op(Bt, ldB)
+    else:
+        ldB = pad8(K)
+        Bp = torch.zeros(N, ldB, dtype=torch.bfloat16, device=dev)
+        Bp[:, :K] = B
+        opB = ops.Op(Bp, ldB)
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t)
+    torch.cuda.synchronize()
+    _close(C, ref, 2e-3, "layout a_t=%s b_t=%s" % (a_t, b_t))
+
+
+def test_kcontig_tail_needs_no_zero_padding(dev):
+    # K = 199: the last 16-byte vector is partially valid; garbage (NaN) beyond K must be masked
+    M, N, K = 70, 90, 199
+    A = _rand((M, K), dev, 3); B = _rand((N, K), dev, 4)
+    Ap = torch.full((M, 208), float("nan"), dtype=torch.bfloat16, device=dev); Ap[:, :K] = A
+    Bp = torch.full((N, 208), float("nan"), dtype=torch.bfloat16, device=dev); Bp[:, :K] = B
+    C = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(Ap, 208), ops.Op(Bp, 208), C, M, N, K)
+    _close(C, A.float() @ B.float().t(), 2e-3, "k tail")
+    # transposed operands: rows >= K and cols >= M/N hold NaN and must not leak
+    At = torch.full((K + 9, 72), float("nan"), dtype=torch.bfloat16, device=dev); At[:K, :M] = A.t()
+    Bt = torch.full((K + 9, 96), float("nan"), dtype=torch.bfloat16, device=dev); Bt[:K, :N] = B.t()
+    C2 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(At, 72), ops.Op(Bt, 96), C2, M, N, K, a_t=True, b_t=True)
+    _close(C2, A.float() @ B.float().t(), 2e-3, "t tail")
+
+
+def test_epilogues(dev):
+    M, N, K = 200, 264, 320
+    A = _rand((M, K), dev, 5, 0.2); B = _rand((N, K), dev, 6, 0.2)
+    bias = torch.randn(N, device=dev)
+    lin = A.float() @ B.float().t() + bias
+    # bias + gelu with pre-activation second output (bf16)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.Op(A, K), ops.Op(B, K), C, M, N, K, bias=bias, act=1, c2=C2)
+    _close(C2, lin, 8e-3, "pre-act")
+    _close(C, torch.nn.functional.gelu(lin), 8e-3, "gelu")
+    # bias + f32 residual -> f32
+    R = torch.randn(M, N, device=dev)
+    C = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(A, K), ops.Op(B, K), C, M, N, K, bias=bias, R=R, rmode=1)
+    _close(C, lin + R, 2e-3, "residual")
+    # alpha and grad-multiply by gelu'(H) with H bf16
+    H = _rand((M, N), dev, 7)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.Op(A, K), ops.Op(B, K), C, M, N, K, alpha=0.5, R=H, rmode=2, ract=1)
+    h = H.float().requires_grad_(True)
+    torch.nn.functional.gelu(h).sum().backward()
+    _close(C, 0.5 * (A.float() @ B.float().t()) * h.grad, 8e-3, "gelu-grad-mul")
+    # relu / leaky
+    for act, fn in ((2, torch.relu), (3, lambda t: torch.nn.functional.leaky_relu(t, 0.01))):
+        C = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(B, K), C, M, N, K, bias=bias, act=act)
+        _close(C, fn(lin), 2e-3, "act %d" % act)
+
+
+def test_dropout_mask_is_reproducible_and_unbiased(dev):
+    M, N, K = 256, 256, 64
+    A = torch.ones(M, K, dtype=torch.bfloat16, device=dev); B = torch.ones(N, K, dtype=torch.bfloat16, device=dev)
+    C1 = torch.empty(M, N, dtype=torch.float32, device=dev); C2 = torch.empty_like(C1)
+    ops.gemm(ops.Op(A, K), ops.Op(B, K), C1, M, N, K, drop_p=0.5, drop_seed=123)
+    ops.gemm(ops.Op(A, K), ops.Op(B, K), C2, M, N, K, drop_p=0.5, drop_seed=123)
+    assert torch.equal(C1, C2)
+    vals = set(C1.unique().tolist())
+    assert vals == {0.0, 128.0}
+    keep = (C1 > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.02
+
+
+def test_conv_rows_and_split_k_index(dev):
+    # conv1d k=3, stride 2, channels-last == GEMM with overlapping rows (ld = stride*C < K)
+    Bsz, Tin, Cc, Co, k, s = 3, 41, 32, 48, 3, 2
+    Tout = (Tin - k) // s + 1
+    x = _rand((Bsz, Tin, Cc), dev, 8)
+    w = _rand((Co, Cc, k), dev, 9, 0.2)   # torch layout [co, ci, j]
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), stride=s).transpose(1, 2)  # [B,Tout,Co]
+    wk = w.permute(0, 2, 1).contiguous().view(Co, k * Cc)  # [co, j*C + ci]
+    xpad = torch.zeros(Bsz * Tin * Cc + 64, dtype=torch.bfloat16, device=dev); xpad[:x.numel()] = x.flatten()
+    C = torch.empty(Bsz * Tout, Co, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(xpad, s * Cc, rpb=Tout, rbstride=Tin * Cc), ops.Op(wk, k * Cc), C, Bsz * Tout, Co, k * Cc)
+    _close(C.view(Bsz, Tout, Co), ref, 2e-3, "conv rows")
+    # the same contraction as a wgrad: dW[co][j*C+ci] = sum_{b,t} dy[b,t,co] * x[b, s*t+j, ci]
+    dy = _rand((Bsz * Tout, Co), dev, 10)
+    xf = x.float().transpose(1, 2).requires_grad_(False)
+    wv = w.float().clone().requires_grad_(True)
+    y = torch.nn.functional.conv1d(xf, wv, stride=s).transpose(1, 2).reshape(Bsz * Tout, Co)
+    (y * dy.float()).sum().backward()
+    dw_ref = wv.grad.permute(0, 2, 1).reshape(Co, k * Cc)
+    dW = torch.empty(Co, k * Cc, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(dy, Co), ops.Op(xpad, s * Cc, rpb=Tout, rbstride=Tin * Cc), dW, Co, k * Cc, Bsz * Tout,
+             a_t=True, b_t=True)
+    _close(dW, dw_ref, 2e-3, "conv wgrad")
+    # 2-level contiguous index (grouped positional conv): k = (j, ci) -> j*ldx + ci, groups via batch
+    G, Cg, kk, T = 2, 16, 8, 37
+    Ctot = G * Cg
+    xp = _rand((Bsz, T + kk, Ctot), dev, 11)
+    wg = _rand((Ctot, Cg, kk), dev, 12, 0.3)   # [co_total, ci, j]
+    ref = torch.nn.functional.conv1d(xp.float().transpose(1, 2), wg.float(), groups=G).transpose(1, 2)[:, :T]
+    wgk = wg.view(G, Cg, Cg, kk).permute(0, 1, 3, 2).contiguous()  # [g][co][j][ci]
+    out = torch.zeros(Bsz * T, Ctot, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(xp, Ctot, rpb=T, rbstride=(T + kk) * Ctot, cin=Cg, cout=Ctot, bs2=Cg),
+             ops.Op(wgk, kk * Cg, bs2=Cg * kk * Cg), out, Bsz * T, Cg, kk * Cg,
+             nb2=G, ldc=Ctot, c_bs2=Cg)
+    _close(out.view(Bsz, T, Ctot), ref, 2e-3, "grouped conv")
+
+
+def test_batched_attention_shapes_and_splitk(dev):
+    Bsz, H, T, D = 2, 3, 199, 64
+    qkv = _rand((Bsz, T, 3, H, D), dev, 13, 0.5)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]   # [B,T,H,D]
+    ld = 3 * H * D
+    S = torch.empty(Bsz, H, T, T, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(qkv, ld, bs1=T * ld, bs2=D), ops.Op(qkv, ld, bs1=T * ld, bs2=D, offset=H * D), S, T, T, D,
+             nb1=Bsz, nb2=H, alpha=0.125, c_bs1=H * T * T, c_bs2=T * T)
+    ref = torch.einsum("bihd,bjhd->bhij", q.float(), k.float()) * 0.125
+    _close(S, ref, 2e-3, "QK^T")
+    Tp = 208
+    P = torch.zeros(Bsz, H, T, Tp, dtype=torch.bfloat16, device=dev)
+    P[..., :T] = torch.softmax(ref, -1).to(torch.bfloat16)
+    O = torch.zeros(Bsz, T, H * D, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.Op(P, Tp, bs1=H * T * Tp, bs2=T * Tp), ops.Op(qkv, ld, bs1=T * ld, bs2=D, offset=2 * H * D),
+             O, T, D, T, b_t=True, nb1=Bsz, nb2=H, ldc=H * D, c_bs1=T * H * D, c_bs2=D)
+    refO = torch.einsum("bhij,bjhd->bihd", P[..., :T].float(), v.float()).reshape(Bsz, T, H * D)
+    _close(O, refO, 8e-3, "PV")
+    # split-K slabs + deterministic reduce (wgrad shape: long reduction, small output)
+    M, N, K = 256, 128, 6368
+    A = _rand((K, M), dev, 14, 0.1); Bm = _rand((K, N), dev, 15, 0.1)
+    slabs = torch.empty(4, M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(A, M), ops.Op(Bm, N), slabs, M, N, K, a_t=True, b_t=True, splitk=4, c_split_stride=M * N)
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.reduce_slabs(slabs, out, M * N, 4, M * N)
+    _close(out, A.float().t() @ Bm.float(), 2e-3, "split-K")
+
+
+def test_gemm_speed_report(dev, capsys):
+    M, N, K = 6368, 4096, 1024
+    A = _rand((M, K), dev, 16, 0.1); B = _rand((N, K), dev, 17, 0.1)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    for name, kw, a, b in (("NT", {}, ops.Op(A, K), ops.Op(B, K)),):
+        for _ in range(3):
+            ops.gemm(a, b, C, M, N, K, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.gemm(a, b, C, M, N, K, **kw)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        with capsys.disabled():
+            print("\n[gemm %s %dx%dx%d] %.3f ms  %.1f TFLOP/s" % (name, M, N, K, ms, 2 * M * N * K / ms / 1e9))
