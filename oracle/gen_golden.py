@@ -1,0 +1,340 @@
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference's own Python — with empty stand-in modules for the third-party packages that
+are not installed (fairseq, librosa, torchaudio, soundfile, pydub, tensorboardX); none of the code
+paths exercised below calls into those stand-ins except `librosa.load`, which is replaced by an
+in-memory array provider — runs it on seeded synthetic inputs and writes small .npz fixtures to
+tests/golden/.  The fixtures are data (inputs + expected outputs); the reference never travels.
+
+    python oracle/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+class _Any(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return type(k, (), {})
+
+
+def import_reference():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in ["fairseq", "librosa", "librosa.effects", "torchaudio", "torchaudio.functional", "torchaudio.io",
+                 "torchaudio.transforms", "torchaudio.sox_effects", "soundfile", "pydub", "pydub.effects",
+                 "tensorboardX"]:
+        if name not in sys.modules:
+            m = _Any(name)
+            m.__path__ = []
+            sys.modules[name] = m
+
+
+class Args:
+    algo = 5
+    nBands, minF, maxF, minBW, maxBW = 5, 20, 8000, 100, 1000
+    minCoeff, maxCoeff, minG, maxG = 10, 100, 0, 0
+    minBiasLinNonLin, maxBiasLinNonLin, N_f = 5, 20, 5
+    P, g_sd, SNRmin, SNRmax = 10, 2, 10, 40
+
+
+def synth_clip(L, seed):
+    return (0.1 * np.random.RandomState(seed).randn(L)).astype(np.float32)
+
+
+def gen_rawboost():
+    from datautils import RawBoost as R
+    import datautils.asvspoof_2019_augall_3 as D
+    out = {}
+    L = 4000
+    for seed in (0, 1):
+        x = synth_clip(L, 100 + seed)
+        out["x_s%d" % seed] = x
+        for algo in range(0, 9):
+            np.random.seed(1000 * algo + seed)
+            y = D.process_Rawboost_feature(x, 16000, Args(), algo)
+            out["algo%d_s%d" % (algo, seed)] = np.asarray(y)
+    # one clip at a BASELINE config-1 length through LnL only, louder so that normWav triggers
+    x = (0.9 * np.random.RandomState(7).randn(16000)).astype(np.float32)
+    np.random.seed(77)
+    a = Args()
+    out["x_long"] = x
+    out["lnl_long"] = R.LnL_convolutive_noise(x, a.N_f, a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff,
+                                              a.maxCoeff, a.minG, a.maxG, a.minBiasLinNonLin, a.maxBiasLinNonLin, 16000)
+    # notch design + centred FIR on their own
+    for seed in (3, 4, 5):
+        np.random.seed(seed)
+        b = R.genNotchCoeffs(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, -5, -20, 16000)
+        out["notch_b_s%d" % seed] = b
+    out["fir_y"] = R.filterFIR(out["x_s0"], out["notch_b_s3"])
+    # eval-side pad (augall_3:49-60)
+    xs = synth_clip(700, 9)
+    out["pad_in"] = xs
+    out["pad_repeat"] = D.pad(xs, "repeat", 2000)
+    out["pad_zero"] = D.pad(xs, "zero", 2000)
+    out["pad_cut"] = D.pad(synth_clip(2500, 10), "zero", 2000)
+    np.savez_compressed(os.path.join(OUT, "rawboost.npz"), **out)
+    print("rawboost.npz", len(out), "arrays")
+
+
+def gen_multiview():
+    from core_scripts.data_io import wav_augmentation as A
+    out = {}
+    lens = {"longer": [5000, 4000, 6500, 5000], "shorter": [900, 1300, 500, 900], "exact": [2000, 2500, 100]}
+    for name, ls in lens.items():
+        views = [synth_clip(l, 20 + i)[:, None].astype(np.float64) for i, l in enumerate(ls)]
+        for i, v in enumerate(views):
+            out["%s_in%d" % (name, i)] = v
+        for rp in (False, True):
+            np.random.seed(5)
+            res = A.batch_pad_for_multiview(views, 16000, 2000, random_trim_nosil=True, repeat_pad=rp)
+            for i, v in enumerate(res):
+                out["%s_rp%d_out%d" % (name, int(rp), i)] = v
+    np.savez_compressed(os.path.join(OUT, "multiview.npz"), **out)
+    print("multiview.npz", len(out), "arrays")
+
+
+def gen_pack():
+    """Dataset_for.__getitem__ (augall_3:103-146) on in-memory 'files', RawBoost12 online only."""
+    import datautils.asvspoof_2019_augall_3 as D
+    files = {}
+    ids = ["a.flac", "b.flac", "c.flac", "d.flac"]
+    vocoders = ["hifigan", "waveglow"]
+    rs = np.random.RandomState(1)
+    for i, u in enumerate(ids):
+        files[os.path.join("/syn/", "bonafide", u)] = (0.1 * rs.randn(3000 + 400 * i)).astype(np.float32)
+        for v in vocoders:
+            files[os.path.join("/syn/", "vocoded", v + "_" + u)] = (0.1 * rs.randn(3000 + 400 * i - 37)).astype(np.float32)
+    D.librosa.load = lambda path, sr=16000, mono=True: (files[path], sr)
+    args = Args()
+    ds = D.Dataset_for(args, list_IDs=ids, labels=[], base_dir="/syn/", algo=5, vocoders=vocoders,
+                       augmentation_methods=["RawBoost12"], num_additional_real=1, trim_length=2000,
+                       wav_samp_rate=16000, online_aug=True, aug_dir="/tmp/x", repeat_pad=True)
+    out = {"ids": np.array(ids), "vocoders": np.array(vocoders)}
+    for k, v in files.items():
+        out["file:" + k] = v
+    for idx in (0, 2):
+        np.random.seed(40 + idx)
+        uid, data, label = ds[idx]
+        out["pack%d_data" % idx] = data.numpy()
+        out["pack%d_label" % idx] = label.numpy()
+        out["pack%d_id" % idx] = np.array(uid)
+    np.savez_compressed(os.path.join(OUT, "pack.npz"), **out)
+    print("pack.npz", len(out), "arrays")
+
+
+def gen_head_loss():
+    """Reference Model (linear head) with an injected encoder: BackEnd / _forward / loss / supcon."""
+    import model.wav2vec2_linear_nll as M
+    from model.loss_metrics import supcon_loss
+    from oracle import head as OH
+    E = 64
+
+    class Enc(torch.nn.Module):
+        out_dim = E
+
+        def extract_feat(self, x, is_train=True):
+            return x  # the test feeds encoder features directly
+
+    M.SSLModel = lambda device: Enc()
+    torch.manual_seed(3)
+    m = M.Model({"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}, "cpu")
+    m.eval()
+    out = {}
+    hsd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in hsd.items():
+        out["sd:" + k] = v.numpy()
+    B, T = 6, 49
+    x = torch.randn(B, T, E)
+    y = torch.tensor([1, 1, 1, 0, 0, 0])
+    x.requires_grad_(True)
+    o, feats, emb = m(x)
+    losses = m.loss(o, feats, emb, y, {"model": {"contra_mode": "all", "loss_type": 1}})
+    total = sum(losses.values())
+    total.backward()
+    out.update(x=x.detach().numpy(), y=y.numpy(), out=o.detach().numpy(), feats=feats.detach().numpy(),
+               emb=emb.detach().numpy(), grad_x=x.grad.numpy(), grad_LL_weight=m.LL.weight.grad.numpy(),
+               grad_utt_weight=m.backend.m_utt_level.weight.grad.numpy(),
+               grad_frame0_weight=m.backend.m_frame_level[0].weight.grad.numpy())
+    for k, v in losses.items():
+        out["loss:" + k] = np.array(v.item())
+    # supcon on its own: seeds -> expected loss and a gradient fingerprint (inputs regenerated from the seed)
+    rows = []
+    for bz, T2, d, seed in ((4, 49, 128, 0), (11, 199, 128, 1), (64, 49, 128, 2), (11, 128, 1, 3), (32, 199, 128, 4)):
+        torch.manual_seed(seed)
+        f = torch.randn(bz, 1, T2, d, requires_grad=True)
+        lab = torch.tensor(([1] * ((5 * bz + 10) // 11) + [0] * bz)[:bz])
+        l = supcon_loss(f, labels=lab)
+        l.backward()
+        rows.append([bz, T2, d, seed, l.item(), f.grad.norm().item(), f.grad[0, 0, 0, 0].item(), f.grad[-1, 0, -1, -1].item()])
+    out["supcon_cases"] = np.array(rows, dtype=np.float64)
+    # the single-member-class NaN (loss_metrics.py:202)
+    torch.manual_seed(9)
+    f = torch.randn(4, 1, 10, 8)
+    out["supcon_nan"] = np.array(supcon_loss(f, labels=torch.tensor([1, 0, 0, 0])).item())
+    np.savez_compressed(os.path.join(OUT, "head_loss.npz"), **out)
+    print("head_loss.npz", len(out), "arrays")
+
+
+def gen_train_step():
+    """One train_epoch iteration (main.py:53-80) of the reference Model whose encoder is the
+    oracle's wav2vec2 restatement (tiny config), AdamW as main.py:339."""
+    import model.wav2vec2_linear_nll as M
+    from oracle import wav2vec2 as W
+    cfg = W.W2VConfig.tiny()
+
+    class Enc(torch.nn.Module):
+        out_dim = cfg.embed
+
+        def __init__(self):
+            super().__init__()
+            sd = W.init_state(cfg, seed=11)
+            self.names = list(sd)
+            self.model = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v) for k, v in sd.items()})
+
+        def sd(self):
+            return {k: self.model[k.replace(".", "/")] for k in self.names}
+
+        def extract_feat(self, x, is_train=True):
+            return W.forward(self.sd(), cfg, x)
+
+    M.SSLModel = lambda device: Enc()
+    torch.manual_seed(5)
+    m = M.Model({"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}, "cpu")
+    m.eval()  # dropout off (its RNG cannot be shared); everything else as train_epoch
+    out = {}
+    for k, v in m.state_dict().items():
+        if not k.startswith("ssl_model"):
+            out["sd:" + k] = v.detach().clone().numpy()
+    g = torch.Generator().manual_seed(1234)
+    x = 0.1 * torch.randn(4, 4000, generator=g)
+    y = torch.tensor([1, 1, 0, 0])
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)  # larger lr so the update is visible in fp32
+    o, feats, emb = m(x)
+    losses = m.loss(o, feats, emb, y, {"model": {"contra_mode": "all", "loss_type": 1}})
+    train_loss = 0.0
+    for k, v in losses.items():
+        train_loss = train_loss + v
+    opt.zero_grad()
+    train_loss.backward()
+    enc = m.ssl_model
+    probe = ["feature_extractor.conv_layers.0.0.weight", "feature_extractor.conv_layers.3.0.weight",
+             "feature_extractor.conv_layers.6.2.1.weight", "post_extract_proj.weight",
+             "encoder.pos_conv.0.weight_g", "encoder.pos_conv.0.weight_v",
+             "encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.0.self_attn.k_proj.bias",
+             "encoder.layers.1.fc2.weight", "encoder.layers.1.final_layer_norm.bias", "encoder.layer_norm.weight"]
+    for p in probe:
+        out["grad:ssl_model.model." + p] = enc.model[p.replace(".", "/")].grad.numpy().copy()
+    out["grad:LL.weight"] = m.LL.weight.grad.numpy().copy()
+    out["grad:backend.m_utt_level.bias"] = m.backend.m_utt_level.bias.grad.numpy().copy()
+    opt.step()
+    for p in probe:
+        out["post:ssl_model.model." + p] = enc.model[p.replace(".", "/")].detach().numpy().copy()
+    out["post:LL.weight"] = m.LL.weight.detach().numpy().copy()
+    out.update(x=x.numpy(), y=y.numpy(), out=o.detach().numpy(), emb=emb.detach().numpy(),
+               feats=feats.detach().numpy(), total_loss=np.array(train_loss.item()))
+    for k, v in losses.items():
+        out["loss:" + k] = np.array(v.item())
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("train_step.npz", len(out), "arrays")
+
+
+def gen_w2v_hf():
+    """Pin the wav2vec2 restatement against transformers.Wav2Vec2Model with copied weights."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    from oracle import wav2vec2 as W
+
+    def hf_model(cfg):
+        hc = Wav2Vec2Config(hidden_size=cfg.embed, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                            intermediate_size=cfg.ffn, conv_dim=[cfg.conv_dim] * 7, conv_kernel=list(cfg.conv_kernels),
+                            conv_stride=list(cfg.conv_strides), feat_extract_norm="layer", do_stable_layer_norm=True,
+                            conv_bias=True, num_conv_pos_embeddings=cfg.pos_k,
+                            num_conv_pos_embedding_groups=cfg.pos_groups, hidden_dropout=0.0, attention_dropout=0.0,
+                            activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, final_dropout=0.0,
+                            mask_time_prob=0.0, hidden_act="gelu", apply_spec_augment=False)
+        return Wav2Vec2Model(hc).eval()
+
+    cfg = W.W2VConfig.tiny()
+    sd = W.init_state(cfg, seed=11)
+    hf = hf_model(cfg)
+    hsd = {k: v for k, v in W.to_hf_state(sd, cfg).items() if k in hf.state_dict()}
+    missing, unexpected = hf.load_state_dict(hsd, strict=False)
+    assert not unexpected and all("masked_spec" in k for k in missing), (missing, unexpected)
+    g = torch.Generator().manual_seed(1234)
+    x = 0.1 * torch.randn(2, 4000, generator=g)
+    with torch.no_grad():
+        ho = hf(x, output_hidden_states=True)
+        mine, inter = W.forward(sd, cfg, x, return_all=True)
+    err = (mine - ho.last_hidden_state).abs().max().item()
+    print("tiny wav2vec2 vs HF max abs err: %.3e" % err)
+    assert err < 1e-4
+    out = {"x": x.numpy(), "hf_last_hidden": ho.last_hidden_state.numpy(),
+           "hf_extract_features": ho.extract_features.numpy(), "seed": np.array(11)}
+    np.savez_compressed(os.path.join(OUT, "w2v_tiny_hf.npz"), **out)
+    if os.environ.get("SCL_GOLDEN_FULL") == "1":  # in-container only: XLS-R-300M shape, 1 x 16000
+        cfg = W.W2VConfig()
+        sd = W.init_state(cfg, seed=12)
+        hf = hf_model(cfg)
+        hf.load_state_dict({k: v for k, v in W.to_hf_state(sd, cfg).items() if k in hf.state_dict()}, strict=False)
+        x = 0.1 * torch.randn(1, 16000, generator=g)
+        with torch.no_grad():
+            e = (W.forward(sd, cfg, x) - hf(x).last_hidden_state).abs().max().item()
+        print("full-size wav2vec2 vs HF max abs err: %.3e" % e)
+
+
+def gen_eer():
+    from evaluate_metrics import compute_eer
+    out = {}
+    # merges as Result.ipynb cells 4 and 13 do: LA19 protocol = "sid utt phy attack label" filtered to LA_E and
+    # joined on the score file's utt with ".flac" stripped; In-the-Wild protocol = "path subset label"
+    for tag, score_file, proto, keycol, strip in (
+            ("la19_conf3", "docs/asvspoof2019_conf-3.txt", "DATA/asvspoof_2019_supcon/protocol.txt", 1, True),
+            ("itw_conf3", "docs/inwild_conf-3.txt", "DATA/in_the_wild/protocol.txt", 0, False)):
+        lab = {}
+        with open(os.path.join(REF, proto)) as f:
+            for line in f:
+                p = line.split()
+                if len(p) >= 3 and (not strip or "LA_E" in p[keycol]):
+                    lab[p[keycol]] = p[-1]
+        scores, labels = [], []
+        with open(os.path.join(REF, score_file)) as f:
+            for line in f:
+                p = line.split()
+                key = p[0].split(".")[0] if strip else p[0]
+                if key in lab:
+                    scores.append(float(p[1]))
+                    labels.append(1 if lab[key] == "bonafide" else 0)
+        s, l = np.array(scores), np.array(labels)
+        full_eer, full_thr = compute_eer(s[l == 1], s[l == 0])
+        print(tag, "full EER %.7f thr %.7f n=%d" % (full_eer, full_thr, len(s)))
+        idx = np.arange(0, len(s), 20)
+        ss, ll = s[idx], l[idx]
+        eer, thr = compute_eer(ss[ll == 1], ss[ll == 0])
+        out[tag + "_scores"] = ss
+        out[tag + "_labels"] = ll.astype(np.int8)
+        out[tag + "_eer_thr"] = np.array([eer, thr])
+        out[tag + "_full_eer_thr_n"] = np.array([full_eer, full_thr, len(s)])
+    np.savez_compressed(os.path.join(OUT, "eer.npz"), **out)
+    print("eer.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
+    import_reference()
+    gen_rawboost()
+    gen_multiview()
+    gen_pack()
+    gen_head_loss()
+    gen_train_step()
+    gen_eer()

@@ -66,7 +66,7 @@ def filter_fir(x, b):
 
 def lnl_apply(x, taps):
     """RawBoost.py:59-69 with the N_f tap vectors given."""
-    x = np.asarray(x, dtype=np.float64)
+    x = np.asarray(x)  # powers are taken in the input dtype (float32 clips stay float32 here), as np.power does
     y = np.zeros(x.shape[0])
     for i, b in enumerate(taps):
         y = y + filter_fir(np.power(x, i + 1), b)
