@@ -106,6 +106,111 @@ int scl_gemm_bf16(const SclGemmDesc* desc, void* stream);
 /* out[i] = sum_s slabs[s*stride + i]  (deterministic split-K combine). */
 int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* LayerNorm (+GELU), column reductions                                                        */
+/* ------------------------------------------------------------------------------------------ */
+/* y = act(LN(x) * gamma + beta) per row of [M, C]; x f32 or bf16; y to bf16 and/or f32; saves mean / rstd.
+ * act: 0 none, 1 gelu.  Replaces fairseq Fp32LayerNorm / nn.LayerNorm (+ nn.GELU in the conv stack)
+ * inside Wav2Vec2Model.forward (model/xlsr.py:41). */
+int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                      float* mean, float* rstd, int M, int C, int64_t ldx, int64_t ldy, float eps, int act, void* stream);
+/* number of row-slab partials scl_layernorm_bwd writes for M rows */
+int scl_layernorm_bwd_nparts(int M);
+/* dx = LN'(dy [* gelu'(.)]) (+ dres); per-slab partial sums of dgamma/dbeta into dgamma_part/dbeta_part
+ * [nparts, C] (combine with scl_colreduce_f32).  Autograd backward of the above (main.py:79). */
+int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
+                      float* dgamma_part, float* dbeta_part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx,
+                      int act, void* stream);
+int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream);
+/* bias gradients: part[p][n] = sum over row slab p of x[m][n]; nparts = scl_colsum_nparts(M) */
+int scl_colsum_nparts(int M);
+int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* element-wise glue                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+int scl_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int scl_add_f32(const float* a, const float* b, float* out, void* out_bf16, int64_t n, void* stream);
+/* dst[b][r][:] = src[b][r - pad_before][:] (* act'(pre)), zero outside [0,T): zero-padded operand of the
+ * grouped positional conv (fairseq encoder.pos_conv, padding = k/2) and of its dgrad. */
+int scl_pad_rows_bf16(const void* src, int src_f32, void* dst, const void* pre, int ract, int B, int T, int C,
+                      int rows_out, int pad_before, void* stream);
+/* conv-stack dgrad tail: dz[b][r][c] = sum_j dcol[b][(r-j)/s][j*C+c] (Conv1d backward-data, layers 1..6) */
+int scl_col2im_bf16(const void* dcol, void* dz, int B, int Tin, int Tout, int C, int k, int s, void* stream);
+/* Conv1d weight [co][ci][j] f32 <-> GEMM operand [co][j*Ci+ci] (bf16 forward copy / f32 gradient back) */
+int scl_conv_weight_pack(const float* w, void* wk, int Co, int Ci, int k, void* stream);
+int scl_conv_weight_unpack_grad(const float* dwk, float* dw, int Co, int Ci, int k, void* stream);
+/* torch.nn.utils.weight_norm(dim=2) of encoder.pos_conv.0 + GEMM layouts (forward and flipped dgrad) */
+int scl_posconv_weight_pack(const float* v, const float* g, float* norm, void* wf, void* wd, int E, int Cg, int K, void* stream);
+int scl_posconv_weight_bwd(const float* dwf, const float* v, const float* g, const float* norm, float* sdot_ws,
+                           float* dv, float* dg, int E, int Cg, int K, void* stream);
+/* tail of the linear head: mean over frames, m_utt_level, log_softmax (model/wav2vec2_linear_nll.py:88-93,134) */
+int scl_meanpool_fwd(const void* h, float* emb, int B, int T, int C, void* stream);
+int scl_meanpool_bwd(const float* demb, const void* pre, void* dpre, int B, int T, int C, int ract, float drop_p,
+                     uint32_t seed, void* stream);
+int scl_utt_head_fwd(const float* emb, const float* W, const float* bias, float* logp, int B, int C, int NC, void* stream);
+int scl_utt_head_bwd(const float* dlogp, const float* logp, const float* emb, const float* W, const float* demb_in,
+                     float* demb, float* dW, float* db, float* ws, int B, int C, int NC, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* attention softmax (between the QK^T and PV contractions)                                    */
+/* ------------------------------------------------------------------------------------------ */
+int scl_softmax_fwd(const float* S, void* P, int64_t R, int T, int ldS, int Tp, void* stream);
+int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, int lddP, int Tp, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* feature-extractor layer 0 (Conv1d(1,C,10,5) + LayerNorm + GELU), fused fwd / bwd            */
+/* ------------------------------------------------------------------------------------------ */
+int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, void* z,
+                  int B, int L, int C, int k, int stride, float eps, void* stream);
+int scl_conv0_bwd_nparts(int B, int L, int k, int stride);
+int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const void* dz,
+                  float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L, int C, int k, int stride,
+                  float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
+/* ------------------------------------------------------------------------------------------ */
+int scl_supcon_nchunks(int64_t K);
+int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int64_t K, int64_t ldF, int Tprime, float temperature,
+                   float* ws, float* G, float* loss_out, float* S_out, void* stream);
+int scl_supcon_bwd(const float* F, const float* G, const float* upstream, float coef, int bz, int64_t K, int64_t ldF,
+                   int Tprime, float temperature, float* dF, void* dF_bf16, int accumulate, void* stream);
+int scl_nll_fwd(const float* logp, const int64_t* labels, int bz, int NC, float* loss_out, float* dlogp_coef, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* optimizer: torch.optim.AdamW semantics over a flat buffer (main.py:339,80)                  */
+/* ------------------------------------------------------------------------------------------ */
+int scl_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* waveform augmentation (datautils/RawBoost.py, datautils/audio_augmentor/*, wav_augmentation.py) */
+/* ------------------------------------------------------------------------------------------ */
+/* y[c][n] = sum_{f<nf} sum_k taps_f[k] * x[c][n + h_f - k]^(use_pow ? f+1 : 1), n in [0,Lout), x zero outside [0,Lin).
+ * filterFIR: h = (len+1)/2, Lout = Lin; np.convolve full (reverb): h = 0, Lout = Lin+len-1.
+ * part (optional): per clip and 2048-sample block (sum, min, max, sumsq) of y. */
+int scl_fir_nblocks(int Lout);
+int scl_fir_multi_f32(const float* x, int64_t ldx, int Lin, const float* taps, const int* tap_off, const int* tap_len,
+                      const int* tap_h, int nclip, int nf, int use_pow, float* y, int64_t ldy, int Lout, float* part, void* stream);
+int scl_clip_stats_f32(const float* x, int64_t ldx, int L, int nclip, float* part, void* stream);
+int scl_isd_scatter_f32(float* y, int64_t ldy, const int* pos, const float* fr, const int* clip_off, int nclip, int max_per_clip,
+                        float g_sd, void* stream);
+#define SCL_AFF_CENTER_PEAK_COND 0  /* y - mean(y), then / max|.| iff > 1           (LnL tail, RawBoost.py:67-68)  */
+#define SCL_AFF_PEAK_COND        1  /* normWav(x, 0)                                (ISD tail, RawBoost.py:83)     */
+#define SCL_AFF_PEAK_ALWAYS      2  /* normWav(x, 1)                                                               */
+#define SCL_AFF_SSI_MIX          3  /* z + x * ||z|| / ||x|| / 10^(snr/20)          (RawBoost.py:93-96)            */
+#define SCL_AFF_PEAK_QUANT_I16   4  /* int16(x / max|x| * 32768) by C cast, as float (reverb.py:41-44, utils.py:26) */
+int scl_clip_affine_f32(int mode, const float* x, int64_t ldx, const float* z, int64_t ldz, const float* partx, const float* partz,
+                        const float* snr_db, float* out, int64_t ldo, int L, int nclip, void* stream);
+int scl_f32_to_i16_wrap(const float* x, void* out_i16, int64_t n, void* stream);
+int scl_i16_sumsq(const void* x_i16, int64_t n, uint64_t* part64, int nparts, void* stream);
+int scl_i16_gain_overlay(const void* speech_i16, int64_t n, const void* noise_i16, int64_t nn, double factor, float* out_f32,
+                         void* out_i16, void* stream);
+int scl_multiview_crop_f32(const float* src, const int64_t* off, const int* len, int V, int firstlen, int start, int out_len,
+                           int repeat_pad, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,240 @@
+// conv0.hip — first layer of the wav2vec2 feature extractor, forward and backward, fully fused:
+//   z[b][t][c] = GELU( LayerNorm_c( bias[c] + sum_j w[c][j] * x[b][stride*t + j] ) )
+// (fairseq ConvFeatureExtractionModel layer 0: Conv1d(1, C, k=10, stride=5, bias) -> Fp32LayerNorm
+// over channels -> GELU, reached from model/xlsr.py:41).  C_in = 1 makes this layer HBM-bound
+// (output [B, 12799, 512] bf16 = 13 MB per utterance), so it is not a GEMM: one wave owns one frame,
+// 8 channels per lane, taps and the waveform slab staged in LDS, LayerNorm statistics by wave
+// shuffles, 16-byte coalesced bf16 stores.  The backward recomputes the pre-norm activation from the
+// waveform instead of saving it and reduces dW / dbias / dgamma / dbeta per block, deterministically.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 16;
+constexpr int MAXCH0 = 2;  // C <= 1024
+
+struct Conv0Smem {
+    float* wT;   // [k][C]
+    float* xs;   // [rows*stride + k]
+    float* red;  // [C*(k+3)]  (backward only)
+};
+
+__device__ __forceinline__ void conv0_stage(float* wT, float* xs, const float* __restrict__ w, const float* __restrict__ x,
+                                            int C, int k, int L, int x0, int nx) {
+    for (int i = threadIdx.x; i < C * k; i += blockDim.x) {
+        const int c = i / k, j = i % k;
+        wT[j * C + c] = w[i];
+    }
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) xs[i] = (x0 + i) < L ? x[x0 + i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ z, int L, int T0,
+                                                        int C, int k, int stride, int rows_per_block, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm0[];
+    float* wT = sm0;
+    float* xs = sm0 + k * C;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * rows_per_block;
+    const int nrows = min(rows_per_block, T0 - t0);
+    const int nx = nrows * stride + k;
+    conv0_stage(wT, xs, w, x + (int64_t)b * L, C, k, L, t0 * stride, nx);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv; r < nrows; r += 4) {
+        float y[MAXCH0][8];
+        float s = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH0; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[ch][i] = bias[c + i];
+                for (int j = 0; j < k; ++j) {
+                    const float xv = xs[r * stride + j];
+                    const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
+                    y[ch][0] += w0.x * xv; y[ch][1] += w0.y * xv; y[ch][2] += w0.z * xv; y[ch][3] += w0.w * xv;
+                    y[ch][4] += w1.x * xv; y[ch][5] += w1.y * xv; y[ch][6] += w1.z * xv; y[ch][7] += w1.w * xv;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += y[ch][i];
+            }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH0; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = y[ch][i] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int ch = 0; ch < MAXCH0; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = gelu_f((y[ch][i] - mean) * rstd * gamma[c + i] + beta[c + i]);
+                uint4 u;
+                u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+                *reinterpret_cast<uint4*>(z + ((int64_t)b * T0 + t0 + r) * C + c) = u;
+            }
+        }
+    }
+}
+
+// part[blk][c*(k+3) + q]: q < k -> dW[c][q]; q == k -> dbias; k+1 -> dgamma; k+2 -> dbeta
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const bf16_t* __restrict__ dz,
+                                                        float* __restrict__ part, int L, int T0, int C, int k, int stride,
+                                                        int rows_per_block, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm0[];
+    float* wT = sm0;
+    float* red = sm0 + k * C;
+    float* xs = red + C * (k + 3);
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * rows_per_block;
+    const int nrows = min(rows_per_block, T0 - t0);
+    const int nx = nrows * stride + k;
+    conv0_stage(wT, xs, w, x + (int64_t)b * L, C, k, L, t0 * stride, nx);
+    for (int i = threadIdx.x; i < C * (k + 3); i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float aw[8][MAXK + 3];
+    if (C > 512) return;  // backward supports C <= 512 (one chunk of 8 channels per lane)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int q = 0; q < MAXK + 3; ++q) aw[i][q] = 0.f;
+    const int c = lane * 8;
+    const bool act = c < C;
+    for (int r = wv; r < nrows; r += 4) {
+        float y[8], g8[8], dzv[8];
+        float s = 0.f;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = bias[c + i];
+            for (int j = 0; j < k; ++j) {
+                const float xv = xs[r * stride + j];
+                const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
+                const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
+                y[0] += w0.x * xv; y[1] += w0.y * xv; y[2] += w0.z * xv; y[3] += w0.w * xv;
+                y[4] += w1.x * xv; y[5] += w1.y * xv; y[6] += w1.z * xv; y[7] += w1.w * xv;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += y[i];
+            const uint4 u = *reinterpret_cast<const uint4*>(dz + ((int64_t)b * T0 + t0 + r) * C + c);
+            const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dzv[2 * i] = __uint_as_float(uw[i] << 16); dzv[2 * i + 1] = __uint_as_float(uw[i] & 0xFFFF0000u); }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = y[i] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float h = (y[i] - mean) * rstd;
+                const float gm = gamma[c + i];
+                const float dyn = dzv[i] * gelu_grad_f(h * gm + beta[c + i]);
+                aw[i][MAXK + 1] += dyn * h;  // dgamma
+                aw[i][MAXK + 2] += dyn;      // dbeta
+                const float dh = dyn * gm;
+                y[i] = h;      // xhat
+                g8[i] = dh;    // dxhat
+                s1 += dh; s2 += dh * h;
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dy = rstd * (g8[i] - s1 - y[i] * s2);
+                aw[i][MAXK] += dy;  // dbias
+#pragma unroll
+                for (int j = 0; j < MAXK; ++j)
+                    if (j < k) aw[i][j] += dy * xs[r * stride + j];
+            }
+        }
+    }
+    // deterministic combine of the 4 waves
+    for (int ww = 0; ww < 4; ++ww) {
+        if (wv == ww && act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < MAXK; ++j)
+                    if (j < k) red[(c + i) * (k + 3) + j] += aw[i][j];
+                red[(c + i) * (k + 3) + k] += aw[i][MAXK];
+                red[(c + i) * (k + 3) + k + 1] += aw[i][MAXK + 1];
+                red[(c + i) * (k + 3) + k + 2] += aw[i][MAXK + 2];
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int i = threadIdx.x; i < C * (k + 3); i += blockDim.x) part[blk * C * (k + 3) + i] = red[i];
+}
+
+__global__ void conv0_reduce_kernel(const float* __restrict__ part, int nparts, int C, int k, float* __restrict__ dW,
+                                    float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = C * (k + 3);
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
+    const int c = i / (k + 3), q = i % (k + 3);
+    if (q < k) dW[c * k + q] = s;
+    else if (q == k) db[c] = s;
+    else if (q == k + 1) dgamma[c] = s;
+    else dbeta[c] = s;
+}
+
+}  // namespace
+
+static const int CONV0_BWD_ROWS = 512;
+
+extern "C" int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                             void* z, int B, int L, int C, int k, int stride, float eps, void* stream) {
+    SCL_REQUIRE(x && w && bias && gamma && beta && z, "conv0_fwd: null pointer");
+    SCL_REQUIRE(B > 0 && L >= k && C >= 8 && C <= 1024 && (C & 7) == 0 && k >= 1 && k <= MAXK && stride >= 1, "conv0_fwd: bad dims");
+    const int T0 = (L - k) / stride + 1;
+    const int rows = 128;
+    dim3 grid((T0 + rows - 1) / rows, B), block(256);
+    const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
+    hipLaunchKernelGGL(conv0_fwd_kernel, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (bf16_t*)z, L, T0, C, k, stride, rows, eps);
+    return scl_check_launch("scl_conv0_fwd");
+}
+
+extern "C" int scl_conv0_bwd_nparts(int B, int L, int k, int stride) {
+    const int T0 = (L - k) / stride + 1;
+    return B * ((T0 + CONV0_BWD_ROWS - 1) / CONV0_BWD_ROWS);
+}
+
+extern "C" int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                             const void* dz, float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L,
+                             int C, int k, int stride, float eps, void* stream) {
+    SCL_REQUIRE(x && w && bias && gamma && beta && dz && part_ws && dW && db && dgamma && dbeta, "conv0_bwd: null pointer");
+    SCL_REQUIRE(B > 0 && L >= k && C >= 8 && C <= 512 && (C & 7) == 0 && k >= 1 && k <= MAXK && stride >= 1, "conv0_bwd: bad dims (C <= 512)");
+    const int T0 = (L - k) / stride + 1;
+    const int rows = CONV0_BWD_ROWS;
+    dim3 grid((T0 + rows - 1) / rows, B), block(256);
+    const size_t lds = (size_t)(k * C + C * (k + 3) + rows * stride + k) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv0_bwd_kernel, grid, block, lds, s, x, w, bias, gamma, beta, (const bf16_t*)dz, part_ws, L, T0, C, k, stride, rows, eps);
+    const int nparts = grid.x * grid.y, n = C * (k + 3);
+    hipLaunchKernelGGL(conv0_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part_ws, nparts, C, k, dW, db, dgamma, dbeta);
+    return scl_check_launch("scl_conv0_bwd");
+}

@@ -1,0 +1,206 @@
+// loss.hip — supervised-contrastive loss with the reference's sequence similarity, and the NLL term.
+//
+// Reference: model/loss_metrics.py:85-209 (sim_metric_seq, supcon_loss) as called from
+// model/wav2vec2_linear_nll.py:158-192 (Model.loss): n_views = 1, contra_mode 'all', t = 0.07, no
+// length normalisation.  With F[i] = feats[i] flattened to K = T'*d values,
+//     S[i][j]   = <F[i], F[j]> / (T' * t)                        (bmm over frames, mean over frames, / t)
+//     m_i       = max_j S[i][j] * selfmask[i][j]                 (diagonal forced to 0, detached)
+//     logp[i][j]= (S[i][j] - m_i) - log sum_{j != i} exp(S[i][j] - m_i)
+//     loss      = - mean_i  sum_{j != i, y_j == y_i} logp[i][j] / #{j != i, y_j == y_i}   (0/0 -> NaN kept)
+// All of it in fp32 (the logits reach 1e2..1e4 because features are not normalised).
+// Three kernels: Gram partials over K-chunks, a single-workgroup loss + dL/dS kernel, and the
+// backward contraction dF = (dL/dS + dL/dS^T) F / (T' t).  The [T', bz, bz] temporary of the
+// reference's bmm is never materialised.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 64;  // K-chunk staged in LDS per step
+
+// part[chunk][i][j] = sum_{k in chunk} F[i][k] F[j][k];   grid.x = number of chunks
+__global__ __launch_bounds__(256) void supcon_gram_kernel(const float* __restrict__ F, float* __restrict__ part, int bz,
+                                                          int64_t K, int64_t ldF, int64_t kchunk) {
+    extern __shared__ float sm[];  // [bz][KC+1]
+    const int64_t k0 = (int64_t)blockIdx.x * kchunk;
+    const int64_t k1 = min(K, k0 + kchunk);
+    const int npairs = bz * bz;
+    // each thread owns pairs p = tid, tid+256, ...  (<= 64 pairs per thread for bz <= 128)
+    float acc[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) acc[q] = 0.f;
+    for (int64_t kb = k0; kb < k1; kb += KC) {
+        const int kn = (int)min((int64_t)KC, k1 - kb);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < bz * KC; idx += 256) {
+            const int i = idx / KC, kk = idx % KC;
+            sm[i * (KC + 1) + kk] = kk < kn ? F[(int64_t)i * ldF + kb + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            const int p = threadIdx.x + q * 256;
+            if (p < npairs) {
+                const int i = p / bz, j = p % bz;
+                float s = 0.f;
+                for (int kk = 0; kk < KC; ++kk) s += sm[i * (KC + 1) + kk] * sm[j * (KC + 1) + kk];
+                acc[q] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        const int p = threadIdx.x + q * 256;
+        if (p < npairs) part[(int64_t)blockIdx.x * npairs + p] = acc[q];
+    }
+}
+
+// single block: S = sum(parts) * scale; loss; G[i][j] = dloss/dS[i][j]
+__global__ __launch_bounds__(256) void supcon_loss_kernel(const float* __restrict__ part, int nparts, const int64_t* __restrict__ labels,
+                                                          int bz, float scale, float* __restrict__ loss_out, float* __restrict__ G,
+                                                          float* __restrict__ S_out) {
+    extern __shared__ float sm[];  // S [bz*bz], rowloss [bz]
+    float* S = sm;
+    float* rowloss = sm + bz * bz;
+    const int npairs = bz * bz;
+    for (int p = threadIdx.x; p < npairs; p += 256) {
+        float s = 0.f;
+        for (int c = 0; c < nparts; ++c) s += part[(int64_t)c * npairs + p];
+        S[p] = s * scale;
+        if (S_out) S_out[p] = s * scale;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < bz; i += 4) {
+        const int64_t yi = labels[i];
+        float mx = -INFINITY;
+        for (int j = lane; j < bz; j += 64) mx = fmaxf(mx, j == i ? 0.f : S[i * bz + j]);  // logits * self_mask
+        mx = wave_max(mx);
+        float se = 0.f, npos = 0.f, spos = 0.f;
+        for (int j = lane; j < bz; j += 64) {
+            if (j == i) continue;
+            const float l = S[i * bz + j] - mx;
+            se += expf(l);
+            if (labels[j] == yi) { npos += 1.f; spos += l; }
+        }
+        se = wave_sum(se); npos = wave_sum(npos); spos = wave_sum(spos);
+        const float lse = logf(se);
+        const float mlpp = (spos - npos * lse) / npos;  // 0/0 -> NaN as the reference
+        if (lane == 0) rowloss[i] = -mlpp;
+        // d(-mlpp_i)/dS[i][j] = -( pos_ij / npos - exp(l_ij) / se ), j != i ; times 1/bz for the mean
+        for (int j = lane; j < bz; j += 64) {
+            float g = 0.f;
+            if (j != i) {
+                const float l = S[i * bz + j] - mx;
+                g = -((labels[j] == yi ? 1.f / npos : 0.f) - expf(l) / se) / (float)bz;
+            }
+            G[i * bz + j] = g;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < bz; ++i) s += rowloss[i];
+        *loss_out = s / (float)bz;
+    }
+}
+
+// dF[i][k] (+)= upstream * scale * sum_j (G[i][j] + G[j][i]) F[j][k]
+__global__ __launch_bounds__(256) void supcon_bwd_kernel(const float* __restrict__ F, const float* __restrict__ G,
+                                                         const float* __restrict__ upstream, float coef, float* __restrict__ dF,
+                                                         bf16_t* __restrict__ dF_bf, int bz, int64_t K, int64_t ldF, int accumulate) {
+    extern __shared__ float sm[];  // Gs [bz*bz]
+    for (int p = threadIdx.x; p < bz * bz; p += 256) {
+        const int i = p / bz, j = p % bz;
+        sm[p] = G[i * bz + j] + G[j * bz + i];
+    }
+    __syncthreads();
+    const float c = coef * (upstream ? *upstream : 1.f);
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    // column k of F for all j (coalesced across threads), then the bz outputs
+    for (int i0 = 0; i0 < bz; i0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < bz; ++j) {
+            const float f = F[(int64_t)j * ldF + k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q < bz) acc[q] += sm[(i0 + q) * bz + j] * f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i0 + q < bz) {
+                const int64_t o = (int64_t)(i0 + q) * ldF + k;
+                float v = c * acc[q];
+                if (accumulate) v += dF[o];
+                dF[o] = v;
+                if (dF_bf) dF_bf[o] = f2bf(v);
+            }
+        }
+    }
+}
+
+// NLL as the reference computes it: CrossEntropyLoss applied to log-probs, mean over the batch, then / bz.
+//   loss = (1/bz) * mean_i ( -log_softmax(logp_i)[y_i] );  dlogp = upstream * (softmax(logp_i) - onehot) / bz^2
+__global__ void nll_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels, int bz, int NC,
+                           float* __restrict__ loss_out, float* __restrict__ dlogp_coef) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < bz; i += blockDim.x) {
+        float mx = -INFINITY;
+        for (int k = 0; k < NC; ++k) mx = fmaxf(mx, logp[i * NC + k]);
+        float se = 0.f;
+        for (int k = 0; k < NC; ++k) se += expf(logp[i * NC + k] - mx);
+        const float lse = mx + logf(se);
+        const int y = (int)labels[i];
+        s += -(logp[i * NC + y] - lse);
+        for (int k = 0; k < NC; ++k)
+            dlogp_coef[i * NC + k] = (expf(logp[i * NC + k] - lse) - (k == y ? 1.f : 0.f)) / ((float)bz * (float)bz);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < blockDim.x; ++i) t += red[i];
+        *loss_out = t / ((float)bz * (float)bz);
+    }
+}
+
+}  // namespace
+
+extern "C" int scl_supcon_nchunks(int64_t K) {
+    int64_t n = (K + 1023) / 1024;
+    if (n > 512) n = 512;
+    return (int)(n < 1 ? 1 : n);
+}
+
+// F f32 [bz, K] (row stride ldF); labels int64 [bz]; ws: nchunks*bz*bz floats; G: bz*bz floats.
+// loss_out = supcon_loss(feats) exactly as the reference returns it (before Model.loss's extra 1/bz).
+extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int64_t K, int64_t ldF, int Tprime, float temperature,
+                              float* ws, float* G, float* loss_out, float* S_out, void* stream) {
+    SCL_REQUIRE(F && labels && ws && G && loss_out, "supcon_fwd: null pointer");
+    SCL_REQUIRE(bz >= 1 && bz <= 128 && K >= 1 && Tprime >= 1 && temperature > 0.f, "supcon_fwd: need 1 <= bz <= 128");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = scl_supcon_nchunks(K);
+    int64_t kchunk = (K + nch - 1) / nch;
+    kchunk = (kchunk + KC - 1) / KC * KC;
+    const int nch_eff = (int)((K + kchunk - 1) / kchunk);
+    hipLaunchKernelGGL(supcon_gram_kernel, dim3(nch_eff), dim3(256), (size_t)bz * (KC + 1) * sizeof(float), s, F, ws, bz, K, ldF, kchunk);
+    hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(256), (size_t)(bz * bz + bz) * sizeof(float), s, ws, nch_eff, labels, bz,
+                       1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
+    return scl_check_launch("scl_supcon_fwd");
+}
+
+// dF (+)= (*upstream) * coef / (T' t) * (G + G^T) F      (coef carries Model.loss's 1/bz)
+extern "C" int scl_supcon_bwd(const float* F, const float* G, const float* upstream, float coef, int bz, int64_t K, int64_t ldF,
+                              int Tprime, float temperature, float* dF, void* dF_bf16, int accumulate, void* stream) {
+    SCL_REQUIRE(F && G && dF && bz >= 1 && bz <= 128 && K >= 1, "supcon_bwd: bad args");
+    hipLaunchKernelGGL(supcon_bwd_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), (size_t)bz * bz * sizeof(float), (hipStream_t)stream,
+                       F, G, upstream, coef / ((float)Tprime * temperature), dF, (bf16_t*)dF_bf16, bz, K, ldF, accumulate);
+    return scl_check_launch("scl_supcon_bwd");
+}
+
+extern "C" int scl_nll_fwd(const float* logp, const int64_t* labels, int bz, int NC, float* loss_out, float* dlogp_coef, void* stream) {
+    SCL_REQUIRE(logp && labels && loss_out && dlogp_coef && bz >= 1 && NC >= 1 && NC <= 8, "nll_fwd: bad args");
+    hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, labels, bz, NC, loss_out, dlogp_coef);
+    return scl_check_launch("scl_nll_fwd");
+}

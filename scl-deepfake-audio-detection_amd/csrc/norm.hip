@@ -1,0 +1,300 @@
+// norm.hip — LayerNorm over the channel dimension, forward and backward, with the optional fused
+// GELU of the wav2vec2 conv stack, plus the column reductions used for bias / affine gradients.
+//
+// Reference arithmetic: fairseq Fp32LayerNorm / nn.LayerNorm (eps 1e-5, biased variance, affine)
+// reached from model/xlsr.py:41 — conv layers `TransposeLast -> Fp32LayerNorm -> TransposeLast ->
+// GELU`, `layer_norm` before post_extract_proj, the two pre-LN norms of each encoder layer and
+// `encoder.layer_norm`.  Statistics are always fp32, whatever the storage dtype.
+//
+// One 64-lane wave owns one row: C/64 (<= 32) values per lane live in registers, mean / variance
+// are two wave-shuffle reductions, loads and stores are 16-byte (bf16x8) or 32-byte (f32x8) per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXCH = 4;  // chunks of 8 elements per lane -> C <= 64*8*4 = 2048
+
+template <bool F32>
+__device__ __forceinline__ void load8(const void* base, int64_t off, float (&v)[8]) {
+    if (F32) {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(base) + off);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* base, int64_t off, const float (&v)[8]) {
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(base + off) = u;
+}
+__device__ __forceinline__ void store8_f32(float* base, int64_t off, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(base + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <bool XF32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y_bf,
+                                                     float* __restrict__ y_f32, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int M, int C, int64_t ldx,
+                                                     int64_t ldy, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = ch * 512 + lane * 8;
+        if (c < C) {
+            load8<XF32>(x, (int64_t)row * ldx + c, v[ch]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[ch][i];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = ch * 512 + lane * 8;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[ch][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = ch * 512 + lane * 8;
+        if (c < C) {
+            float g[8], b[8], o[8];
+            load8<true>(gamma, c, g);
+            load8<true>(beta, c, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = (v[ch][i] - mean) * rstd * g[i] + b[i];
+                o[i] = act == 1 ? gelu_f(t) : t;
+            }
+            if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
+            if (y_f32) store8_f32(y_f32, (int64_t)row * ldy + c, o);
+        }
+    }
+}
+
+// Backward.  dy -> dx (optionally + residual gradient), per-block partial sums of dgamma / dbeta.
+// Each wave walks rows row0 + w, row0 + w + 4, ... of its block's slab and keeps the per-column
+// sums in registers; the four waves are combined through LDS.
+template <bool XF32, bool DYF32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ dres, float* __restrict__ dx_f32,
+                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ dgamma_part,
+                                                     float* __restrict__ dbeta_part, int M, int C, int64_t ldx,
+                                                     int64_t lddy, int64_t lddx, int rows_per_block, int act) {
+    extern __shared__ float red[];  // [4][2][C]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float ag[MAXCH][8], ab[MAXCH][8];
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ag[ch][i] = 0.f; ab[ch][i] = 0.f; }
+
+    for (int row = r0 + w; row < r1; row += 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[MAXCH][8], dyv[MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+                float xv[8], g[8];
+                load8<XF32>(x, (int64_t)row * ldx + c, xv);
+                load8<DYF32>(dy, (int64_t)row * lddy + c, dyv[ch]);
+                load8<true>(gamma, c, g);
+                if (act == 1) {
+                    float b[8];
+                    load8<true>(beta, c, b);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float h = (xv[i] - mean) * rstd;
+                        dyv[ch][i] *= gelu_grad_f(h * g[i] + b[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float h = (xv[i] - mean) * rstd;
+                    xh[ch][i] = h;
+                    ag[ch][i] += dyv[ch][i] * h;
+                    ab[ch][i] += dyv[ch][i];
+                    const float dh = dyv[ch][i] * g[i];
+                    dyv[ch][i] = dh;  // now dxhat
+                    s1 += dh;
+                    s2 += dh * h;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rstd * (dyv[ch][i] - s1 - xh[ch][i] * s2);
+                if (dres) {
+                    float r[8];
+                    load8<true>(dres, (int64_t)row * lddx + c, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] += r[i];
+                }
+                if (dx_f32) store8_f32(dx_f32, (int64_t)row * lddx + c, o);
+                if (dx_bf) store8_bf16(dx_bf, (int64_t)row * lddx + c, o);
+            }
+        }
+    }
+    // combine the 4 waves
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+        const int c = ch * 512 + lane * 8;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[(w * 2 + 0) * C + c + i] = ag[ch][i];
+                red[(w * 2 + 1) * C + c + i] = ab[ch][i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float g = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { g += red[(ww * 2 + 0) * C + c]; b += red[(ww * 2 + 1) * C + c]; }
+        dgamma_part[(int64_t)blockIdx.x * C + c] = g;
+        dbeta_part[(int64_t)blockIdx.x * C + c] = b;
+    }
+}
+
+// out[c] (+)= sum_p part[p][c]
+__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
+                                 int64_t pstride, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * pstride + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of a [M, N] matrix (bias gradients): part[rowchunk][n]
+template <bool F32>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ part, int M, int N,
+                                                     int64_t ld, int rows_per_block) {
+    __shared__ float red[16][128 + 1];
+    const int cg = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 128 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < N) {
+        for (int r = r0 + ty; r < r1; r += 16) {
+            float v[8];
+            load8<F32>(x, (int64_t)r * ld + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[ty][cg * 8 + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = blockIdx.x * 128 + threadIdx.x;
+        if (c < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];
+            part[(int64_t)blockIdx.y * N + c] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16,
+                                 float* y_f32, float* mean, float* rstd, int M, int C, int64_t ldx, int64_t ldy,
+                                 float eps, int act, void* stream) {
+    SCL_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
+    SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0,
+                "layernorm_fwd: need 8 <= C <= 2048, C, ldx, ldy multiples of 8 (C=%d)", C);
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_f32) hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act);
+    else hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act);
+    return scl_check_launch("scl_layernorm_fwd");
+}
+
+extern "C" int scl_layernorm_bwd_nparts(int M) {
+    int rows_per_block = 32;
+    while ((M + rows_per_block - 1) / rows_per_block > 1024) rows_per_block *= 2;
+    return (M + rows_per_block - 1) / rows_per_block;
+}
+
+extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, const float* dres,
+                                 float* dx_f32, void* dx_bf16, float* dgamma_part, float* dbeta_part, int M, int C,
+                                 int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream) {
+    SCL_REQUIRE(dy && x && mean && rstd && gamma && dgamma_part && dbeta_part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
+    SCL_REQUIRE(act == 0 || beta, "layernorm_bwd: gelu variant needs beta");
+    SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0,
+                "layernorm_bwd: need 8 <= C <= 2048 and multiples of 8");
+    int rows_per_block = 32;
+    while ((M + rows_per_block - 1) / rows_per_block > 1024) rows_per_block *= 2;
+    const int nblk = (M + rows_per_block - 1) / rows_per_block;
+    const size_t lds = (size_t)8 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblk), block(256);
+#define LN_BWD(XF, DF) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
+                                          dx_f32, (bf16_t*)dx_bf16, dgamma_part, dbeta_part, M, C, ldx, lddy, lddx, rows_per_block, act)
+    if (x_f32 && dy_f32) LN_BWD(true, true);
+    else if (x_f32) LN_BWD(true, false);
+    else if (dy_f32) LN_BWD(false, true);
+    else LN_BWD(false, false);
+#undef LN_BWD
+    return scl_check_launch("scl_layernorm_bwd");
+}
+
+extern "C" int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream) {
+    SCL_REQUIRE(part && out && nparts >= 1 && C >= 1, "colreduce: bad args");
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride, accumulate);
+    return scl_check_launch("scl_colreduce_f32");
+}
+
+extern "C" int scl_colsum_nparts(int M) {
+    int rows_per_block = 256;
+    while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    return (M + rows_per_block - 1) / rows_per_block;
+}
+
+extern "C" int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream) {
+    SCL_REQUIRE(x && part && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: bad args (N, ld multiples of 8)");
+    int rows_per_block = 256;
+    while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block);
+    else hipLaunchKernelGGL((colsum_kernel<false>), grid, block, 0, s, x, part, M, N, ld, rows_per_block);
+    return scl_check_launch("scl_colsum");
+}

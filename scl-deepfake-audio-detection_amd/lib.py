@@ -57,6 +57,51 @@ def _protos():
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
+        # norm.hip
+        "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
+        "scl_layernorm_bwd_nparts": ([_i32], _i32),
+        "scl_layernorm_bwd": ([_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64,
+                               _i64, _i32, _vp], _i32),
+        "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
+        "scl_colsum_nparts": ([_i32], _i32),
+        "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
+        # elementwise.hip
+        "scl_cast_f32_bf16": ([_vp, _vp, _i64, _vp], _i32),
+        "scl_add_f32": ([_vp, _vp, _vp, _vp, _i64, _vp], _i32),
+        "scl_pad_rows_bf16": ([_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_col2im_bf16": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_conv_weight_pack": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_conv_weight_unpack_grad": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_posconv_weight_pack": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_posconv_weight_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_meanpool_fwd": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_meanpool_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _vp], _i32),
+        "scl_utt_head_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_utt_head_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        # attention.hip
+        "scl_softmax_fwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
+        "scl_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
+        # conv0.hip
+        "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_conv0_bwd_nparts": ([_i32, _i32, _i32, _i32], _i32),
+        "scl_conv0_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        # loss.hip
+        "scl_supcon_nchunks": ([_i64], _i32),
+        "scl_supcon_fwd": ([_vp, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
+        "scl_supcon_bwd": ([_vp, _vp, _vp, _f32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp], _i32),
+        "scl_nll_fwd": ([_vp, _vp, _i32, _i32, _vp, _vp, _vp], _i32),
+        # optim.hip
+        "scl_adamw_flat": ([_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),
+        # augment.hip
+        "scl_fir_nblocks": ([_i32], _i32),
+        "scl_fir_multi_f32": ([_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp], _i32),
+        "scl_clip_stats_f32": ([_vp, _i64, _i32, _i32, _vp, _vp], _i32),
+        "scl_isd_scatter_f32": ([_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _vp], _i32),
+        "scl_clip_affine_f32": ([_i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+        "scl_f32_to_i16_wrap": ([_vp, _vp, _i64, _vp], _i32),
+        "scl_i16_sumsq": ([_vp, _i64, _vp, _i32, _vp], _i32),
+        "scl_i16_gain_overlay": ([_vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp], _i32),
+        "scl_multiview_crop_f32": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp], _i32),
     }
 
 

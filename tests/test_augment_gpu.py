@@ -1,0 +1,80 @@
+"""Parity of the waveform-augmentation kernels against the oracle (which is pinned to the
+reference) on the golden clips.  fp32 direct-form FIR vs the reference's float64: 2e-5 absolute on
+signals of O(0.1..1); int16 paths are bit-exact except where noted."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from scl_amd import augment as AUG  # noqa: E402
+from oracle import audio_int16 as AI  # noqa: E402
+from oracle import multiview as OM  # noqa: E402
+from oracle import rawboost as RB  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_rawboost_algos_match_reference_goldens(dev):
+    g = np.load(os.path.join(G, "rawboost.npz"))
+    args = RB.RawBoostArgs()
+    for seed in (0, 1):
+        x = g["x_s%d" % seed]
+        for algo in range(0, 9):
+            np.random.seed(1000 * algo + seed)   # the host sampler consumes np.random in the reference's order
+            xs = torch.from_numpy(x)[None].to(dev)
+            y = AUG.rawboost_batch(xs, args, algo, 16000)
+            ref = g["algo%d_s%d" % (algo, seed)]
+            err = np.abs(y[0].cpu().numpy().astype(np.float64) - ref).max()
+            assert err < 3e-5, "algo %d seed %d: %.3e" % (algo, seed, err)
+
+
+def test_lnl_long_clip_with_normalisation(dev):
+    g = np.load(os.path.join(G, "rawboost.npz"))
+    np.random.seed(77)
+    y = AUG.rawboost_batch(torch.from_numpy(g["x_long"])[None].to(dev), RB.RawBoostArgs(), 1, 16000)
+    assert np.abs(y[0].cpu().numpy() - g["lnl_long"]).max() < 3e-5
+
+
+def test_batched_clips_get_independent_draws(dev):
+    rs = np.random.RandomState(0)
+    xs = (0.1 * rs.randn(5, 6000)).astype(np.float32)
+    np.random.seed(3)
+    y = AUG.rawboost_batch(torch.from_numpy(xs).to(dev), RB.RawBoostArgs(), 5, 16000).cpu().numpy()
+    np.random.seed(3)
+    for i in range(5):
+        ref = RB.process_rawboost_feature(xs[i], 16000, RB.RawBoostArgs(), 5)
+        assert np.abs(y[i] - ref).max() < 3e-5
+
+
+def test_reverb_and_background_noise(dev):
+    rs = np.random.RandomState(1)
+    sp = (0.1 * rs.randn(5000)).astype(np.float32)
+    rir = (np.exp(-np.arange(900) / 120.0) * rs.randn(900)).astype(np.float32)
+    got = AUG.reverb(torch.from_numpy(sp).to(dev), torch.from_numpy(rir).to(dev)).cpu().numpy()
+    ref = AI.reverb(sp, rir).astype(np.float32)
+    assert got.shape == ref.shape
+    # fp32 summation order differs from numpy's: allow 1 LSB, and the +-32768 wrap at the peak sample
+    d = np.abs(got - ref)
+    assert (d <= 1).mean() > 0.999 and np.all((d <= 1) | (d >= 65535))
+    noise = (500 * rs.randn(4000)).astype(np.int16)
+    for snr in (5, 10, 15):
+        got = AUG.background_noise(torch.from_numpy(sp).to(dev), torch.from_numpy(noise).to(dev), snr).cpu().numpy()
+        ref, _ = AI.background_noise(sp, noise, snr)
+        assert np.array_equal(got, ref.astype(np.float32))
+    loud = np.array([1.0, -1.0, 0.99999, -0.00002, 0.5], np.float32)
+    assert AUG.to_int16(torch.from_numpy(loud).to(dev)).cpu().numpy().tolist() == AI.librosa_to_int16(loud).tolist()
+
+
+def test_multiview_crop_matches_reference_goldens(dev):
+    g = np.load(os.path.join(G, "multiview.npz"))
+    for name, n in (("longer", 4), ("shorter", 4), ("exact", 3)):
+        views = [g["%s_in%d" % (name, i)][:, 0].astype(np.float32) for i in range(n)]
+        for rp in (False, True):
+            np.random.seed(5)
+            out = AUG.multiview_crop([torch.from_numpy(v).to(dev) for v in views], 2000, rp).cpu().numpy()
+            for i in range(n):
+                ref = g["%s_rp%d_out%d" % (name, int(rp), i)][:, 0].astype(np.float32)
+                assert out[i].shape == ref.shape and np.array_equal(out[i], ref), (name, rp, i)

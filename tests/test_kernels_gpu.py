@@ -1,0 +1,257 @@
+"""Parity of every non-GEMM HIP kernel (through the C ABI) against plain torch fp32 references /
+the oracle.  Tolerances: fp32 kernels 1e-5..1e-4 relative to the tensor scale; bf16-output kernels
+one bf16 ulp (8e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from scl_amd import ops  # noqa: E402
+
+
+def rel(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("C,M", [(512, 130), (1024, 67), (32, 50), (64, 9)])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1])
+def test_layernorm_fwd_bwd(dev, C, M, xdt, act):
+    x = torch.randn(M, C, generator=g(1)).to(xdt).to(dev)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g(2))).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g(3))).to(dev)
+    y_bf = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    y_f = torch.empty(M, C, dtype=torch.float32, device=dev)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, y_bf, y_f, mean, rstd, M, C, act=act)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    if act:
+        ref = F.gelu(ref)
+    assert rel(y_f, ref) < 2e-5
+    assert rel(y_bf, ref) < 8e-3
+    assert rel(mean, x.float().mean(1)) < 1e-5
+    dy = torch.randn(M, C, generator=g(4)).to(dev)
+    dres = torch.randn(M, C, generator=g(5)).to(dev)
+    ref.backward(dy)
+    nparts = ops.layernorm_bwd_nparts(M)
+    dgp = torch.empty(nparts, C, device=dev); dbp = torch.empty(nparts, C, device=dev)
+    dx_f = torch.empty(M, C, device=dev); dx_b = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f, dx_b, dgp, dbp, M, C, act=act)
+    dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
+    ops.colreduce(dgp, dgam, nparts, C); ops.colreduce(dbp, dbet, nparts, C)
+    assert rel(dx_f, xr.grad + dres) < 5e-5
+    assert rel(dx_b, xr.grad + dres) < 8e-3
+    assert rel(dgam, gr.grad) < 5e-5 and rel(dbet, br.grad) < 5e-5
+    # bf16 dy variant
+    dyb = dy.to(torch.bfloat16)
+    ops.layernorm_bwd(dyb, x, mean, rstd, gamma, beta, None, dx_f, None, dgp, dbp, M, C, act=act)
+    xr.grad = None
+    ref2 = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    if act:
+        ref2 = F.gelu(ref2)
+    ref2.backward(dyb.float())
+    assert rel(dx_f, xr.grad) < 5e-5
+
+
+def test_colsum_and_cast_and_add(dev):
+    M, N = 1000, 264
+    x = torch.randn(M, N, generator=g(1)).to(dev)
+    for t in (x, x.to(torch.bfloat16)):
+        n = ops.colsum_nparts(M)
+        part = torch.empty(n, N, device=dev); out = torch.empty(N, device=dev)
+        ops.colsum(t, part, M, N)
+        ops.colreduce(part, out, n, N)
+        assert rel(out, t.float().sum(0)) < 1e-5
+    ops.colreduce(part, out, n, N, accumulate=True)
+    assert rel(out, 2 * x.to(torch.bfloat16).float().sum(0)) < 1e-5
+    d = torch.empty(M * N + 3, dtype=torch.bfloat16, device=dev)
+    src = torch.randn(M * N + 3, generator=g(2)).to(dev)
+    ops.cast_bf16(src, d)
+    assert torch.equal(d, src.to(torch.bfloat16))
+    a, b = torch.randn(999, generator=g(3)).to(dev), torch.randn(999, generator=g(4)).to(dev)
+    o = torch.empty(999, device=dev); ob = torch.empty(999, dtype=torch.bfloat16, device=dev)
+    ops.add_f32(a, b, o, ob, 999)
+    assert torch.equal(o, a + b) and torch.equal(ob, (a + b).to(torch.bfloat16))
+
+
+def test_pad_rows_col2im_weight_packs(dev):
+    B, T, C = 3, 21, 32
+    x = torch.randn(B, T, C, generator=g(1)).to(dev)
+    dst = torch.full((B, T + 10, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.pad_rows(x, dst, B, T, C, T + 10, 4)
+    ref = torch.zeros(B, T + 10, C, device=dev); ref[:, 4:4 + T] = x
+    assert torch.equal(dst, ref.to(torch.bfloat16))
+    pre = torch.randn(B, T, C, generator=g(2)).to(torch.bfloat16).to(dev)
+    ops.pad_rows(x, dst, B, T, C, T + 10, 3, pre=pre, ract=1)
+    pr = pre.float().requires_grad_(True); F.gelu(pr).sum().backward()
+    ref = torch.zeros(B, T + 10, C, device=dev); ref[:, 3:3 + T] = x * pr.grad
+    assert rel(dst, ref) < 8e-3
+    # col2im == conv1d backward-data given dcol = dy @ Wflat
+    for (k, s, Tin) in ((3, 2, 41), (2, 2, 40), (2, 2, 41), (3, 2, 42)):
+        Tout = (Tin - k) // s + 1
+        dcol = torch.randn(B, Tout, k, C, generator=g(3)).to(torch.bfloat16).to(dev)
+        dz = torch.full((B, Tin, C), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.col2im(dcol, dz, B, Tin, Tout, C, k, s)
+        ref = torch.zeros(B, Tin, C, device=dev)
+        for t in range(Tout):
+            for j in range(k):
+                ref[:, s * t + j] += dcol[:, t, j].float()
+        assert rel(dz, ref) < 8e-3
+    Co, Ci, k = 16, 8, 3
+    w = torch.randn(Co, Ci, k, generator=g(4)).to(dev)
+    wk = torch.empty(Co, k * Ci, dtype=torch.bfloat16, device=dev)
+    ops.conv_weight_pack(w, wk, Co, Ci, k)
+    assert torch.equal(wk, w.permute(0, 2, 1).reshape(Co, k * Ci).to(torch.bfloat16))
+    dwk = torch.randn(Co, k * Ci, generator=g(5)).to(dev); dw = torch.empty(Co, Ci, k, device=dev)
+    ops.conv_weight_unpack_grad(dwk, dw, Co, Ci, k)
+    assert torch.equal(dw, dwk.view(Co, k, Ci).permute(0, 2, 1))
+
+
+def test_posconv_weight_norm_pack_and_bwd(dev):
+    E, G, K = 32, 4, 8
+    Cg = E // G
+    v = torch.randn(E, Cg, K, generator=g(1)).to(dev)
+    gg = (1 + 0.3 * torch.randn(1, 1, K, generator=g(2))).to(dev)
+    norm = torch.empty(K, device=dev)
+    wf = torch.empty(G, Cg, K * Cg, dtype=torch.bfloat16, device=dev); wd = torch.empty_like(wf)
+    ops.posconv_weight_pack(v, gg, norm, wf, wd, E, Cg, K)
+    vr, gr = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    w = gr * vr / vr.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    assert rel(norm, v.pow(2).sum(dim=(0, 1)).sqrt()) < 1e-5
+    ref_wf = w.view(G, Cg, Cg, K).permute(0, 1, 3, 2).reshape(G, Cg, K * Cg)          # [g][co][j][ci]
+    ref_wd = w.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).reshape(G, Cg, K * Cg)  # [g][ci][j'][co]
+    assert rel(wf, ref_wf) < 8e-3 and rel(wd, ref_wd) < 8e-3
+    dwf = torch.randn(G, Cg, K * Cg, generator=g(3)).to(dev)
+    dw_torch = dwf.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(E, Cg, K)
+    w.backward(dw_torch)
+    dv = torch.empty_like(v); dg = torch.empty(K, device=dev); ws = torch.empty(K, device=dev)
+    ops.posconv_weight_bwd(dwf, v, gg, norm, ws, dv, dg, E, Cg, K)
+    assert rel(dv, vr.grad) < 1e-4 and rel(dg, gr.grad.view(-1)) < 1e-4
+
+
+def test_head_tail(dev):
+    B, T, C, NC = 5, 49, 128, 2
+    h = torch.randn(B, T, C, generator=g(1)).to(torch.bfloat16).to(dev)
+    emb = torch.empty(B, C, device=dev)
+    ops.meanpool_fwd(h, emb, B, T, C)
+    assert rel(emb, h.float().mean(1)) < 1e-5
+    W = (0.1 * torch.randn(NC, C, generator=g(2))).to(dev); b = torch.randn(NC, generator=g(3)).to(dev)
+    logp = torch.empty(B, NC, device=dev)
+    ops.utt_head_fwd(emb, W, b, logp, B, C, NC)
+    er, Wr, br = emb.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.log_softmax(F.linear(er, Wr, br), 1)
+    assert rel(logp, ref) < 1e-5
+    dlogp = torch.randn(B, NC, generator=g(4)).to(dev); demb_in = torch.randn(B, C, generator=g(5)).to(dev)
+    ref.backward(dlogp)
+    demb = torch.empty(B, C, device=dev); dW = torch.empty(NC, C, device=dev); db = torch.empty(NC, device=dev)
+    ws = torch.empty(B * NC, device=dev)
+    ops.utt_head_bwd(dlogp, logp, emb, W, demb_in, demb, dW, db, ws, B, C, NC)
+    assert rel(demb, er.grad + demb_in) < 1e-5 and rel(dW, Wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    pre = torch.randn(B, T, C, generator=g(6)).to(torch.bfloat16).to(dev)
+    dpre = torch.empty(B, T, C, dtype=torch.bfloat16, device=dev)
+    ops.meanpool_bwd(demb, pre, dpre, B, T, C, 3)
+    refd = (demb[:, None, :] / T) * torch.where(pre.float() > 0, 1.0, 0.01)
+    assert rel(dpre, refd) < 8e-3
+    ops.meanpool_bwd(demb, pre, dpre, B, T, C, 3, drop_p=0.5, seed=7)
+    ratio = (dpre.float() / refd)
+    vals = ratio[refd.abs() > 1e-3].round().unique().tolist()
+    assert set(vals) <= {0.0, 2.0}
+
+
+def test_softmax_fwd_bwd(dev):
+    R, T, Tp = 300, 199, 208
+    S = (3 * torch.randn(R, T, generator=g(1))).to(dev)
+    P = torch.full((R, Tp), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.softmax_fwd(S, P, R, T, T, Tp)
+    Sr = S.clone().requires_grad_(True)
+    ref = torch.softmax(Sr, -1)
+    assert rel(P[:, :T], ref) < 8e-3 and (P[:, T:] == 0).all()
+    dP = torch.randn(R, T, generator=g(2)).to(dev)
+    dS = torch.full((R, Tp), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.softmax_bwd(P, dP, dS, R, T, T, Tp)
+    pf = P[:, :T].float()
+    refd = pf * (dP - (dP * pf).sum(-1, keepdim=True))
+    assert rel(dS[:, :T], refd) < 8e-3 and (dS[:, T:] == 0).all()
+
+
+@pytest.mark.parametrize("C,L,B", [(512, 16000, 2), (32, 4000, 3)])
+def test_conv0_fwd_bwd(dev, C, L, B):
+    k, s = 10, 5
+    x = (0.5 * torch.randn(B, L, generator=g(1))).to(dev)
+    w = (torch.randn(C, 1, k, generator=g(2)) * (2.0 / k) ** 0.5).to(dev)
+    b = (0.1 * torch.randn(C, generator=g(3))).to(dev)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g(4))).to(dev); beta = (0.1 * torch.randn(C, generator=g(5))).to(dev)
+    T0 = (L - k) // s + 1
+    z = torch.empty(B, T0, C, dtype=torch.bfloat16, device=dev)
+    ops.conv0_fwd(x, w, b, gamma, beta, z, B, L, C, k, s)
+    wr, br_, gr, ber = (t.clone().requires_grad_(True) for t in (w, b, gamma, beta))
+    ref = F.gelu(F.layer_norm(F.conv1d(x[:, None], wr, br_, stride=s).transpose(1, 2), (C,), gr, ber, 1e-5))
+    assert rel(z, ref) < 8e-3
+    dz = (torch.randn(B, T0, C, generator=g(6))).to(torch.bfloat16).to(dev)
+    ref.backward(dz.float())
+    nparts = ops.conv0_bwd_nparts(B, L, k, s)
+    ws = torch.empty(nparts * C * (k + 3), device=dev)
+    dW = torch.empty(C, 1, k, device=dev); db = torch.empty(C, device=dev); dg = torch.empty(C, device=dev); dbe = torch.empty(C, device=dev)
+    ops.conv0_bwd(x, w, b, gamma, beta, dz, ws, dW, db, dg, dbe, B, L, C, k, s)
+    assert rel(dW, wr.grad) < 2e-4 and rel(db, br_.grad) < 2e-4 and rel(dg, gr.grad) < 2e-4 and rel(dbe, ber.grad) < 2e-4
+
+
+def test_supcon_and_nll_match_oracle(dev):
+    from oracle import head as OH
+    for bz, T2, d, seed in ((4, 49, 128, 0), (11, 199, 128, 1), (64, 49, 128, 2), (11, 128, 1, 3), (32, 199, 128, 4), (100, 7, 16, 5)):
+        torch.manual_seed(seed)
+        f = torch.randn(bz, 1, T2, d)
+        lab = torch.tensor(([1] * ((5 * bz + 10) // 11) + [0] * bz)[:bz])
+        fr = f.clone().requires_grad_(True)
+        ref = OH.supcon_loss(fr, lab)
+        (ref * 0.37).backward()
+        K = T2 * d
+        Fd = f.view(bz, K).to(dev).contiguous()
+        ws = torch.empty(ops.supcon_nchunks(K) * bz * bz, device=dev)
+        G = torch.empty(bz * bz, device=dev); loss = torch.empty(1, device=dev)
+        ops.supcon_fwd(Fd, lab.to(dev), bz, K, K, T2, 0.07, ws, G, loss)
+        assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (bz, T2, d)
+        dF = torch.empty(bz, K, device=dev)
+        up = torch.tensor([0.37], device=dev)
+        ops.supcon_bwd(Fd, G, up, 1.0, bz, K, K, T2, 0.07, dF)
+        assert rel(dF, fr.grad.view(bz, K)) < 2e-4, (bz, T2, d)
+    # single-member class -> NaN, as loss_metrics.py:202
+    torch.manual_seed(9)
+    f = torch.randn(4, 80).to(dev)
+    ws = torch.empty(ops.supcon_nchunks(80) * 16, device=dev); G = torch.empty(16, device=dev); loss = torch.empty(1, device=dev)
+    ops.supcon_fwd(f, torch.tensor([1, 0, 0, 0], device=dev), 4, 80, 80, 10, 0.07, ws, G, loss)
+    assert torch.isnan(loss).item()
+    # NLL term: CE on log-probs, mean, then / bz
+    bz = 11
+    logits = torch.randn(bz, 2, generator=g(7))
+    logp = F.log_softmax(logits, 1).requires_grad_(True)
+    y = torch.tensor([1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0])
+    ref = F.cross_entropy(logp, y) / bz
+    ref.backward()
+    lo = torch.empty(1, device=dev); coef = torch.empty(bz, 2, device=dev)
+    ops.nll_fwd(logp.detach().to(dev), y.to(dev), bz, 2, lo, coef)
+    assert abs(lo.item() - ref.item()) < 1e-6 and rel(coef, logp.grad) < 1e-5
+
+
+def test_adamw_matches_torch(dev):
+    n = 10007
+    p = torch.randn(n, generator=g(1)).to(dev); p_ref = p.clone().requires_grad_(True)
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    pb = torch.empty(n + 1, dtype=torch.bfloat16, device=dev)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, weight_decay=1e-2)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g(10 + step)).to(dev)
+        p_ref.grad = gr.clone()
+        opt.step()
+        ops.adamw_flat(p, gr, m, v, pb, n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+        assert rel(p, p_ref.detach()) < 1e-6
+    assert torch.equal(pb[:n], p.to(torch.bfloat16))
