@@ -1,0 +1,386 @@
+"""wav2vec2 / XLS-R encoder: forward and hand-scheduled backward over the HIP kernels.
+
+What the reference gets from `fairseq Wav2Vec2Model.forward(src, mask=False, features_only=True)['x']`
+(model/xlsr.py:41) and from autograd's backward through it (main.py:79).
+Layout decisions (MI355X-first, not fairseq's):
+  * activations are channels-last [B, T, C] everywhere, so every Conv1d of the feature extractor is
+    a plain GEMM whose A rows overlap (ld = stride*C) — no im2col buffer, no transposes;
+  * GEMM operands are bf16, accumulation fp32; the residual stream, LayerNorm statistics, softmax
+    and all gradients of parameters are fp32;
+  * q/k/v projections are one [3E, E] GEMM; attention scores are materialised per layer as bf16
+    P[B,H,T,Tp] (41 MB at B=32) and reused by the backward — HBM is 288 GB, recompute buys nothing here;
+  * every buffer is allocated once per (B, L) and reused across steps (no allocator traffic).
+"""
+import torch
+
+from . import ops
+from .lib import ACT_GELU, FLAT
+from .ops import Op
+
+
+class W2VConfig:
+    def __init__(self, conv_dim=512, conv_kernels=(10, 3, 3, 3, 3, 2, 2), conv_strides=(5, 2, 2, 2, 2, 2, 2), embed=1024,
+                 layers=24, heads=16, ffn=4096, pos_k=128, pos_groups=16, final_dim=768, latent_vars=320, latent_groups=2,
+                 encoder_layerdrop=0.0):
+        self.conv_dim, self.conv_kernels, self.conv_strides = conv_dim, tuple(conv_kernels), tuple(conv_strides)
+        self.embed, self.layers, self.heads, self.ffn = embed, layers, heads, ffn
+        self.pos_k, self.pos_groups = pos_k, pos_groups
+        self.final_dim, self.latent_vars, self.latent_groups = final_dim, latent_vars, latent_groups
+        self.encoder_layerdrop = encoder_layerdrop
+        assert embed % heads == 0 and (embed // heads) % 8 == 0 and conv_dim % 8 == 0 and pos_k % 2 == 0
+        assert (embed // pos_groups) % 8 == 0
+
+    @staticmethod
+    def tiny():
+        return W2VConfig(conv_dim=32, embed=64, layers=2, heads=4, ffn=128, pos_k=16, pos_groups=4, final_dim=16,
+                         latent_vars=8, latent_groups=2)
+
+    def conv_lens(self, L):
+        out = []
+        for k, s in zip(self.conv_kernels, self.conv_strides):
+            L = (L - k) // s + 1
+            out.append(L)
+        return out
+
+
+def param_specs(cfg, prefix="ssl_model.model."):
+    """(name, shape, trainable) in MEMORY order (q,k,v adjacent); names are fairseq's."""
+    C, E = cfg.conv_dim, cfg.embed
+    sp = []
+    cin = 1
+    for i, k in enumerate(cfg.conv_kernels):
+        p = prefix + "feature_extractor.conv_layers.%d." % i
+        sp += [(p + "0.weight", (C, cin, k), True), (p + "0.bias", (C,), True),
+               (p + "2.1.weight", (C,), True), (p + "2.1.bias", (C,), True)]
+        cin = C
+    sp += [(prefix + "layer_norm.weight", (C,), True), (prefix + "layer_norm.bias", (C,), True),
+           (prefix + "post_extract_proj.weight", (E, C), True), (prefix + "post_extract_proj.bias", (E,), True),
+           (prefix + "encoder.pos_conv.0.bias", (E,), True), (prefix + "encoder.pos_conv.0.weight_g", (1, 1, cfg.pos_k), True),
+           (prefix + "encoder.pos_conv.0.weight_v", (E, E // cfg.pos_groups, cfg.pos_k), True)]
+    for n in range(cfg.layers):
+        p = prefix + "encoder.layers.%d." % n
+        sp += [(p + "self_attn_layer_norm.weight", (E,), True), (p + "self_attn_layer_norm.bias", (E,), True)]
+        for proj in ("q_proj", "k_proj", "v_proj"):
+            sp.append((p + "self_attn.%s.weight" % proj, (E, E), True))
+        for proj in ("q_proj", "k_proj", "v_proj"):
+            sp.append((p + "self_attn.%s.bias" % proj, (E,), True))
+        sp += [(p + "self_attn.out_proj.weight", (E, E), True), (p + "self_attn.out_proj.bias", (E,), True),
+               (p + "final_layer_norm.weight", (E,), True), (p + "final_layer_norm.bias", (E,), True),
+               (p + "fc1.weight", (cfg.ffn, E), True), (p + "fc1.bias", (cfg.ffn,), True),
+               (p + "fc2.weight", (E, cfg.ffn), True), (p + "fc2.bias", (E,), True)]
+    sp += [(prefix + "encoder.layer_norm.weight", (E,), True), (prefix + "encoder.layer_norm.bias", (E,), True)]
+    vd = cfg.final_dim // cfg.latent_groups
+    nv = cfg.latent_vars * cfg.latent_groups
+    sp += [(prefix + "mask_emb", (E,), False), (prefix + "quantizer.vars", (1, nv, vd), False),
+           (prefix + "quantizer.weight_proj.weight", (nv, C), False), (prefix + "quantizer.weight_proj.bias", (nv,), False),
+           (prefix + "project_q.weight", (cfg.final_dim, cfg.final_dim), False), (prefix + "project_q.bias", (cfg.final_dim,), False),
+           (prefix + "final_proj.weight", (cfg.final_dim, E), False), (prefix + "final_proj.bias", (cfg.final_dim,), False)]
+    return sp
+
+
+def _splitk(tiles, ksteps, target=512, cap=32):
+    s = max(1, min(cap, target // max(tiles, 1), ksteps))
+    return s
+
+
+class Encoder:
+    """Forward / backward of the SSL encoder on one GPU.  `P` is a FlatParams holding (at least)
+    the parameters named by param_specs(cfg, prefix)."""
+
+    def __init__(self, cfg, P, prefix="ssl_model.model."):
+        self.cfg, self.P, self.pre = cfg, P, prefix
+        self.dev = P.device
+        self._bufs = {}
+        C, E, K, G = cfg.conv_dim, cfg.embed, cfg.pos_k, cfg.pos_groups
+        Cg = E // G
+        bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=self.dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        # derived bf16 weights that are not plain casts
+        self.wk = [None] + [bf(C, cfg.conv_kernels[i] * C) for i in range(1, len(cfg.conv_kernels))]
+        self.pos_wf, self.pos_wd, self.pos_norm = bf(G, Cg, K * Cg), bf(G, Cg, K * Cg), f32(K)
+        self.ws_small = f32(max(K, 16))
+        self._slab = None
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def n(self, name):
+        return self.pre + name
+
+    def refresh_weights(self):
+        """Rebuild the bf16 working set after the fp32 masters changed (the flat cast is fused into
+        the AdamW kernel; this covers load_state_dict / first use and the re-laid-out weights)."""
+        P, cfg = self.P, self.cfg
+        if P.bf16_version != P.version:
+            ops.cast_bf16(P.flat, P.bf16, P.n_train)
+            P.bf16_version = P.version
+        if getattr(self, "_derived_version", -1) == P.version:
+            return
+        C, E, K, G = cfg.conv_dim, cfg.embed, cfg.pos_k, cfg.pos_groups
+        for i in range(1, len(cfg.conv_kernels)):
+            ops.conv_weight_pack(P.f32(self.n("feature_extractor.conv_layers.%d.0.weight" % i)), self.wk[i], C, C, cfg.conv_kernels[i])
+        ops.posconv_weight_pack(P.f32(self.n("encoder.pos_conv.0.weight_v")), P.f32(self.n("encoder.pos_conv.0.weight_g")),
+                                self.pos_norm, self.pos_wf, self.pos_wd, E, E // G, K)
+        self._derived_version = P.version
+
+    def W(self, name, ld):
+        """bf16 GEMM operand view of a plain (cast-only) weight."""
+        return Op(self.P.bf16, ld, offset=self.P.off(self.n(name)))
+
+    def b(self, name):
+        return self.P.f32(self.n(name))
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def bufs(self, B, L):
+        key = (B, L)
+        if key in self._bufs:
+            return self._bufs[key]
+        cfg, dev = self.cfg, self.dev
+        C, E, H, Fd, K = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k
+        Ts = cfg.conv_lens(L)
+        T = Ts[-1]
+        M = B * T
+        Tp = (T + 7) // 8 * 8
+        bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d = {"Ts": Ts, "T": T, "M": M, "Tp": Tp}
+        slack = 128 * max(C, E)  # tail slack: tile rows past the last frame are clamped/masked, never dereferenced past this
+        d["z"] = [bf(B * t * C + slack) for t in Ts]
+        d["y"] = [None] + [f32(B * t * C) for t in Ts[1:]]   # pre-LayerNorm conv outputs stay fp32 (fairseq's Fp32LayerNorm input)
+        d["cmean"] = [None] + [f32(B * t) for t in Ts[1:]]
+        d["crstd"] = [None] + [f32(B * t) for t in Ts[1:]]
+        d["h0"], d["fmean"], d["frstd"] = bf(M * C), f32(M), f32(M)
+        d["x0"] = f32(M * E)
+        d["xpad"] = bf(B * (T + K) * E + slack)
+        d["pc_pre"] = bf(M * E)
+        d["xin"] = [f32(M * E) for _ in range(cfg.layers + 1)]
+        d["h1"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["m1"], d["r1"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
+        d["qkv"] = [bf(M * 3 * E + slack) for _ in range(cfg.layers)]
+        d["S"] = f32(B * H * T * T)
+        d["P"] = [bf(B * H * T * Tp + 1024) for _ in range(cfg.layers)]
+        d["ctx"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["x1"] = [f32(M * E) for _ in range(cfg.layers)]
+        d["m2"], d["r2"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
+        d["h2"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["f"] = [bf(M * Fd) for _ in range(cfg.layers)]
+        d["a"] = [bf(M * Fd) for _ in range(cfg.layers)]
+        d["out"], d["omean"], d["orstd"] = bf(M * E), f32(M), f32(M)
+        # backward scratch (shared by all layers)
+        d["dx_a"], d["dx_b"] = f32(M * E), f32(M * E)
+        d["dxbf_a"], d["dxbf_b"] = bf(M * E + slack), bf(M * E + slack)
+        d["d_f"] = bf(M * Fd + slack)
+        d["d_h"] = bf(M * E + slack)
+        d["d_ctx"] = bf(M * E + slack)
+        d["dqkv"] = bf(M * 3 * E + slack)
+        d["dS"] = bf(B * H * T * Tp + 1024)
+        d["dcpad"] = bf(B * (T + K) * E + slack)
+        d["dz"] = [bf(B * t * C + slack) for t in Ts]
+        d["dy"] = bf(B * Ts[1] * C + slack) if len(Ts) > 1 else None
+        kmax = max(cfg.conv_kernels[1:]) if len(cfg.conv_kernels) > 1 else 1
+        d["dcol"] = bf(B * Ts[1] * kmax * C + slack) if len(Ts) > 1 else None
+        nln = max(ops.layernorm_bwd_nparts(B * t) for t in Ts)
+        d["ln_pg"], d["ln_pb"] = f32(nln * max(C, E)), f32(nln * max(C, E))
+        ncs = max(ops.colsum_nparts(B * max(Ts[1:] + [T + K])), 1)
+        d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
+        d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
+        d["slab"] = None  # split-K slabs, sized on first use
+        d["dwk"] = f32(C * kmax * C)
+        d["dwf"] = f32(E * (E // cfg.pos_groups) * K)
+        self._bufs[key] = d
+        return d
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _wgrad(self, d, A, B_, out, Mo, No, Kr, **kw):
+        """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small."""
+        tiles = ((Mo + 127) // 128) * ((No + 127) // 128) * kw.get("nb2", 1)
+        sk = _splitk(tiles, (Kr + 63) // 64)
+        if sk == 1:
+            ops.gemm(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, **kw)
+            return
+        n = out.numel()
+        if d["slab"] is None or d["slab"].numel() < sk * n:
+            d["slab"] = torch.empty(sk * n, dtype=torch.float32, device=self.dev)
+        ops.gemm(A, B_, d["slab"], Mo, No, Kr, a_t=True, b_t=True, splitk=sk, c_split_stride=n, **kw)
+        ops.reduce_slabs(d["slab"], out, n, sk, n)
+
+    def _bias_grad(self, d, dy, Mrows, N, gname):
+        n = ops.colsum_nparts(Mrows)
+        ops.colsum(dy, d["cs_part"], Mrows, N)
+        ops.colreduce(d["cs_part"], self.P.g(self.n(gname)), n, N)
+
+    def _ln_grads(self, d, nparts, C, wname, bname):
+        ops.colreduce(d["ln_pg"], self.P.g(self.n(wname)), nparts, C)
+        ops.colreduce(d["ln_pb"], self.P.g(self.n(bname)), nparts, C)
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x, training=True):
+        """x [B, L] fp32 contiguous on the GPU -> (enc_out bf16 [B*T, E], ctx)."""
+        cfg, P = self.cfg, self.P
+        B, L = x.shape
+        self.refresh_weights()
+        d = self.bufs(B, L)
+        C, E, H, Fd, K, G = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k, cfg.pos_groups
+        D, Cg = E // H, E // G
+        Ts, T, M, Tp = d["Ts"], d["T"], d["M"], d["Tp"]
+        fe = "feature_extractor.conv_layers.%d."
+        # -- conv stack (M1)
+        ops.conv0_fwd(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"),
+                      self.b(fe % 0 + "2.1.bias"), d["z"][0], B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0])
+        for i in range(1, len(Ts)):
+            k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
+            ops.gemm(Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), Op(self.wk[i], k * C), d["y"][i], B * Tout, C, k * C,
+                     bias=self.b(fe % i + "0.bias"))
+            ops.layernorm_fwd(d["y"][i], self.b(fe % i + "2.1.weight"), self.b(fe % i + "2.1.bias"), d["z"][i], None,
+                              d["cmean"][i], d["crstd"][i], B * Tout, C, act=1)
+        ops.layernorm_fwd(d["z"][-1], self.b("layer_norm.weight"), self.b("layer_norm.bias"), d["h0"], None, d["fmean"],
+                          d["frstd"], M, C)
+        ops.gemm(Op(d["h0"], C), self.W("post_extract_proj.weight", C), d["x0"], M, E, C, bias=self.b("post_extract_proj.bias"))
+        # -- positional conv (grouped, weight-normed), GELU, residual (M2 head)
+        ops.pad_rows(d["x0"], d["xpad"], B, T, E, T + K, K // 2)
+        ops.gemm(Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wf, K * Cg, bs2=Cg * K * Cg),
+                 d["xin"][0], M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=self.b("encoder.pos_conv.0.bias"), bias_bs2=Cg,
+                 act=ACT_GELU, c2=d["pc_pre"], R=d["x0"], rmode=1)
+        # -- transformer layers
+        skipped = []
+        for n in range(cfg.layers):
+            pn = "encoder.layers.%d." % n
+            xin, xout = d["xin"][n], d["xin"][n + 1]
+            if training and cfg.encoder_layerdrop > 0 and float(torch.rand(())) < cfg.encoder_layerdrop:
+                xout.copy_(xin)  # fairseq LayerDrop: the whole layer is skipped
+                skipped.append(n)
+                continue
+            ops.layernorm_fwd(xin, self.b(pn + "self_attn_layer_norm.weight"), self.b(pn + "self_attn_layer_norm.bias"),
+                              d["h1"][n], None, d["m1"][n], d["r1"][n], M, E)
+            ops.gemm(Op(d["h1"][n], E), self.W(pn + "self_attn.q_proj.weight", E), d["qkv"][n], M, 3 * E, E,
+                     bias=self.b(pn + "self_attn.q_proj.bias"))  # q,k,v biases are adjacent in the flat buffer
+            qkv = d["qkv"][n]
+            ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
+                     nb1=B, nb2=H, alpha=D ** -0.5, c_bs1=H * T * T, c_bs2=T * T)
+            ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, T, Tp)
+            ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
+                     d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
+            ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
+                     bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
+            ops.layernorm_fwd(d["x1"][n], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"),
+                              d["h2"][n], None, d["m2"][n], d["r2"][n], M, E)
+            ops.gemm(Op(d["h2"][n], E), self.W(pn + "fc1.weight", E), d["a"][n], M, Fd, E, bias=self.b(pn + "fc1.bias"),
+                     act=ACT_GELU, c2=d["f"][n])
+            ops.gemm(Op(d["a"][n], Fd), self.W(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"),
+                     R=d["x1"][n], rmode=1)
+        ops.layernorm_fwd(d["xin"][cfg.layers], self.b("encoder.layer_norm.weight"), self.b("encoder.layer_norm.bias"),
+                          d["out"], None, d["omean"], d["orstd"], M, E)
+        return d["out"], {"d": d, "x": x, "B": B, "L": L, "skipped": skipped}
+
+    # ---- backward --------------------------------------------------------------------------------
+    def backward(self, ctx, d_out):
+        """d_out: bf16 or f32 [M, E] gradient w.r.t. forward()'s output.  Writes every parameter
+        gradient of the encoder into the flat gradient buffer (overwrite semantics)."""
+        cfg, P = self.cfg, self.P
+        d, x, B, L = ctx["d"], ctx["x"], ctx["B"], ctx["L"]
+        C, E, H, Fd, K, G = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k, cfg.pos_groups
+        D, Cg = E // H, E // G
+        Ts, T, M, Tp = d["Ts"], d["T"], d["M"], d["Tp"]
+        nlnM = ops.layernorm_bwd_nparts(M)
+        # final LayerNorm
+        dx, dxb = d["dx_a"], d["dxbf_a"]
+        ops.layernorm_bwd(d_out, d["xin"][cfg.layers], d["omean"], d["orstd"], self.b("encoder.layer_norm.weight"), None, None,
+                          dx, dxb, d["ln_pg"], d["ln_pb"], M, E)
+        self._ln_grads(d, nlnM, E, "encoder.layer_norm.weight", "encoder.layer_norm.bias")
+        other, otherb = d["dx_b"], d["dxbf_b"]
+        for n in reversed(range(cfg.layers)):
+            pn = "encoder.layers.%d." % n
+            if n in ctx["skipped"]:
+                for nm in ("self_attn_layer_norm.weight", "self_attn_layer_norm.bias", "self_attn.q_proj.weight",
+                           "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.bias",
+                           "self_attn.v_proj.bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias", "final_layer_norm.weight",
+                           "final_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+                    P.g(self.n(pn + nm)).zero_()
+                continue
+            xin = d["xin"][n]
+            # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
+            self._bias_grad(d, dx, M, E, pn + "fc2.bias")
+            self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
+            ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU)
+            self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
+            self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
+            ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
+            ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
+                              other, otherb, d["ln_pg"], d["ln_pb"], M, E)
+            self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias")
+            dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d x1
+            # ---- attention:  x1 = xin + ctx Wo^T + bo
+            self._bias_grad(d, dx, M, E, pn + "self_attn.out_proj.bias")
+            self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M)
+            ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
+            qkv, dqkv, Pn = d["qkv"][n], d["dqkv"], d["P"][n]
+            bq = dict(nb1=B, nb2=H)
+            # dV[j] = sum_i P[i][j] dctx[i]
+            ops.gemm(Op(Pn, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(d["d_ctx"], E, bs1=T * E, bs2=D), dqkv, T, D, T, a_t=True, b_t=True,
+                     ldc=3 * E, c_bs1=T * 3 * E, c_bs2=D, c_offset=2 * E, **bq)
+            # dP = dctx V^T
+            ops.gemm(Op(d["d_ctx"], E, bs1=T * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["S"], T, T, D,
+                     c_bs1=H * T * T, c_bs2=T * T, **bq)
+            ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, T, Tp)
+            sc = D ** -0.5
+            dS = Op(d["dS"], Tp, bs1=H * T * Tp, bs2=T * Tp)
+            ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), dqkv, T, D, T, b_t=True, alpha=sc, ldc=3 * E,
+                     c_bs1=T * 3 * E, c_bs2=D, c_offset=0, **bq)                                   # dQ = s dS K
+            ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=0), dqkv, T, D, T, a_t=True, b_t=True, alpha=sc, ldc=3 * E,
+                     c_bs1=T * 3 * E, c_bs2=D, c_offset=E, **bq)                                   # dK = s dS^T Q
+            ops.colsum(dqkv, d["cs_part"], M, 3 * E)
+            ops.colreduce(d["cs_part"], self._qkv_view(pn, "bias"), ops.colsum_nparts(M), 3 * E)
+            self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
+            ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
+            ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
+                              other, otherb, d["ln_pg"], d["ln_pb"], M, E)
+            self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias")
+            dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d xin
+        # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
+        pb = K // 2 - 1
+        ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)
+        n_cs = ops.colsum_nparts(B * (T + K))
+        ops.colsum(d["dcpad"], d["cs_part"], B * (T + K), E)
+        ops.colreduce(d["cs_part"], P.g(self.n("encoder.pos_conv.0.bias")), n_cs, E)
+        dwf = d["dwf"]
+        self._wgrad(d, Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=pb * E),
+                    Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), dwf, Cg, K * Cg, M,
+                    nb2=G, c_bs2=Cg * K * Cg, ldc=K * Cg)
+        ops.posconv_weight_bwd(dwf, self.b("encoder.pos_conv.0.weight_v"), self.b("encoder.pos_conv.0.weight_g"), self.pos_norm,
+                               self.ws_small, P.g(self.n("encoder.pos_conv.0.weight_v")), P.g(self.n("encoder.pos_conv.0.weight_g")),
+                               E, Cg, K)
+        ops.gemm(Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wd, K * Cg, bs2=Cg * K * Cg),
+                 other, M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, R=dx, rmode=1)
+        dx0 = other
+        ops.cast_bf16(dx0, otherb, M * E)
+        # ---- post_extract_proj + feature LayerNorm
+        self._bias_grad(d, dx0, M, E, "post_extract_proj.bias")
+        self._wgrad(d, Op(otherb, E), Op(d["h0"], C), P.g(self.n("post_extract_proj.weight")), E, C, M)
+        ops.gemm(Op(otherb, E), self.W("post_extract_proj.weight", C), d["d_h"], M, C, E, b_t=True)
+        ops.layernorm_bwd(d["d_h"], d["z"][-1], d["fmean"], d["frstd"], self.b("layer_norm.weight"), None, None, None, d["dz"][-1],
+                          d["ln_pg"], d["ln_pb"], M, C)
+        self._ln_grads(d, nlnM, C, "layer_norm.weight", "layer_norm.bias")
+        # ---- conv stack, layers 6..1
+        fe = "feature_extractor.conv_layers.%d."
+        for i in reversed(range(1, len(Ts))):
+            k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
+            Mi = B * Tout
+            ops.layernorm_bwd(d["dz"][i], d["y"][i], d["cmean"][i], d["crstd"][i], self.b(fe % i + "2.1.weight"),
+                              self.b(fe % i + "2.1.bias"), None, None, d["dy"], d["ln_pg"], d["ln_pb"], Mi, C, act=1)
+            self._ln_grads(d, ops.layernorm_bwd_nparts(Mi), C, fe % i + "2.1.weight", fe % i + "2.1.bias")
+            self._bias_grad(d, d["dy"], Mi, C, fe % i + "0.bias")
+            dwk = d["dwk"][: C * k * C].view(C, k * C)
+            self._wgrad(d, Op(d["dy"], C), Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), dwk, C, k * C, Mi)
+            ops.conv_weight_unpack_grad(dwk, P.g(self.n(fe % i + "0.weight")), C, C, k)
+            ops.gemm(Op(d["dy"], C), Op(self.wk[i], k * C), d["dcol"], Mi, k * C, C, b_t=True)
+            ops.col2im(d["dcol"], d["dz"][i - 1], B, Tin, Tout, C, k, s)
+        ops.conv0_bwd(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"),
+                      self.b(fe % 0 + "2.1.bias"), d["dz"][0], d["conv0_ws"], P.g(self.n(fe % 0 + "0.weight")),
+                      P.g(self.n(fe % 0 + "0.bias")), P.g(self.n(fe % 0 + "2.1.weight")), P.g(self.n(fe % 0 + "2.1.bias")),
+                      B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0])
+
+    def _qkv_view(self, pn, kind):
+        """q/k/v gradients are adjacent in the flat buffer: one [3E, E] wgrad / [3E] bias-grad output."""
+        E = self.cfg.embed
+        o = self.P.off(self.n(pn + "self_attn.q_proj." + kind))
+        n = 3 * E * E if kind == "weight" else 3 * E
+        v = self.P.grad[o:o + n]
+        return v.view(3 * E, E) if kind == "weight" else v

@@ -1,0 +1,284 @@
+"""`wav2vec2_linear_nll` model plugin — host-side mirror of the reference's
+model/wav2vec2_linear_nll.py::Model (ctor, `is_train`, forward, loss), with every
+numeric step executed by the HIP kernels behind the C ABI.
+
+    Model(args: dict, device, is_train=True)
+    forward(x [bz, L] fp32) -> (log_probs [bz,2], feats [bz,T,128], emb [bz,128])   (or log_probs when not is_train)
+    loss(output, feats, emb, labels, config, info=None) -> dict of 0-d tensors, summed and .backward()-ed by the caller
+
+State-dict keys equal the reference's (ssl_model.model.<fairseq keys>, LL.*, first_bn.*, first_bn1.*,
+backend.m_frame_level.{0,3,6}.*, backend.m_utt_level.*), so its checkpoints load unchanged.
+`train_loss.backward()` reaches the hand-written backward through two torch.autograd.Function
+boundaries (model, loss); parameter gradients are written straight into the flat gradient buffer.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .encoder import Encoder, W2VConfig, param_specs
+from .lib import ACT_LEAKY, ACT_RELU
+from .ops import Op
+from .params import FlatParams, register_by_name
+
+HEAD_DIM = 128
+N_CLASS = 2
+DROP_P = 0.5  # BackEnd(128, 128, 2, 0.5, False): torch.nn.Dropout(0.5) after each frame-level layer
+
+
+def head_specs(embed):
+    return [("LL.weight", (HEAD_DIM, embed), True), ("LL.bias", (HEAD_DIM,), True),
+            ("backend.m_frame_level.0.weight", (HEAD_DIM, HEAD_DIM), True), ("backend.m_frame_level.0.bias", (HEAD_DIM,), True),
+            ("backend.m_frame_level.3.weight", (HEAD_DIM, HEAD_DIM), True), ("backend.m_frame_level.3.bias", (HEAD_DIM,), True),
+            ("backend.m_frame_level.6.weight", (HEAD_DIM, HEAD_DIM), True), ("backend.m_frame_level.6.bias", (HEAD_DIM,), True),
+            ("backend.m_utt_level.weight", (N_CLASS, HEAD_DIM), True), ("backend.m_utt_level.bias", (N_CLASS,), True)]
+
+
+def init_parameters_(P, cfg, seed=0):
+    """Seeded random init at the right shapes (no checkpoint ships with the repo): kaiming-normal convs
+    and N(0, 0.02) linears for the encoder, torch's default uniform for the head."""
+    g = torch.Generator().manual_seed(seed)
+    for name, (o, n, shape, tr) in P.index.items():
+        short = name.split("ssl_model.model.")[-1]
+        if short.endswith("2.1.weight") or "layer_norm.weight" in short:
+            t = torch.ones(shape)
+        elif short.endswith("2.1.bias") or "layer_norm.bias" in short:
+            t = torch.zeros(shape)
+        elif "conv_layers" in short and short.endswith("0.weight"):
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[1] * shape[2]))
+        elif short == "encoder.pos_conv.0.weight_v":
+            t = torch.randn(shape, generator=g) * math.sqrt(4.0 / (cfg.pos_k * cfg.embed))
+        elif short == "encoder.pos_conv.0.weight_g":
+            continue
+        elif name.startswith("LL.") or name.startswith("backend."):
+            fan_in = shape[-1] if len(shape) > 1 else HEAD_DIM
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        elif short.endswith(".bias"):
+            t = torch.zeros(shape)
+        else:
+            t = 0.02 * torch.randn(shape, generator=g)
+        P.f32(name).copy_(t.to(P.device))
+    v = P.f32("ssl_model.model.encoder.pos_conv.0.weight_v")
+    P.f32("ssl_model.model.encoder.pos_conv.0.weight_g").copy_(v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+    P.mark_dirty()
+
+
+class _ModelFn(torch.autograd.Function):
+    """Autograd boundary around the whole network: forward runs the kernels and keeps the activation
+    buffers; backward consumes (d_logp, d_feats, d_emb) and fills the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, x, anchor):
+        out, feats, emb, saved = model._run_forward(x)
+        ctx.model, ctx.saved = model, saved
+        return out, feats, emb
+
+    @staticmethod
+    def backward(ctx, d_out, d_feats, d_emb):
+        ctx.model._run_backward(ctx.saved, d_out, d_feats, d_emb)
+        return None, None, None
+
+
+class Model(nn.Module):
+    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0):
+        super().__init__()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("scl_amd.Model needs an MI355X device: the product path has no CPU fallback")
+        self.is_train = is_train
+        self.flag_fix_ssl = args["flag_fix_ssl"]
+        self.contra_mode = args["contra_mode"]
+        self.loss_type = args["loss_type"]
+        if self.contra_mode != "all":
+            raise NotImplementedError("contra_mode 'one' (the reference's configs all use 'all')")
+        self.cfg = w2v_cfg or W2VConfig(encoder_layerdrop=float(args.get("encoder_layerdrop", 0.0)))
+        specs = param_specs(self.cfg) + head_specs(self.cfg.embed)
+        # memory order: trainable encoder, head, then the checkpoint-only tensors (FlatParams puts those last)
+        self.P = FlatParams(specs, self.device)
+        for name, p in self.P.params.items():
+            register_by_name(self, name, p)
+        # defined-but-unused modules of the reference (linear_nll:108-109) — state-dict compatibility only
+        self.first_bn = nn.BatchNorm2d(num_features=1).to(self.device)
+        self.first_bn1 = nn.BatchNorm2d(num_features=64).to(self.device)
+        init_parameters_(self.P, self.cfg, seed)
+        self.encoder = Encoder(self.cfg, self.P)
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self._hbufs = {}
+        self._step_seed = 0
+        self.out_dim = self.cfg.embed
+
+    # nn.Module plumbing ----------------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        # .to(device) / .cuda() on an already-placed model must not break the flat-buffer views
+        probe = fn(torch.zeros(1, device=self.device))
+        if probe.device != self.device or probe.dtype != torch.float32:
+            raise RuntimeError("scl_amd.Model lives in one flat fp32 device buffer; construct it on the target device")
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.P.mark_dirty()
+        return r
+
+    def optimizer_stepped(self, bf16_fresh):
+        self.P.mark_dirty()
+        if bf16_fresh:
+            self.P.bf16_version = self.P.version
+
+    # forward ---------------------------------------------------------------------------------------
+    def _head_bufs(self, B, T):
+        key = (B, T)
+        if key not in self._hbufs:
+            M, dev = B * T, self.device
+            bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+            f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            self._hbufs[key] = dict(r0=bf(M * HEAD_DIM + 1024), pre=[bf(M * HEAD_DIM) for _ in range(3)],
+                                    h=[bf(M * HEAD_DIM + 1024) for _ in range(3)], dpre=[bf(M * HEAD_DIM + 1024) for _ in range(3)],
+                                    dfe=f32(M * HEAD_DIM), dfe_bf=bf(M * HEAD_DIM + 1024), denc=bf(M * self.cfg.embed),
+                                    demb=f32(B * HEAD_DIM), ws=f32(B * N_CLASS + 16),
+                                    cs=f32(ops.colsum_nparts(M) * max(HEAD_DIM, 8)), dW=f32(HEAD_DIM * max(HEAD_DIM, self.cfg.embed)))
+        return self._hbufs[key]
+
+    def _run_forward(self, x):
+        P, E = self.P, self.cfg.embed
+        B, L = x.shape
+        training = self.training
+        if self.flag_fix_ssl:
+            enc_out, ectx = self.encoder.forward(x, training=False)
+        else:
+            # reference quirk: the SSL sub-model follows `is_train`, not model.eval()
+            enc_out, ectx = self.encoder.forward(x, training=self.is_train and training)
+        T = ectx["d"]["T"]
+        M = B * T
+        hb = self._head_bufs(B, T)
+        feats = torch.empty(B, T, HEAD_DIM, dtype=torch.float32, device=self.device)
+        emb = torch.empty(B, HEAD_DIM, dtype=torch.float32, device=self.device)
+        logp = torch.empty(B, N_CLASS, dtype=torch.float32, device=self.device)
+        W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
+        # feats = LL(x) (pre-ReLU tensor is what SupCon sees, linear_nll:127-129), r0 = relu(feats)
+        ops.gemm(Op(enc_out, E), W("LL.weight", E), hb["r0"], M, HEAD_DIM, E, bias=P.f32("LL.bias"), act=ACT_RELU, c2=feats)
+        drop = DROP_P if training else 0.0
+        self._step_seed = (self._step_seed * 1664525 + 1013904223) & 0x7FFFFFFF
+        seeds = [(self._step_seed + 7919 * j) & 0x7FFFFFFF for j in range(3)]
+        prev = hb["r0"]
+        for j, idx in enumerate((0, 3, 6)):
+            ops.gemm(Op(prev, HEAD_DIM), W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), hb["h"][j], M, HEAD_DIM, HEAD_DIM,
+                     bias=P.f32("backend.m_frame_level.%d.bias" % idx), act=ACT_LEAKY, c2=hb["pre"][j], drop_p=drop, drop_seed=seeds[j])
+            prev = hb["h"][j]
+        ops.meanpool_fwd(prev, emb, B, T, HEAD_DIM)
+        ops.utt_head_fwd(emb, P.f32("backend.m_utt_level.weight"), P.f32("backend.m_utt_level.bias"), logp, B, HEAD_DIM, N_CLASS)
+        saved = dict(ectx=ectx, hb=hb, B=B, T=T, drop=drop, seeds=seeds, feats=feats, emb=emb, logp=logp, enc_out=enc_out)
+        return logp, feats, emb, saved
+
+    def _run_backward(self, sv, d_logp, d_feats, d_emb):
+        P, E = self.P, self.cfg.embed
+        P.rebind_grads()
+        B, T, hb = sv["B"], sv["T"], sv["hb"]
+        M = B * T
+        dev = self.device
+        if d_logp is None:
+            d_logp = torch.zeros(B, N_CLASS, device=dev)
+        W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
+        ops.utt_head_bwd(d_logp.contiguous(), sv["logp"], sv["emb"], P.f32("backend.m_utt_level.weight"),
+                         None if d_emb is None else d_emb.contiguous(), hb["demb"], P.g("backend.m_utt_level.weight"),
+                         P.g("backend.m_utt_level.bias"), hb["ws"], B, HEAD_DIM, N_CLASS)
+        ops.meanpool_bwd(hb["demb"], hb["pre"][2], hb["dpre"][2], B, T, HEAD_DIM, ACT_LEAKY, sv["drop"], sv["seeds"][2])
+        ncs = ops.colsum_nparts(M)
+        for j, idx in reversed(list(enumerate((0, 3, 6)))):
+            dpre = hb["dpre"][j]
+            inp = hb["h"][j - 1] if j > 0 else hb["r0"]
+            ops.colsum(dpre, hb["cs"], M, HEAD_DIM)
+            ops.colreduce(hb["cs"], P.g("backend.m_frame_level.%d.bias" % idx), ncs, HEAD_DIM)
+            self.encoder._wgrad(sv["ectx"]["d"], Op(dpre, HEAD_DIM), Op(inp, HEAD_DIM), P.g("backend.m_frame_level.%d.weight" % idx),
+                                HEAD_DIM, HEAD_DIM, M)
+            wj = W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM)
+            if j > 0:
+                ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dpre"][j - 1], M, HEAD_DIM, HEAD_DIM, b_t=True, R=hb["pre"][j - 1], rmode=2,
+                         ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=sv["seeds"][j - 1])
+            else:
+                ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dfe"], M, HEAD_DIM, HEAD_DIM, b_t=True, R=sv["feats"], rmode=2, ract=ACT_RELU)
+        # total gradient at feats = ReLU path + SupCon path
+        ops.add_f32(hb["dfe"], None if d_feats is None else d_feats.contiguous(), hb["dfe"], hb["dfe_bf"], M * HEAD_DIM)
+        ops.colsum(hb["dfe"], hb["cs"], M, HEAD_DIM)
+        ops.colreduce(hb["cs"], P.g("LL.bias"), ncs, HEAD_DIM)
+        self.encoder._wgrad(sv["ectx"]["d"], Op(hb["dfe_bf"], HEAD_DIM), Op(sv["enc_out"], E), P.g("LL.weight"), HEAD_DIM, E, M)
+        if self.flag_fix_ssl:
+            return
+        ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)
+        self.encoder.backward(sv["ectx"], hb["denc"])
+
+    def _forward(self, x):
+        if x.dim() == 3:
+            x = x[:, :, 0]
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()   # main.py:60 hands over a transposed view
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (self._anchor,)):
+            out, feats, emb = _ModelFn.apply(self, x, self._anchor)
+        else:
+            out, feats, emb, _ = self._run_forward(x)
+        if self.is_train:
+            return out, feats, emb
+        return out
+
+    def forward(self, x_big):
+        if not self.is_train:
+            print("Inference mode")  # linear_nll:152
+        return self._forward(x_big)
+
+    # loss ------------------------------------------------------------------------------------------
+    def loss(self, output, feats, emb, labels, config, info=None):
+        return loss_custom(output, feats, emb, labels, config)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, feats, emb, labels):
+        dev = output.device
+        bz = output.shape[0]
+        Tq, dq = feats.shape[1], feats.shape[2]
+        res = torch.empty(3, device=dev)
+        coef = torch.empty(bz, output.shape[1], device=dev)
+        labels = labels.to(torch.int64).contiguous()
+        outc, F1, F2 = output.contiguous(), feats.contiguous().view(bz, -1), emb.contiguous()
+        ops.nll_fwd(outc, labels, bz, output.shape[1], res[0:1], coef)
+        K1, K2 = Tq * dq, emb.shape[1]
+        ws = torch.empty(max(ops.supcon_nchunks(K1), ops.supcon_nchunks(K2)) * bz * bz, device=dev)
+        G1, G2 = torch.empty(bz * bz, device=dev), torch.empty(bz * bz, device=dev)
+        ops.supcon_fwd(F1, labels, bz, K1, K1, Tq, 0.07, ws, G1, res[1:2])
+        ops.supcon_fwd(F2, labels, bz, K2, K2, K2, 0.07, ws, G2, res[2:3])   # emb as [bz,1,128,1]: T' = 128, d = 1
+        ctx.save_for_backward(coef, G1, G2, F1, F2)
+        ctx.dims = (bz, Tq, dq, K1, K2)
+        scale = torch.tensor([1.0, 1.0 / bz, 1.0 / bz], device=dev)   # Model.loss multiplies the SupCon terms by 1/bz
+        out = res * scale
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_ce, g_cf1, g_cf2):
+        coef, G1, G2, F1, F2 = ctx.saved_tensors
+        bz, Tq, dq, K1, K2 = ctx.dims
+        dev = coef.device
+        d_out = coef * g_ce
+        dF1 = torch.empty(bz, K1, device=dev)
+        dF2 = torch.empty(bz, K2, device=dev)
+        ops.supcon_bwd(F1, G1, g_cf1.contiguous().view(1), 1.0 / bz, bz, K1, K1, Tq, 0.07, dF1)
+        ops.supcon_bwd(F2, G2, g_cf2.contiguous().view(1), 1.0 / bz, bz, K2, K2, K2, 0.07, dF2)
+        return d_out, dF1.view(bz, Tq, dq), dF2, None
+
+
+def loss_custom(output, feats, emb, labels, config):
+    """model/loss_metrics.py:498-532 / Model.loss: dict of loss terms selected by loss_type."""
+    L_CE, L_CF1, L_CF2 = _LossFn.apply(output, feats, emb, labels)
+    lt = config["model"]["loss_type"]
+    if config["model"].get("contra_mode", "all") != "all":
+        raise NotImplementedError("contra_mode 'one'")
+    if lt == 1:
+        return {"L_CE": L_CE, "L_CF1": L_CF1, "L_CF2": L_CF2}
+    if lt == 2:
+        return {"L_CE": L_CE, "L_CF1": L_CF1}
+    if lt == 3:
+        return {"L_CE": L_CE, "L_CF2": L_CF2}
+    if lt == 4:
+        return {"L_CE": L_CE}
+    if lt == 5:
+        return {"L_CF1": L_CF1, "L_CF2": L_CF2}
+    return None
