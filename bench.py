@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py — train-step throughput of the MI355X hot path on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one optimizer step of `wav2vec2_linear_nll` at XLS-R-300M shape on a synthetic batch that is
+already resident in HBM: [RawBoost on the GPU if the config says so ->] forward -> NLL + SupCon losses
+-> backward -> gradient all-reduce (N > 1) -> fused AdamW.  Default workload = BASELINE.json
+configs[1]: batch 32 x 64000-sample clips per GPU, bf16 GEMM operands, RawBoost off.
+Weak scaling: every rank runs the same per-GPU batch; value = all ranks' utterances / max-over-ranks time.
+
+The JSON line also carries
+  roofline     — the dominant kernel family (scl_gemm_kernel, bf16 MFMA): algorithmic FLOPs per launch
+                 / average launch duration, both measured live with HIP events on the launch stream
+                 over the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline — the oracle's CPU train step (torch fp32, all host cores) on a bounded sample of the
+                 same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+FLOP_PER_UTT_STEP_64000 = 444e9  # 74.0 GMAC forward x 2 x 3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (configs[1]: 32; configs[2]: 64)")
+    ap.add_argument("--samples", type=int, default=64000)
+    ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo applied on the GPU inside the step (0 = off)")
+    ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle train step (the CPU restatement pinned to the reference) on a bounded sample:
+    `cpu_batch` utterances of the same length, one warm-up-free timed step."""
+    from oracle import head as OH
+    from oracle import wav2vec2 as W
+    cfg = W.W2VConfig.tiny() if args.tiny else W.W2VConfig()
+    ssl, head = W.init_state(cfg, seed=0), OH.init_head(cfg.embed, seed=1)
+    B = args.cpu_batch
+    x = 0.1 * torch.randn(B, args.samples, generator=torch.Generator().manual_seed(1234))
+    y = torch.tensor(([1] * ((5 * B + 10) // 11) + [0] * B)[:B])
+    t0 = time.time()
+    OH.train_step(ssl, head, cfg, x, y)
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train step (fwd+loss+bwd+AdamW, fp32 torch CPU oracle) on %d x %d-sample clips, %.1f s" % (B, args.samples, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from scl_amd import augment, ops
+    from scl_amd.encoder import W2VConfig
+    from scl_amd.lib import KID_GEMM
+    from scl_amd.model_linear import Model
+    from scl_amd.optim import FusedAdamW
+    from scl_amd.parallel import GradSync
+
+    cfg = W2VConfig.tiny() if args.tiny else W2VConfig()
+    margs = {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}
+    conf = {"model": {"contra_mode": "all", "loss_type": 1}}
+    model = Model(margs, dev, w2v_cfg=cfg, seed=0)          # same seed on every rank = replicated weights
+    model.train()                                            # dropout on, as train_epoch does (main.py:48)
+    sync = GradSync(model.P.grad) if world > 1 else None
+    model.grad_sync = sync
+    opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4, grad_sync=sync)   # main.py:339 defaults (max_lr, weight_decay)
+
+    B, L = args.batch, args.samples
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = (0.1 * torch.randn(B, L, generator=g)).to(dev)       # resident in HBM before the timed region
+    y = torch.tensor(([1] * ((5 * B + 10) // 11) + [0] * B)[:B], device=dev)
+    rb_args = None
+    if args.rawboost:
+        from scl_amd.datautils_common import default_rawboost_args
+        rb_args = default_rawboost_args()
+
+    def step():
+        xs = augment.rawboost_batch(x, rb_args, args.rawboost, 16000) if args.rawboost else x
+        out, feats, emb = model(xs)
+        losses = model.loss(out, feats, emb, y, conf)
+        total = None
+        for v in losses.values():
+            total = v if total is None else total + v
+        opt.zero_grad()
+        if sync is not None:
+            sync.begin()
+        total.backward()
+        opt.step()
+        return total
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.prof_enable(KID_GEMM, True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(KID_GEMM, False)
+    n_launch, gemm_ms, gemm_flops = ops.prof_read(KID_GEMM)
+    loss_val = float(last.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    utt_s = world * B * args.steps / dt
+    flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    res = {
+        "metric": "train-step utterances/sec (64000-sample clips)", "value": utt_s, "unit": "utterances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "wav2vec2_linear_nll (XLS-R-300M shape, random init) full train step: fwd + NLL/SupCon + bwd + "
+                               "AdamW, batch %d x %d-sample clips per GPU, RawBoost %s" % (B, L, ("algo %d on-GPU" % args.rawboost) if args.rawboost else "off"),
+                   "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
+        "final_loss": loss_val,
+        "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
+        "roofline": {"bound": "mfma", "kernel": "scl_gemm_kernel (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
+                     "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
+                     "gemm_share_of_step_time": gemm_ms * 1e-3 / dt},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,9 @@ resolved, importing / calling raises immediately.
 import ctypes
 import os
 
+import torch  # noqa: F401  — MUST precede CDLL: torch ships its own libamdhip64; loading ours first would put two HIP
+#                             runtimes in the process and the kernels would see "no ROCm-capable device"
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libscl_hip.so")
 FLAT = 0x7FFFFFFF
