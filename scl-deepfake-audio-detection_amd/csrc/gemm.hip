@@ -14,128 +14,151 @@
 //     tiles of v_mfma_f32_16x16x32_bf16), BK = 64 per barrier, fp32 accumulation.
 //   * LDS double buffer (2 x 32 KiB): global -> registers -> LDS, the loads of tile k+1 in
 //     flight while tile k is multiplied; one barrier per K step.
+//   * Loads are `buffer_load_dwordx4` through a raw buffer descriptor with 32-bit byte offsets:
+//     rows / reduction indices outside the problem get the offset 0xFFFFFFFF, which the hardware
+//     range check turns into zeros — the main loop has no divergent branch.  Row offsets of the
+//     utterance-batched operands ((r / rpb) * rbstride + (r % rpb) * ld) use a multiply-high
+//     "magic" division prepared on the host.
 //   * Operand layouts: K-contiguous operands are staged as [rows][64 k] with a 16-byte-slot XOR
 //     swizzle (slot ^= (row>>1)&7) so ds_read_b128 fragment reads are bank-conflict free;
 //     transposed operands ([K rows][128 contiguous]) are staged as they lie in memory (coalesced
 //     16-byte loads, 32-byte-chunk XOR swizzle) and delivered to the MFMA through
 //     ds_read_b64_tr_b16 — no transposed copies of weights or activations exist anywhere.
-//   * Epilogue fused: alpha, bias, activation (+ pre-activation second output), residual add or
-//     activation-gradient multiply, dropout mask, bf16/f32 store, split-K slabs.
+//   * The MFMA is issued with the operands swapped (D = B-frag x A-frag), so each lane ends up
+//     with 4 CONSECUTIVE output columns of one row: the epilogue (alpha, bias, activation +
+//     pre-activation second output, residual add or activation-gradient multiply, dropout mask)
+//     is vectorised 4-wide and stores 8 B (bf16) / 16 B (f32) per lane.
+//   * Workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
+constexpr unsigned OOB = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint4 mask_tail(uint4 v, int nvalid) {  // keep the first nvalid (1..7) bf16
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+struct OpK {             // device-side operand description (bytes, 32-bit)
+    const void* ptr;
+    long long bs1, bs2;  // batch strides in BYTES
+    unsigned rb_bytes, ld_bytes, cout_bytes;
+    unsigned rpb, rpb_magic, rpb_shift;
+    unsigned cin_shift, cin_mask;
+};
+struct GemmK {
+    OpK A, B;
+    void* C; void* C2; const void* R; const float* bias;
+    long long c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2;  // elements
+    unsigned c_rpb, c_magic, c_shift;
+    int ldc, M, N, K, nb2, splitk, flags, vec_ok;
+    float alpha, drop_p;
+    unsigned drop_seed;
+};
+
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic, unsigned shift) {
+    return (unsigned)(((unsigned long long)__umulhi(magic, n) + n) >> shift);
+}
+__device__ __forceinline__ unsigned row_off(const OpK& o, unsigned r) {
+    const unsigned q = udiv_magic(r, o.rpb_magic, o.rpb_shift);
+    return q * o.rb_bytes + (r - q * o.rpb) * o.ld_bytes;
+}
+__device__ __forceinline__ unsigned col_off(const OpK& o, unsigned c) {
+    return (c >> o.cin_shift) * o.cout_bytes + ((c & o.cin_mask) << 1);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// buffer descriptor from PROVABLY wave-uniform words, or hipcc wraps every buffer_load in a waterfall loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base) {
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0xFFFFFFFF, 0x00020000);
+}
+
+__device__ __forceinline__ u32x4 mask_tail(u32x4 v, int nvalid) {  // keep the first nvalid (<= 8) bf16
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        if (2 * d >= nvalid) w[d] = 0u;
-        else if (2 * d + 1 >= nvalid) w[d] &= 0x0000FFFFu;
+        const unsigned m = (2 * d + 1 < nvalid) ? 0xFFFFFFFFu : ((2 * d < nvalid) ? 0x0000FFFFu : 0u);
+        v[d] &= m;
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return v;
 }
 
 // ---- staging of a K-contiguous operand tile: [128 rows][64 k] -------------------------------
 struct StageK {
-    const bf16_t* base;
-    int64_t rowoff[4];
-    int64_t kq_off;
-    int krem, kcur, kend, cin;
-    int64_t cout;
-    uint32_t rowok;  // bit i: row i in range
-    uint32_t lds_off[4];
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned rowoff[4];   // OOB for rows outside the problem
+    unsigned lds_off[4];
+    int kcur, kend;
 
-    __device__ __forceinline__ void init(const SclOperand& o, const bf16_t* b, int row0, int rowlimit,
-                                         int kbegin, int kend_, int tid) {
-        base = b;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int row0, int rowlimit, int kbegin, int kend_, int tid) {
+        rsrc = make_rsrc(base);
         const int c = tid & 7;
-        rowok = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 3) + 32 * i;
             const int r = row0 + row;
-            const bool ok = r < rowlimit;
-            const int rr = ok ? r : 0;
-            rowoff[i] = (int64_t)(rr / o.rpb) * o.rbstride + (int64_t)(rr % o.rpb) * o.ld;
-            rowok |= (ok ? 1u : 0u) << i;
-            lds_off[i] = (uint32_t)(row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            rowoff[i] = r < rowlimit ? row_off(o, (unsigned)r) : OOB;
+            lds_off[i] = (unsigned)(row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
         }
-        cin = o.cin; cout = o.cout;
         kcur = kbegin + 8 * c; kend = kend_;
-        kq_off = (int64_t)(kcur / cin) * cout;
-        krem = kcur % cin;
     }
-    __device__ __forceinline__ void load(uint4 (&r)[4]) const {
-        const int nvalid = kend - kcur;
+    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[4]) const {
+        const unsigned koff = col_off(o, (unsigned)kcur);
+        const bool kok = kcur < kend;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (((rowok >> i) & 1u) && nvalid > 0) {
-                v = *reinterpret_cast<const uint4*>(base + rowoff[i] + kq_off + krem);
-                if (nvalid < 8) v = mask_tail(v, nvalid);
-            }
-            r[i] = v;
+            const unsigned off = (kok && rowoff[i] != OOB) ? rowoff[i] + koff : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         }
     }
-    __device__ __forceinline__ void advance() {
-        kcur += BK; krem += BK;
-        while (krem >= cin) { krem -= cin; kq_off += cout; }
+    __device__ __forceinline__ void fix_tail(u32x4 (&r)[4]) const {   // only called on a partial last K step
+        const int nvalid = kend - kcur;
+        if (nvalid < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = mask_tail(r[i], nvalid);
+        }
     }
+    __device__ __forceinline__ void advance() { kcur += BK; }
 };
 
 // ---- staging of a transposed operand tile: [64 k rows][128 contiguous] ----------------------
 struct StageT {
-    const bf16_t* base;
-    int64_t coloff;
-    int64_t rq_off[4];
-    int rrem[4];
-    int rcur, kend, rpb, ld, ncolvalid;
-    int64_t rbstride;
-    uint32_t lds_off[4];
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned coloff;      // OOB when this thread's 8 columns are all outside the problem
+    unsigned lds_off[4];
+    int rcur, kend, ncolvalid;
 
-    __device__ __forceinline__ void init(const SclOperand& o, const bf16_t* b, int col0, int collimit,
-                                         int kbegin, int kend_, int tid) {
-        base = b;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int col0, int collimit, int kbegin, int kend_, int tid) {
+        rsrc = make_rsrc(base);
         const int c16 = tid & 15;
         const int col = col0 + 8 * c16;
         int nv = collimit - col; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
         ncolvalid = nv;
-        const int cc = nv > 0 ? col : 0;
-        coloff = (int64_t)(cc / o.cin) * o.cout + (cc % o.cin);
-        rpb = o.rpb; ld = o.ld; rbstride = o.rbstride;
+        coloff = nv > 0 ? col_off(o, (unsigned)col) : OOB;
         rcur = kbegin + (tid >> 4); kend = kend_;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int krow = (tid >> 4) + 16 * i;
-            const int r = kbegin + krow;
-            rq_off[i] = (int64_t)(r / rpb) * rbstride;
-            rrem[i] = r % rpb;
             const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
-            lds_off[i] = (uint32_t)(krow * 256 + (((c16 >> 1) ^ sw) << 5) + ((c16 & 1) << 4));
+            lds_off[i] = (unsigned)(krow * 256 + (((c16 >> 1) ^ sw) << 5) + ((c16 & 1) << 4));
         }
     }
-    __device__ __forceinline__ void load(uint4 (&r)[4]) const {
+    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[4]) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ncolvalid > 0 && (rcur + 16 * i) < kend) {
-                v = *reinterpret_cast<const uint4*>(base + rq_off[i] + (int64_t)rrem[i] * ld + coloff);
-                if (ncolvalid < 8) v = mask_tail(v, ncolvalid);
-            }
-            r[i] = v;
+            const int rr = rcur + 16 * i;
+            const unsigned off = (rr < kend && coloff != OOB) ? row_off(o, (unsigned)rr) + coloff : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         }
     }
-    __device__ __forceinline__ void advance() {
-        rcur += BK;
+    __device__ __forceinline__ void fix_tail(u32x4 (&r)[4]) const {   // only called on column-edge tiles
+        if (ncolvalid < 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rrem[i] += BK;
-            while (rrem[i] >= rpb) { rrem[i] -= rpb; rq_off[i] += rbstride; }
+            for (int i = 0; i < 4; ++i) r[i] = mask_tail(r[i], ncolvalid);
         }
     }
+    __device__ __forceinline__ void advance() { rcur += BK; }
 };
 
 template <bool T> struct StageSel { typedef StageK type; };
@@ -162,34 +185,67 @@ __device__ __forceinline__ bf16x8 frag_t(const char* tile, int colblk, int ks, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// element-wise epilogue for edge tiles / unaligned outputs (rare path, kept out of line)
+struct EpiArgs { void* C; void* C2; const void* R; int N, flags; unsigned drop_seed; float drop_p; };
+__device__ __noinline__ void epi_scalar(EpiArgs d, float t, long long o, int col, const float* bias) {
+    if (col >= d.N) return;
+    const int flags = d.flags;
+    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF, rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF, ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+    if (flags & SCL_GEMM_HAS_BIAS) t += bias[col];
+    if (flags & SCL_GEMM_HAS_C2) {
+        if (flags & SCL_GEMM_C2_F32) reinterpret_cast<float*>(d.C2)[o] = t;
+        else reinterpret_cast<bf16_t*>(d.C2)[o] = f2bf(t);
+    }
+    t = act_f(act, t);
+    float r = 0.f;
+    if (rmode) r = (flags & SCL_GEMM_R_F32) ? reinterpret_cast<const float*>(d.R)[o] : bf2f(reinterpret_cast<const bf16_t*>(d.R)[o]);
+    if (rmode == 2) t *= act_grad_f(ract, r);
+    if (flags & SCL_GEMM_DROPOUT) t *= dropout_scale(d.drop_seed, (uint64_t)o, d.drop_p);
+    if (rmode == 1) t += r;
+    if (flags & SCL_GEMM_C_F32) reinterpret_cast<float*>(d.C)[o] = t;
+    else reinterpret_cast<bf16_t*>(d.C)[o] = f2bf(t);
+}
+
 template <bool AT, bool BT>
-__global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const SclGemmDesc d) {
+__global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
+    // XCD-aware tile id: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
+    // contiguous run of tiles (neighbouring tiles share the A row-panel / B column-panel in its L2)
+    const int ntiles = gridDim.x;
+    int tile;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
     int z = blockIdx.z;
     const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z % d.nb2;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
 
-    // K range of this split (multiples of BK)
     const int nk_total = (d.K + BK - 1) / BK;
     const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
     const int kbegin = ksplit * nk_per * BK;
     int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
 
-    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
-    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
 
     typename StageSel<AT>::type sa;
     typename StageSel<BT>::type sb;
     sa.init(d.A, Ab, m0, d.M, kbegin, kend, tid);
     sb.init(d.B, Bb, n0, d.N, kbegin, kend, tid);
+    // block-uniform conditions under which loaded vectors can be partially valid
+    const bool a_edge = AT ? (m0 + BM > d.M && (d.M & 7)) : false;
+    const bool b_edge = BT ? (n0 + BN > d.N && (d.N & 7)) : false;
+    const bool k_tail = (kend & 7) != 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -197,13 +253,15 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const SclGemmDesc d) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
+    u32x4 ra[4], rb[4];
     if (nk > 0) {
-        sa.load(ra); sb.load(rb);
+        sa.load(d.A, ra); sb.load(d.B, rb);
+        if (AT ? a_edge : (k_tail && nk == 1)) sa.fix_tail(ra);
+        if (BT ? b_edge : (k_tail && nk == 1)) sb.fix_tail(rb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(smem + sa.lds_off[i]) = ra[i];
-            *reinterpret_cast<uint4*>(smem + TILE_BYTES + sb.lds_off[i]) = rb[i];
+            *reinterpret_cast<u32x4*>(smem + sa.lds_off[i]) = ra[i];
+            *reinterpret_cast<u32x4*>(smem + TILE_BYTES + sb.lds_off[i]) = rb[i];
         }
     }
     __syncthreads();
@@ -213,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const SclGemmDesc d) {
         const bool more = (kt + 1) < nk;
         if (more) {
             sa.advance(); sb.advance();
-            sa.load(ra); sb.load(rb);
+            sa.load(d.A, ra); sb.load(d.B, rb);
         }
         const char* tA = smem + cur * (2 * TILE_BYTES);
         const char* tB = tA + TILE_BYTES;
@@ -225,66 +283,90 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const SclGemmDesc d) {
                 fa[i] = AT ? frag_t(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
                 fb[i] = BT ? frag_t(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
             }
+            // swapped operands: D[i = n within tile][j = m within tile]
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
+            const bool last = (kt + 2) == nk;
+            if (AT ? a_edge : (k_tail && last)) sa.fix_tail(ra);
+            if (BT ? b_edge : (k_tail && last)) sb.fix_tail(rb);
             char* nA = smem + (cur ^ 1) * (2 * TILE_BYTES);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<uint4*>(nA + sa.lds_off[i]) = ra[i];
-                *reinterpret_cast<uint4*>(nA + TILE_BYTES + sb.lds_off[i]) = rb[i];
+                *reinterpret_cast<u32x4*>(nA + sa.lds_off[i]) = ra[i];
+                *reinterpret_cast<u32x4*>(nA + TILE_BYTES + sb.lds_off[i]) = rb[i];
             }
         }
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------
+    // ---- epilogue: lane holds C[row = m0 + wr*64 + mt*16 + (lane&15)][col = n0 + wc*64 + nt*16 + 4*(lane>>4) + 0..3]
     const int flags = d.flags;
     const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
     const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
     const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
     const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
     const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
-    const int64_t cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (int64_t)ksplit * d.c_split_stride;
+    const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
     const float* bias = has_bias ? d.bias + z2 * d.bias_bs2 : nullptr;
     const int g = lane >> 4, lc = lane & 15;
+    const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+        const int row = m0 + wr * 64 + mt * 16 + lc;
+        const bool rok = row < d.M;
+        const unsigned q = udiv_magic((unsigned)(rok ? row : 0), d.c_magic, d.c_shift);
+        const long long roff = cbase + (long long)q * d.c_rbstride + (long long)((unsigned)(rok ? row : 0) - q * d.c_rpb) * d.ldc;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = m0 + wr * 64 + mt * 16 + 4 * g + reg;
-            if (row >= d.M) continue;
-            const int64_t roff = cbase + (int64_t)(row / d.c_rpb) * d.c_rbstride + (int64_t)(row % d.c_rpb) * d.ldc;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int col = n0 + wc * 64 + nt * 16 + lc;
-                if (col >= d.N) continue;
-                float v = d.alpha * acc[mt][nt][reg];
-                if (has_bias) v += bias[col];
-                const int64_t off = roff + col;
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = n0 + wc * 64 + nt * 16 + 4 * g;
+            const long long off = roff + col;
+            float v[4] = {d.alpha * acc[mt][nt][0], d.alpha * acc[mt][nt][1], d.alpha * acc[mt][nt][2], d.alpha * acc[mt][nt][3]};
+            if (rok && d.vec_ok && col + 4 <= d.N) {
+                if (has_bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
                 if (has_c2) {
-                    if (c2_f32) reinterpret_cast<float*>(d.C2)[off] = v;
-                    else reinterpret_cast<bf16_t*>(d.C2)[off] = f2bf(v);
+                    if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
-                v = act_f(act, v);
+                if (act) {
+                    v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]);
+                }
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+                if (rmode) {
+                    if (r_f32) {
+                        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.R) + off);
+                        r0 = t.x; r1 = t.y; r2 = t.z; r3 = t.w;
+                    } else {
+                        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(d.R) + off);
+                        r0 = __uint_as_float(t.x << 16); r1 = __uint_as_float(t.x & 0xFFFF0000u);
+                        r2 = __uint_as_float(t.y << 16); r3 = __uint_as_float(t.y & 0xFFFF0000u);
+                    }
+                }
                 if (rmode == 2) {
-                    const float h = r_f32 ? reinterpret_cast<const float*>(d.R)[off]
-                                          : bf2f(reinterpret_cast<const bf16_t*>(d.R)[off]);
-                    v *= act_grad_f(ract, h);
+                    v[0] *= act_grad_f(ract, r0); v[1] *= act_grad_f(ract, r1); v[2] *= act_grad_f(ract, r2); v[3] *= act_grad_f(ract, r3);
                 }
-                if (drop) v *= dropout_scale(d.drop_seed, (uint64_t)off, d.drop_p);
-                if (rmode == 1) {
-                    v += r_f32 ? reinterpret_cast<const float*>(d.R)[off]
-                               : bf2f(reinterpret_cast<const bf16_t*>(d.R)[off]);
+                if (drop) {
+                    v[0] *= dropout_scale(d.drop_seed, (uint64_t)(off + 0), d.drop_p); v[1] *= dropout_scale(d.drop_seed, (uint64_t)(off + 1), d.drop_p);
+                    v[2] *= dropout_scale(d.drop_seed, (uint64_t)(off + 2), d.drop_p); v[3] *= dropout_scale(d.drop_seed, (uint64_t)(off + 3), d.drop_p);
                 }
-                if (c_f32) reinterpret_cast<float*>(d.C)[off] = v;
-                else reinterpret_cast<bf16_t*>(d.C)[off] = f2bf(v);
+                if (rmode == 1) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                if (c_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            } else if (rok) {
+                // edge tile / unaligned C: element-wise path
+                epi_scalar(ea, v[0], off + 0, col + 0, bias);
+                epi_scalar(ea, v[1], off + 1, col + 1, bias);
+                epi_scalar(ea, v[2], off + 2, col + 2, bias);
+                epi_scalar(ea, v[3], off + 3, col + 3, bias);
             }
         }
     }
@@ -312,12 +394,38 @@ __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* 
     }
 }
 
-bool operand_ok(const SclOperand& o, const char* name) {
+// Granlund-Montgomery round-up magic: q = (mulhi(magic, n) + n) >> shift for all n < 2^31, 1 <= d < 2^31
+void make_magic(unsigned dv, unsigned* magic, unsigned* shift) {
+    unsigned l = 0;
+    while ((1ull << l) < dv) ++l;
+    *shift = l;
+    *magic = (unsigned)((((1ull << l) - dv) << 32) / dv + 1);
+}
+
+bool fill_operand(const SclOperand& o, const char* name, long long rows, long long contig, OpK* k) {
     if (!o.ptr || ((uintptr_t)o.ptr & 15)) { scl_set_error("gemm: %s ptr null or not 16B aligned", name); return false; }
-    if (o.rpb < 1 || o.cin < 8 || (o.cin != 0x7fffffff && (o.cin & 7))) { scl_set_error("gemm: %s rpb/cin invalid", name); return false; }
+    if (o.rpb < 1 || o.cin < 8) { scl_set_error("gemm: %s rpb/cin invalid", name); return false; }
     if ((o.ld & 7) || (o.rbstride & 7) || (o.cout & 7) || (o.bs1 & 7) || (o.bs2 & 7)) {
         scl_set_error("gemm: %s strides must be multiples of 8 elements", name); return false;
     }
+    unsigned sh = 31, mask = 0x7fffffffu;
+    if (o.cin != 0x7fffffff) {
+        if (o.cin & (o.cin - 1)) { scl_set_error("gemm: %s cin must be a power of two (or flat)", name); return false; }
+        sh = 0; while ((1 << sh) < o.cin) ++sh;
+        mask = (unsigned)o.cin - 1;
+    }
+    // largest element offset this launch can touch must stay below 2^31 elements (32-bit byte offsets)
+    const long long rq = (rows - 1) / o.rpb, rr = o.rpb == 0x7fffffff ? rows - 1 : (long long)o.rpb - 1;
+    const long long cq = o.cin == 0x7fffffff ? 0 : (contig - 1) / o.cin;
+    const long long cr = o.cin == 0x7fffffff ? contig - 1 : (long long)o.cin - 1;
+    const long long maxoff = rq * o.rbstride + (rr < rows - 1 ? rr : rows - 1) * (long long)o.ld + cq * o.cout + cr + 8;
+    if (maxoff < 0 || maxoff >= (1ll << 31) - 16 || rows >= (1ll << 31)) {
+        scl_set_error("gemm: %s extent exceeds 32-bit byte offsets (%lld elements)", name, maxoff); return false;
+    }
+    k->ptr = o.ptr; k->bs1 = o.bs1 * 2; k->bs2 = o.bs2 * 2;
+    k->rb_bytes = (unsigned)(o.rbstride * 2); k->ld_bytes = (unsigned)o.ld * 2u; k->cout_bytes = (unsigned)(o.cout * 2);
+    k->rpb = (unsigned)o.rpb; make_magic((unsigned)o.rpb, &k->rpb_magic, &k->rpb_shift);
+    k->cin_shift = sh; k->cin_mask = mask;
     return true;
 }
 
@@ -328,7 +436,10 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     const SclGemmDesc& d = *dp;
     SCL_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: M,N,K must be positive (%d,%d,%d)", d.M, d.N, d.K);
     SCL_REQUIRE(d.nb1 >= 1 && d.nb2 >= 1 && d.splitk >= 1, "gemm: nb1/nb2/splitk must be >= 1");
-    if (!operand_ok(d.A, "A") || !operand_ok(d.B, "B")) return SCL_EINVAL;
+    const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
+    GemmK k;
+    if (!fill_operand(d.A, "A", at ? d.K : d.M, at ? d.M : d.K, &k.A)) return SCL_EINVAL;
+    if (!fill_operand(d.B, "B", bt ? d.K : d.N, bt ? d.N : d.K, &k.B)) return SCL_EINVAL;
     SCL_REQUIRE(d.C && d.c_rpb >= 1, "gemm: C null or c_rpb < 1");
     const int rmode = (d.flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
     SCL_REQUIRE(rmode == 0 || d.R, "gemm: RMODE set but R is null");
@@ -340,16 +451,25 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
     SCL_REQUIRE(zdim <= 65535, "gemm: batch*splitk too large (%lld)", zdim);
+    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias;
+    k.c_bs1 = d.c_bs1; k.c_bs2 = d.c_bs2; k.c_rbstride = d.c_rbstride; k.c_split_stride = d.c_split_stride; k.bias_bs2 = d.bias_bs2;
+    k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
+    k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
+    k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
+    // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias
+    auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p & (bytes - 1)) == 0; };
+    const bool strides4 = !(d.ldc & 3) && !(d.c_bs1 & 3) && !(d.c_bs2 & 3) && !(d.c_rbstride & 3) && !(d.c_split_stride & 3) && !(d.bias_bs2 & 3);
+    k.vec_ok = strides4 && al(d.C, (d.flags & SCL_GEMM_C_F32) ? 16 : 8) && al(d.C2, (d.flags & SCL_GEMM_C2_F32) ? 16 : 8) &&
+               al(d.R, (d.flags & SCL_GEMM_R_F32) ? 16 : 8) && al(d.bias, 16);
     dim3 grid(tiles, 1, (unsigned)zdim), block(256);
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
-    const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
     {
         SclProfScope prof(SCL_KID_GEMM, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
-        if (!at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<false, false>), grid, block, lds, s, d);
-        else if (!at && bt) hipLaunchKernelGGL((scl_gemm_kernel<false, true>), grid, block, lds, s, d);
-        else if (at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<true, false>), grid, block, lds, s, d);
-        else hipLaunchKernelGGL((scl_gemm_kernel<true, true>), grid, block, lds, s, d);
+        if (!at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<false, false>), grid, block, lds, s, k);
+        else if (!at && bt) hipLaunchKernelGGL((scl_gemm_kernel<false, true>), grid, block, lds, s, k);
+        else if (at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<true, false>), grid, block, lds, s, k);
+        else hipLaunchKernelGGL((scl_gemm_kernel<true, true>), grid, block, lds, s, k);
     }
     return scl_check_launch("scl_gemm_bf16");
 }

@@ -190,14 +190,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
-// out[c] (+)= sum_p part[p][c]
-__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
-                                 int64_t pstride, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_p part[p][c]; 32 columns x 8 part-lanes per block (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
+                                                        int64_t pstride, int accumulate) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * pstride + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int p = ty; p < nparts; p += 8) s += part[(int64_t)p * pstride + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // column sums of a [M, N] matrix (bias gradients): part[rowchunk][n]
@@ -278,7 +287,7 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
 
 extern "C" int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream) {
     SCL_REQUIRE(part && out && nparts >= 1 && C >= 1, "colreduce: bad args");
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride, accumulate);
     return scl_check_launch("scl_colreduce_f32");
 }
 

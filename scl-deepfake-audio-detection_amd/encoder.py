@@ -155,7 +155,7 @@ class Encoder:
         d["h1"] = [bf(M * E) for _ in range(cfg.layers)]
         d["m1"], d["r1"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
         d["qkv"] = [bf(M * 3 * E + slack) for _ in range(cfg.layers)]
-        d["S"] = f32(B * H * T * T)
+        d["S"] = f32(B * H * T * Tp)   # row stride Tp keeps the 4-wide epilogue stores aligned
         d["P"] = [bf(B * H * T * Tp + 1024) for _ in range(cfg.layers)]
         d["ctx"] = [bf(M * E) for _ in range(cfg.layers)]
         d["x1"] = [f32(M * E) for _ in range(cfg.layers)]
@@ -254,8 +254,8 @@ class Encoder:
                      bias=self.b(pn + "self_attn.q_proj.bias"))  # q,k,v biases are adjacent in the flat buffer
             qkv = d["qkv"][n]
             ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
-                     nb1=B, nb2=H, alpha=D ** -0.5, c_bs1=H * T * T, c_bs2=T * T)
-            ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, T, Tp)
+                     nb1=B, nb2=H, alpha=D ** -0.5, ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
+            ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, Tp, Tp)
             ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
                      d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
             ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
@@ -318,8 +318,8 @@ class Encoder:
                      ldc=3 * E, c_bs1=T * 3 * E, c_bs2=D, c_offset=2 * E, **bq)
             # dP = dctx V^T
             ops.gemm(Op(d["d_ctx"], E, bs1=T * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["S"], T, T, D,
-                     c_bs1=H * T * T, c_bs2=T * T, **bq)
-            ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, T, Tp)
+                     ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp, **bq)
+            ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, Tp, Tp)
             sc = D ** -0.5
             dS = Op(d["dS"], Tp, bs1=H * T * Tp, bs2=T * Tp)
             ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), dqkv, T, D, T, b_t=True, alpha=sc, ldc=3 * E,
