@@ -99,7 +99,7 @@ class Encoder:
         self.wk = [None] + [bf(C, cfg.conv_kernels[i] * C) for i in range(1, len(cfg.conv_kernels))]
         self.pos_wf, self.pos_wd, self.pos_norm = bf(G, Cg, K * Cg), bf(G, Cg, K * Cg), f32(K)
         self.ws_small = f32(max(K, 16))
-        self._slab = None
+        self.on_grads_ready = None   # callback(lo_offset): every gradient at flat offset >= lo_offset is final (DP overlap)
 
     # ---- weights ---------------------------------------------------------------------------------
     def n(self, name):
@@ -334,6 +334,8 @@ class Encoder:
                               other, otherb, d["ln_pg"], d["ln_pb"], M, E)
             self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d xin
+            if self.on_grads_ready is not None:
+                self.on_grads_ready(P.off(self.n(pn + "self_attn_layer_norm.weight")))
         # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
         pb = K // 2 - 1
         ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)

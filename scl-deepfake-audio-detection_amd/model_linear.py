@@ -92,7 +92,11 @@ class Model(nn.Module):
         self.loss_type = args["loss_type"]
         if self.contra_mode != "all":
             raise NotImplementedError("contra_mode 'one' (the reference's configs all use 'all')")
-        self.cfg = w2v_cfg or W2VConfig(encoder_layerdrop=float(args.get("encoder_layerdrop", 0.0)))
+        if w2v_cfg is None:
+            # optional YAML key `w2v_arch`: "xlsr_300m" (default, the reference's only encoder) or "tiny" (tests / plumbing)
+            w2v_cfg = W2VConfig.tiny() if args.get("w2v_arch", "xlsr_300m") == "tiny" else \
+                W2VConfig(encoder_layerdrop=float(args.get("encoder_layerdrop", 0.0)))
+        self.cfg = w2v_cfg
         specs = param_specs(self.cfg) + head_specs(self.cfg.embed)
         # memory order: trainable encoder, head, then the checkpoint-only tensors (FlatParams puts those last)
         self.P = FlatParams(specs, self.device)
@@ -107,6 +111,7 @@ class Model(nn.Module):
         self._hbufs = {}
         self._step_seed = 0
         self.out_dim = self.cfg.embed
+        self.grad_sync = None   # scl_amd.parallel.GradSync when data-parallel (set by FusedAdamW)
 
     # nn.Module plumbing ----------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):
@@ -206,6 +211,9 @@ class Model(nn.Module):
         if self.flag_fix_ssl:
             return
         ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)
+        if self.grad_sync is not None:      # head gradients (the END of the flat buffer) are final: start their all-reduce
+            self.grad_sync.ready_above(P.off("LL.weight"))
+            self.encoder.on_grads_ready = self.grad_sync.ready_above
         self.encoder.backward(sv["ectx"], hb["denc"])
 
     def _forward(self, x):

@@ -22,6 +22,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.P.device)
         self.step_count = 0
         self.grad_sync = grad_sync
+        model.grad_sync = grad_sync
 
     def zero_grad(self, set_to_none=True):
         # gradients live in one flat buffer that every backward overwrites in full; nothing to clear,

@@ -1,0 +1,272 @@
+"""Anchor-pack builder: host-side mirror of the reference's `Dataset_for.__getitem__`
+(datautils/asvspoof_2019_augall_3.py:103-146 and its siblings aug_2 / SCL_normal / augall_5), with every
+waveform transformation executed on the GPU (scl_amd.augment) instead of in DataLoader workers.
+
+Contract kept (SURVEY.md §8b "Data plugin"):
+  Dataset_for(args, list_IDs=, labels=, base_dir=, algo=, repeat_pad=, **yaml_kwargs)[i]
+      -> (id: str, Tensor[L, V] fp32, Tensor[V] fp32 labels)         view order and labels as the reference
+  Dataset_for_eval(list_IDs=, base_dir=, padding_type=)[i] -> (Tensor[64600], id)
+  augmenters are looked up BY NAME with signature (x, args, sr, audio_path=...) -> waveform
+The returned pack lives on the GPU as a transposed view of a contiguous [V, L] buffer, so that
+main.py's `batch_x.squeeze(0).transpose(0, 1)` yields the contiguous [V, L] the model wants.
+
+Randomness: `np.random` / `random` are consumed in the reference's order (one pack after the other),
+so a seeded run draws the same files, crops and RawBoost parameters as the reference would.
+File decoding is host IO (out of the kernel path): WAV through the stdlib, anything else through
+`soundfile` when it is installed; `set_audio_loader()` lets callers (and the tests) supply arrays.
+"""
+import os
+import random
+import wave
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import augment
+
+_LOADER = None
+_FILE_INDEX = {}
+
+
+def set_audio_loader(fn):
+    """fn(path, sr) -> 1-D float32 numpy array at `sr` Hz (mono); None restores the default reader."""
+    global _LOADER
+    _LOADER = fn
+
+
+def _read_wav(path):
+    with wave.open(path, "rb") as w:
+        n, ch, sw, sr = w.getnframes(), w.getnchannels(), w.getsampwidth(), w.getframerate()
+        raw = w.readframes(n)
+    if sw == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif sw == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError("unsupported WAV sample width %d in %s" % (sw, path))
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1)
+    return x, sr
+
+
+def load_audio(path, sr=16000):
+    """librosa.load(path, sr=sr, mono=True) stand-in for the formats this image can decode."""
+    if _LOADER is not None:
+        return np.asarray(_LOADER(path, sr), dtype=np.float32)
+    if path.lower().endswith(".wav"):
+        x, fs = _read_wav(path)
+    else:
+        try:
+            import soundfile as sf
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError("cannot decode %s: install `soundfile` or call scl_amd.pack.set_audio_loader()" % path) from e
+        x, fs = sf.read(path, dtype="float32", always_2d=False)
+        if x.ndim > 1:
+            x = x.mean(axis=1)
+    if fs != sr:
+        from scipy.signal import resample_poly
+        g = np.gcd(int(fs), int(sr))
+        x = resample_poly(x, sr // g, fs // g).astype(np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def list_audio_files(root):
+    """Index of a noise / RIR corpus, built ONCE per path (the reference os.walk()s it for every sample,
+    audio_augmentor/background_noise.py:22, reverb.py:30)."""
+    if root not in _FILE_INDEX:
+        files = []
+        for dp, _, fns in os.walk(root):
+            for fn in fns:
+                if fn.split(".")[-1] in ("wav", "mp3", "flac"):
+                    files.append(os.path.join(dp, fn))
+        _FILE_INDEX[root] = files
+    return _FILE_INDEX[root]
+
+
+def _dev(args):
+    return torch.device(getattr(args, "device", "cuda"))
+
+
+def _to_dev(x, args):
+    if torch.is_tensor(x):
+        return x.to(_dev(args), dtype=torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_dev(args))
+
+
+# ---- augmenters, resolved by name (augall_3:271-374) ---------------------------------------------
+def RawBoost12(x, args, sr=16000, audio_path=None):
+    """RawBoost algo 5 (LnL then ISD), augall_3:359-374."""
+    if not getattr(args, "online_aug", True):
+        return _offline_cached("RawBoost12", x, args, sr, audio_path, lambda: RawBoost12_online(x, args, sr))
+    return RawBoost12_online(x, args, sr)
+
+
+def RawBoost12_online(x, args, sr=16000):
+    xd = _to_dev(x, args)
+    return augment.rawboost_batch(xd[None], args, 5, sr)[0]
+
+
+def background_noise_wrapper(x, args, sr=16000, audio_path=None):
+    """MUSAN overlay, augall_3:271-283 -> audio_augmentor/background_noise.py:40-56 (returns int16-scaled values)."""
+    noise_list = list_audio_files(args.noise_path)
+    noise_file = random.choice(noise_list)
+    snr_db = random.randint(5, 15)
+    noise = load_audio(noise_file, sr)
+    noise_i16 = augment.to_int16(_to_dev(noise, args))   # AudioSegment.from_file decodes to int16 PCM
+    return augment.background_noise(_to_dev(x, args), noise_i16, snr_db)
+
+
+def reverb_wrapper(x, args, sr=16000, audio_path=None):
+    """RIR convolution, augall_3:314-326 -> audio_augmentor/reverb.py:33-44 (returns int16-scaled values, length L+R-1)."""
+    rir_file = random.choice(list_audio_files(args.rir_path))
+    rir = load_audio(rir_file, sr)
+    return augment.reverb(_to_dev(x, args), _to_dev(rir, args))
+
+
+def speed_wrapper(x, args, sr=16000, audio_path=None):
+    raise NotImplementedError("speed_wrapper (conf-5 only) is outside the round-1 hot-path scope (SURVEY.md §8f rank 4)")
+
+
+def pitch_wrapper(x, args, sr=16000, audio_path=None):
+    raise NotImplementedError("pitch_wrapper (conf-5 only) is outside the round-1 hot-path scope (SURVEY.md §8f rank 4)")
+
+
+def _offline_cached(method, x, args, sr, audio_path, make):
+    """online_aug: false — reuse / create <aug_dir>/<method>/<utt> (PCM16), augall_3:366-374."""
+    aug_path = os.path.join(args.aug_dir, method, os.path.basename(audio_path))
+    if os.path.exists(aug_path):
+        return _to_dev(load_audio(aug_path, sr), args)
+    y = make()
+    os.makedirs(os.path.dirname(aug_path), exist_ok=True)
+    pcm = np.clip(np.round(y.detach().cpu().numpy() * 32767.0), -32768, 32767).astype("<i2")
+    if aug_path.lower().endswith(".wav"):
+        with wave.open(aug_path, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+    else:
+        import soundfile as sf
+        sf.write(aug_path, pcm, sr, subtype="PCM_16")
+    return y
+
+
+AUGMENTERS = {"RawBoost12": RawBoost12, "background_noise_wrapper": background_noise_wrapper, "reverb_wrapper": reverb_wrapper,
+              "speed_wrapper": speed_wrapper, "pitch_wrapper": pitch_wrapper}
+
+
+# ---- file lists (augall_3:14-47) -------------------------------------------------------------------
+def gen_list_scp(dir_meta, is_train=False, is_eval=False, is_dev=False):
+    base = os.path.dirname(dir_meta)
+    if is_train:
+        meta = os.path.join(base, "scp/train_bonafide.lst")
+    elif is_dev:
+        meta = os.path.join(base, "scp/dev_bonafide.lst")
+    elif is_eval:
+        meta = os.path.join(base, "scp/test.lst")
+    else:
+        raise ValueError("one of is_train / is_dev / is_eval must be set")
+    with open(meta) as f:
+        files = [ln.strip().split()[0] for ln in f if ln.strip()]
+    return [], files
+
+
+def pad_eval(x, padding_type, max_len=64600):
+    """augall_3:49-60"""
+    n = x.shape[0]
+    if n >= max_len:
+        return x[:max_len]
+    if padding_type == "repeat":
+        return np.tile(x, int(max_len / n) + 1)[:max_len]
+    out = np.zeros(max_len, dtype=x.dtype)
+    out[:n] = x
+    return out
+
+
+class PackDataset(Dataset):
+    """recipe: 'augall_3' | 'aug_2' | 'scl_normal' | 'augall_5' — the view composition of the four reference plugins."""
+
+    def __init__(self, recipe, args, list_IDs, labels, base_dir, algo=5, vocoders=(), augmentation_methods=(), num_additional_real=2,
+                 num_additional_spoof=2, trim_length=64000, wav_samp_rate=16000, noise_path=None, rir_path=None, aug_dir=None,
+                 online_aug=False, repeat_pad=True, is_train=True):
+        self.recipe, self.args = recipe, args
+        args.noise_path, args.rir_path, args.aug_dir, args.online_aug = noise_path, rir_path, aug_dir, online_aug
+        self.list_IDs = list_IDs
+        self.bonafide_dir = os.path.join(base_dir, "bonafide")
+        self.vocoded_dir = os.path.join(base_dir, "vocoded")
+        self.trim_length, self.sample_rate, self.repeat_pad = trim_length, wav_samp_rate, repeat_pad
+        self.vocoders = list(vocoders)
+        self.num_additional_real, self.num_additional_spoof = num_additional_real, num_additional_spoof
+        self.methods = list(augmentation_methods) if len(augmentation_methods) >= 1 else ["RawBoost12"]
+        if recipe in ("scl_normal", "augall_5"):
+            self.spoof_dir = os.path.join(base_dir, "spoof_train" if getattr(args, "is_train", is_train) else "spoof_dev")
+            self.spoof_list = [f for f in sorted(os.listdir(self.spoof_dir)) if f.endswith(".wav") or f.endswith(".flac")] \
+                if os.path.isdir(self.spoof_dir) else []
+        print("vocoders:", self.vocoders)
+
+    def __len__(self):
+        return len(self.list_IDs)
+
+    def _aug(self, name, x, path):
+        return AUGMENTERS[name](x, self.args, self.sample_rate, audio_path=path)
+
+    def _load(self, path):
+        return load_audio(path, self.sample_rate)
+
+    def __getitem__(self, idx):
+        uid = self.list_IDs[idx]
+        real_path = os.path.join(self.bonafide_dir, uid)
+        real = self._load(real_path)
+        m, r = self.methods, self.recipe
+        voc, aug_voc = [], []
+        if r in ("augall_3", "aug_2", "augall_5"):
+            for vf in (os.path.join(self.vocoded_dir, v + "_" + uid) for v in self.vocoders):
+                va = self._load(vf)
+                voc.append(va)
+                name = m[random.choice(range(len(m)))] if r == "aug_2" else m[0]
+                aug_voc.append(self._aug(name, va, vf))
+        aug_real = [self._aug(name, real, real_path) for name in m]
+        idxs = list(range(len(self.list_IDs)))
+        idxs.remove(idx)
+        add_idx = np.random.choice(idxs, self.num_additional_real, replace=False)
+        add_paths = [os.path.join(self.bonafide_dir, self.list_IDs[i]) for i in add_idx]
+        add_real = [self._load(p) for p in add_paths]
+        aug_add, add_spoof, aug_spoof = [], [], []
+        if r in ("aug_2", "scl_normal"):
+            for a, p in zip(add_real, add_paths):
+                aug_add.append(self._aug(m[random.choice(range(len(m)))], a, p))
+        if r in ("scl_normal", "augall_5"):
+            sp_names = np.random.choice(self.spoof_list, self.num_additional_spoof, replace=False)
+            sp_paths = [os.path.join(self.spoof_dir, s) for s in sp_names]
+            add_spoof = [self._load(p) for p in sp_paths]
+            if r == "scl_normal":
+                for a, p in zip(add_spoof, sp_paths):
+                    aug_spoof.append(self._aug(m[random.choice(range(len(m)))], a, p))
+        if r == "augall_3":
+            views, n_pos = [real] + aug_real + add_real + voc + aug_voc, 1 + len(aug_real) + len(add_real)
+        elif r == "aug_2":
+            views, n_pos = [real] + aug_real + add_real + aug_add + voc + aug_voc, 1 + len(aug_real) + len(add_real) + len(aug_add)
+        elif r == "scl_normal":
+            views, n_pos = [real] + aug_real + add_real + aug_add + add_spoof + aug_spoof, 1 + len(aug_real) + len(add_real) + len(aug_add)
+        else:
+            views, n_pos = [real] + aug_real + add_real + voc + aug_voc + add_spoof, 1 + len(aug_real) + len(add_real)
+        dev_views = [_to_dev(v, self.args).reshape(-1) for v in views]
+        pack = augment.multiview_crop(dev_views, self.trim_length, self.repeat_pad, random_trim=True)   # [V, L]
+        label = torch.tensor([1.0] * n_pos + [0.0] * (len(views) - n_pos))
+        return uid, pack.t(), label
+
+
+class EvalDataset(Dataset):
+    def __init__(self, list_IDs, base_dir, padding_type="zero", subdir="eval"):
+        self.list_IDs = list_IDs
+        self.base_dir = os.path.join(base_dir, subdir) if subdir else base_dir
+        self.cut = 64600
+        self.padding_type = padding_type
+
+    def __len__(self):
+        return len(self.list_IDs)
+
+    def __getitem__(self, index):
+        utt_id = self.list_IDs[index]
+        x = load_audio(os.path.join(self.base_dir, utt_id), 16000)
+        return torch.from_numpy(np.ascontiguousarray(pad_eval(x, self.padding_type, self.cut), dtype=np.float32)), utt_id

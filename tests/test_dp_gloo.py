@@ -1,0 +1,63 @@
+"""Data-parallel pieces on CPU with the gloo backend, world_size 2: bucketed gradient all-reduce launched
+in backward order (GradSync), mean-gradient semantics, rank-strided pack sharding."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.parallel import GradSync, shard_indices
+    n = 1000
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    sync = GradSync(g, bucket_elems=300)
+    assert sync.bounds[0] == (700, 1000) and sync.bounds[-1] == (0, 100)
+    sync.begin()
+    sync.ready_above(800)          # nothing complete yet (bucket 0 starts at 700)
+    assert sync.launched == 0
+    sync.ready_above(650)          # head + last layers done -> bucket [700, 1000) goes out
+    assert sync.launched == 1
+    sync.ready_above(100)
+    assert sync.launched == 3
+    scale = sync.finish()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.allclose(g, expect) and abs(scale - 1.0 / world) < 1e-12
+    # second step reuses the object
+    g.fill_(float(rank))
+    sync.begin(); s2 = sync.finish()
+    ok = ok and torch.allclose(g * s2, torch.full((n,), sum(range(world)) / world))
+    sh = shard_indices(11, rank, world, epoch_seed=5)
+    q.put((rank, ok, sh))
+    dist.destroy_process_group()
+
+
+def test_gradsync_and_sharding_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    shards = {r: s for r, _, s in res}
+    assert len(shards[0]) == len(shards[1]) == 5 and not (set(shards[0]) & set(shards[1]))
+
+
+def test_single_process_is_a_noop():
+    from scl_amd.parallel import GradSync
+    g = torch.ones(10)
+    s = GradSync(g)
+    s.begin(); s.ready_above(0)
+    assert s.finish() == 1.0 and torch.equal(g, torch.ones(10))
