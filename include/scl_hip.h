@@ -73,6 +73,7 @@ typedef struct SclOperand {
 #define SCL_GEMM_HAS_BIAS 0x00000020
 #define SCL_GEMM_HAS_C2   0x00000040  /* also store the pre-activation value */
 #define SCL_GEMM_DROPOUT  0x00000080  /* multiply by keep-mask(seed,row,col)/(1-p) after act / grad-mul */
+#define SCL_GEMM_NO_DMA   0x00100000  /* force the register-staged kernel (testing / A-B comparison) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
 #define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */
 #define SCL_GEMM_RACT_SHIFT  16

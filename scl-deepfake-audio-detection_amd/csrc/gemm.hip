@@ -206,6 +206,75 @@ __device__ __noinline__ void epi_scalar(EpiArgs d, float t, long long o, int col
     else reinterpret_cast<bf16_t*>(d.C)[o] = f2bf(t);
 }
 
+__device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[4][4], int m0, int n0, int z1, int z2, int ksplit,
+                                              int lane, int wr, int wc) {
+    // ---- epilogue: lane holds C[row = m0 + wr*64 + mt*16 + (lane&15)][col = n0 + wc*64 + nt*16 + 4*(lane>>4) + 0..3]
+    const int flags = d.flags;
+    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
+    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
+    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
+    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
+    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+    const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
+    const float* bias = has_bias ? d.bias + z2 * d.bias_bs2 : nullptr;
+    const int g = lane >> 4, lc = lane & 15;
+    const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = m0 + wr * 64 + mt * 16 + lc;
+        const bool rok = row < d.M;
+        const unsigned q = udiv_magic((unsigned)(rok ? row : 0), d.c_magic, d.c_shift);
+        const long long roff = cbase + (long long)q * d.c_rbstride + (long long)((unsigned)(rok ? row : 0) - q * d.c_rpb) * d.ldc;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = n0 + wc * 64 + nt * 16 + 4 * g;
+            const long long off = roff + col;
+            float v[4] = {d.alpha * acc[mt][nt][0], d.alpha * acc[mt][nt][1], d.alpha * acc[mt][nt][2], d.alpha * acc[mt][nt][3]};
+            if (rok && d.vec_ok && col + 4 <= d.N) {
+                if (has_bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (has_c2) {
+                    if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+                if (act) {
+                    v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]);
+                }
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+                if (rmode) {
+                    if (r_f32) {
+                        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.R) + off);
+                        r0 = t.x; r1 = t.y; r2 = t.z; r3 = t.w;
+                    } else {
+                        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(d.R) + off);
+                        r0 = __uint_as_float(t.x << 16); r1 = __uint_as_float(t.x & 0xFFFF0000u);
+                        r2 = __uint_as_float(t.y << 16); r3 = __uint_as_float(t.y & 0xFFFF0000u);
+                    }
+                }
+                if (rmode == 2) {
+                    v[0] *= act_grad_f(ract, r0); v[1] *= act_grad_f(ract, r1); v[2] *= act_grad_f(ract, r2); v[3] *= act_grad_f(ract, r3);
+                }
+                if (drop) {
+                    v[0] *= dropout_scale(d.drop_seed, (uint64_t)(off + 0), d.drop_p); v[1] *= dropout_scale(d.drop_seed, (uint64_t)(off + 1), d.drop_p);
+                    v[2] *= dropout_scale(d.drop_seed, (uint64_t)(off + 2), d.drop_p); v[3] *= dropout_scale(d.drop_seed, (uint64_t)(off + 3), d.drop_p);
+                }
+                if (rmode == 1) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                if (c_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            } else if (rok) {
+                // edge tile / unaligned C: element-wise path
+                epi_scalar(ea, v[0], off + 0, col + 0, bias);
+                epi_scalar(ea, v[1], off + 1, col + 1, bias);
+                epi_scalar(ea, v[2], off + 2, col + 2, bias);
+                epi_scalar(ea, v[3], off + 3, col + 3, bias);
+            }
+        }
+    }
+}
+
 template <bool AT, bool BT>
 __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -305,71 +374,147 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds C[row = m0 + wr*64 + mt*16 + (lane&15)][col = n0 + wc*64 + nt*16 + 4*(lane>>4) + 0..3]
-    const int flags = d.flags;
-    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
-    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
-    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
-    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
-    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
-    const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
-    const float* bias = has_bias ? d.bias + z2 * d.bias_bs2 : nullptr;
-    const int g = lane >> 4, lc = lane & 15;
-    const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
+    gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
+}
 
+
+// ---- LDS-DMA variant ---------------------------------------------------------------------------
+// Same tile, same LDS images, same fragment reads and epilogue; the staging goes global -> LDS
+// directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, LDS address = uniform base +
+// lane*16) so no staging VGPRs and no ds_write pass exist.  Because the DMA writes lane-linearly, the
+// XOR swizzles are applied to the per-lane SOURCE address: lane l of piece p fetches the logical
+// chunk that belongs at physical position (p, l).  Out-of-range rows / reduction indices fetch at
+// offset 0xFFFFFFFF (hardware range check -> zeros land in LDS).  Used whenever no 16-byte vector can
+// be partially valid (K % 8 == 0 for K-contiguous operands, M / N % 8 == 0 for transposed ones).
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct DmaK {   // K-contiguous operand: piece p = rows 8p..8p+7; this wave owns pieces wave*4 + i
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned rowoff[4];
+    int kc[4];            // logical k-chunk (x8 elements) this lane fetches for piece i
+    int kcur, kend;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int row0, int rowlimit, int kbegin, int kend_, int lane, int wave) {
+        rsrc = make_rsrc(base);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = m0 + wr * 64 + mt * 16 + lc;
-        const bool rok = row < d.M;
-        const unsigned q = udiv_magic((unsigned)(rok ? row : 0), d.c_magic, d.c_shift);
-        const long long roff = cbase + (long long)q * d.c_rbstride + (long long)((unsigned)(rok ? row : 0) - q * d.c_rpb) * d.ldc;
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            const int row = 8 * p + (lane >> 3);
+            const int r = row0 + row;
+            rowoff[i] = r < rowlimit ? row_off(o, (unsigned)r) : OOB;
+            kc[i] = (lane & 7) ^ ((row >> 1) & 7);
+        }
+        kcur = kbegin; kend = kend_;
+    }
+    __device__ __forceinline__ void issue(const OpK& o, char* tile, int wave) const {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int col = n0 + wc * 64 + nt * 16 + 4 * g;
-            const long long off = roff + col;
-            float v[4] = {d.alpha * acc[mt][nt][0], d.alpha * acc[mt][nt][1], d.alpha * acc[mt][nt][2], d.alpha * acc[mt][nt][3]};
-            if (rok && d.vec_ok && col + 4 <= d.N) {
-                if (has_bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bias + col);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (has_c2) {
-                    if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                }
-                if (act) {
-                    v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]);
-                }
-                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-                if (rmode) {
-                    if (r_f32) {
-                        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.R) + off);
-                        r0 = t.x; r1 = t.y; r2 = t.z; r3 = t.w;
-                    } else {
-                        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(d.R) + off);
-                        r0 = __uint_as_float(t.x << 16); r1 = __uint_as_float(t.x & 0xFFFF0000u);
-                        r2 = __uint_as_float(t.y << 16); r3 = __uint_as_float(t.y & 0xFFFF0000u);
-                    }
-                }
-                if (rmode == 2) {
-                    v[0] *= act_grad_f(ract, r0); v[1] *= act_grad_f(ract, r1); v[2] *= act_grad_f(ract, r2); v[3] *= act_grad_f(ract, r3);
-                }
-                if (drop) {
-                    v[0] *= dropout_scale(d.drop_seed, (uint64_t)(off + 0), d.drop_p); v[1] *= dropout_scale(d.drop_seed, (uint64_t)(off + 1), d.drop_p);
-                    v[2] *= dropout_scale(d.drop_seed, (uint64_t)(off + 2), d.drop_p); v[3] *= dropout_scale(d.drop_seed, (uint64_t)(off + 3), d.drop_p);
-                }
-                if (rmode == 1) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                if (c_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + off) = make_float4(v[0], v[1], v[2], v[3]);
-                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            } else if (rok) {
-                // edge tile / unaligned C: element-wise path
-                epi_scalar(ea, v[0], off + 0, col + 0, bias);
-                epi_scalar(ea, v[1], off + 1, col + 1, bias);
-                epi_scalar(ea, v[2], off + 2, col + 2, bias);
-                epi_scalar(ea, v[3], off + 3, col + 3, bias);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int k = kcur + 8 * kc[i];
+            const unsigned off = (k < kend && rowoff[i] != OOB) ? rowoff[i] + col_off(o, (unsigned)k) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(tile + (wave * 4 + i) * 1024), 16, off, 0, 0, 0);
         }
     }
+    __device__ __forceinline__ void advance() { kcur += BK; }
+};
+
+struct DmaT {   // transposed operand: piece p = k-rows 4p..4p+3 (256 B each)
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned coloff[4];
+    int krow[4];
+    int kcur, kend;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int col0, int collimit, int kbegin, int kend_, int lane, int wave) {
+        rsrc = make_rsrc(base);
+        const int s16 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            const int kr = 4 * p + (lane >> 4);
+            const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
+            const int col = col0 + 8 * ((((s16 >> 1) ^ sw) << 1) | (s16 & 1));
+            krow[i] = kr;
+            coloff[i] = col < collimit ? col_off(o, (unsigned)col) : OOB;
+        }
+        kcur = kbegin; kend = kend_;
+    }
+    __device__ __forceinline__ void issue(const OpK& o, char* tile, int wave) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = kcur + krow[i];
+            const unsigned off = (rr < kend && coloff[i] != OOB) ? row_off(o, (unsigned)rr) + coloff[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(tile + (wave * 4 + i) * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance() { kcur += BK; }
+};
+
+template <bool T> struct DmaSel { typedef DmaK type; };
+template <> struct DmaSel<true> { typedef DmaT type; };
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntiles = gridDim.x;
+    int tile;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int z = blockIdx.z;
+    const int ksplit = z % d.splitk; z /= d.splitk;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + BK - 1) / BK;
+    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int kbegin = ksplit * nk_per * BK;
+    int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    typename DmaSel<AT>::type sa;
+    typename DmaSel<BT>::type sb;
+    sa.init(d.A, Ab, m0, d.M, kbegin, kend, lane, wave);
+    sb.init(d.B, Bb, n0, d.N, kbegin, kend, lane, wave);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) { sa.issue(d.A, smem, wave); sb.issue(d.B, smem + TILE_BYTES, wave); }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+        __syncthreads();                                    // everyone's have; everyone is done reading the other buffer
+        if (kt + 1 < nk) {
+            sa.advance(); sb.advance();
+            char* nb = smem + (cur ^ 1) * (2 * TILE_BYTES);
+            sa.issue(d.A, nb, wave); sb.issue(d.B, nb + TILE_BYTES, wave);
+        }
+        const char* tA = smem + cur * (2 * TILE_BYTES);
+        const char* tB = tA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = AT ? frag_t(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
+                fb[i] = BT ? frag_t(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
 }
 
 __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
@@ -466,10 +611,21 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     {
         SclProfScope prof(SCL_KID_GEMM, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
-        if (!at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<false, false>), grid, block, lds, s, k);
-        else if (!at && bt) hipLaunchKernelGGL((scl_gemm_kernel<false, true>), grid, block, lds, s, k);
-        else if (at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<true, false>), grid, block, lds, s, k);
-        else hipLaunchKernelGGL((scl_gemm_kernel<true, true>), grid, block, lds, s, k);
+        // LDS-DMA staging cannot mask a partially valid 16-byte vector: use it only when none can occur
+        const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
+        const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
+        const bool dma = a_whole && b_whole && !(d.flags & SCL_GEMM_NO_DMA);
+        if (dma) {
+            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);
+            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, true>), grid, block, lds, s, k);
+            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<true, false>), grid, block, lds, s, k);
+            else hipLaunchKernelGGL((scl_gemm_dma_kernel<true, true>), grid, block, lds, s, k);
+        } else {
+            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<false, false>), grid, block, lds, s, k);
+            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_kernel<false, true>), grid, block, lds, s, k);
+            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<true, false>), grid, block, lds, s, k);
+            else hipLaunchKernelGGL((scl_gemm_kernel<true, true>), grid, block, lds, s, k);
+        }
     }
     return scl_check_launch("scl_gemm_bf16");
 }

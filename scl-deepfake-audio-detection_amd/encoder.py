@@ -198,6 +198,7 @@ class Encoder:
             return
         n = out.numel()
         if d["slab"] is None or d["slab"].numel() < sk * n:
+            d.setdefault("slabs_keep", []).append(d["slab"])   # recorded launch plans may still point into the old slab
             d["slab"] = torch.empty(sk * n, dtype=torch.float32, device=self.dev)
         ops.gemm(A, B_, d["slab"], Mo, No, Kr, a_t=True, b_t=True, splitk=sk, c_split_stride=n, **kw)
         ops.reduce_slabs(d["slab"], out, n, sk, n)
@@ -212,11 +213,12 @@ class Encoder:
         ops.colreduce(d["ln_pb"], self.P.g(self.n(bname)), nparts, C)
 
     # ---- forward ---------------------------------------------------------------------------------
-    def forward(self, x, training=True):
+    def forward(self, x, training=True, refresh=True):
         """x [B, L] fp32 contiguous on the GPU -> (enc_out bf16 [B*T, E], ctx)."""
         cfg, P = self.cfg, self.P
         B, L = x.shape
-        self.refresh_weights()
+        if refresh:
+            self.refresh_weights()
         d = self.bufs(B, L)
         C, E, H, Fd, K, G = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k, cfg.pos_groups
         D, Cg = E // H, E // G
@@ -335,7 +337,7 @@ class Encoder:
             self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d xin
             if self.on_grads_ready is not None:
-                self.on_grads_ready(P.off(self.n(pn + "self_attn_layer_norm.weight")))
+                ops.host_callback(self.on_grads_ready, P.off(self.n(pn + "self_attn_layer_norm.weight")))
         # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
         pb = K // 2 - 1
         ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)

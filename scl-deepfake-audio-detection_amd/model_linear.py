@@ -72,7 +72,9 @@ class _ModelFn(torch.autograd.Function):
     def forward(ctx, model, x, anchor):
         out, feats, emb, saved = model._run_forward(x)
         ctx.model, ctx.saved = model, saved
-        return out, feats, emb
+        # the outputs live in static per-(B, L) buffers (launch plans point at them): hand out copies, so results
+        # of successive forward calls do not alias (3 small device copies)
+        return out.clone(), feats.clone(), emb.clone()
 
     @staticmethod
     def backward(ctx, d_out, d_feats, d_emb):
@@ -109,6 +111,7 @@ class Model(nn.Module):
         self.encoder = Encoder(self.cfg, self.P)
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._hbufs = {}
+        self._states = {}
         self._step_seed = 0
         self.out_dim = self.cfg.embed
         self.grad_sync = None   # scl_amd.parallel.GradSync when data-parallel (set by FusedAdamW)
@@ -145,51 +148,100 @@ class Model(nn.Module):
                                     cs=f32(ops.colsum_nparts(M) * max(HEAD_DIM, 8)), dW=f32(HEAD_DIM * max(HEAD_DIM, self.cfg.embed)))
         return self._hbufs[key]
 
+    def _state(self, B, L):
+        """Static per-(B, L) buffers at the autograd boundary, so recorded launch plans stay valid."""
+        key = (B, L)
+        if key not in self._states:
+            T = self.cfg.conv_lens(L)[-1]
+            f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+            self._states[key] = dict(T=T, x=f32(B, L), feats=f32(B, T, HEAD_DIM), emb=f32(B, HEAD_DIM), logp=f32(B, N_CLASS),
+                                     d_logp=f32(B, N_CLASS), d_feats=f32(B, T, HEAD_DIM), d_emb=f32(B, HEAD_DIM), plans={})
+        return self._states[key]
+
     def _run_forward(self, x):
-        P, E = self.P, self.cfg.embed
         B, L = x.shape
-        training = self.training
-        if self.flag_fix_ssl:
-            enc_out, ectx = self.encoder.forward(x, training=False)
-        else:
-            # reference quirk: the SSL sub-model follows `is_train`, not model.eval()
-            enc_out, ectx = self.encoder.forward(x, training=self.is_train and training)
-        T = ectx["d"]["T"]
-        M = B * T
-        hb = self._head_bufs(B, T)
-        feats = torch.empty(B, T, HEAD_DIM, dtype=torch.float32, device=self.device)
-        emb = torch.empty(B, HEAD_DIM, dtype=torch.float32, device=self.device)
-        logp = torch.empty(B, N_CLASS, dtype=torch.float32, device=self.device)
-        W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
-        # feats = LL(x) (pre-ReLU tensor is what SupCon sees, linear_nll:127-129), r0 = relu(feats)
-        ops.gemm(Op(enc_out, E), W("LL.weight", E), hb["r0"], M, HEAD_DIM, E, bias=P.f32("LL.bias"), act=ACT_RELU, c2=feats)
+        training = bool(self.training)
+        ssl_train = False if self.flag_fix_ssl else bool(self.is_train and training)   # SURVEY.md §3.2 quirk
+        st = self._state(B, L)
+        st["x"].copy_(x)
         drop = DROP_P if training else 0.0
         self._step_seed = (self._step_seed * 1664525 + 1013904223) & 0x7FFFFFFF
         seeds = [(self._step_seed + 7919 * j) & 0x7FFFFFFF for j in range(3)]
-        prev = hb["r0"]
+        self.encoder.refresh_weights()
+        use_plan = self.cfg.encoder_layerdrop == 0 or not ssl_train
+        pk = ("fwd", training, ssl_train)
+        plan = st["plans"].get(pk) if use_plan else None
+        if plan is not None:
+            for dsc, sd in zip(plan["drop_descs"], seeds):
+                dsc.drop_seed = sd
+            ops.replay(plan["calls"])
+            saved = dict(plan["saved"], seeds=seeds)
+            return st["logp"], st["feats"], st["emb"], saved
+        if use_plan:
+            ops.start_recording()
+        saved, drop_descs = self._forward_kernels(st, B, L, ssl_train, drop, seeds)
+        if use_plan:
+            st["plans"][pk] = dict(calls=ops.stop_recording(), drop_descs=drop_descs, saved=saved)
+        return st["logp"], st["feats"], st["emb"], dict(saved, seeds=seeds)
+
+    def _forward_kernels(self, st, B, L, ssl_train, drop, seeds):
+        P, E = self.P, self.cfg.embed
+        enc_out, ectx = self.encoder.forward(st["x"], training=ssl_train, refresh=False)
+        T = ectx["d"]["T"]
+        M = B * T
+        hb = self._head_bufs(B, T)
+        feats, emb, logp = st["feats"], st["emb"], st["logp"]
+        W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
+        # feats = LL(x) (pre-ReLU tensor is what SupCon sees, linear_nll:127-129), r0 = relu(feats)
+        ops.gemm(Op(enc_out, E), W("LL.weight", E), hb["r0"], M, HEAD_DIM, E, bias=P.f32("LL.bias"), act=ACT_RELU, c2=feats)
+        prev, drop_descs = hb["r0"], []
         for j, idx in enumerate((0, 3, 6)):
-            ops.gemm(Op(prev, HEAD_DIM), W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), hb["h"][j], M, HEAD_DIM, HEAD_DIM,
-                     bias=P.f32("backend.m_frame_level.%d.bias" % idx), act=ACT_LEAKY, c2=hb["pre"][j], drop_p=drop, drop_seed=seeds[j])
+            dsc = ops.gemm(Op(prev, HEAD_DIM), W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), hb["h"][j], M, HEAD_DIM, HEAD_DIM,
+                           bias=P.f32("backend.m_frame_level.%d.bias" % idx), act=ACT_LEAKY, c2=hb["pre"][j], drop_p=drop,
+                           drop_seed=seeds[j])
+            drop_descs.append(dsc)
             prev = hb["h"][j]
         ops.meanpool_fwd(prev, emb, B, T, HEAD_DIM)
         ops.utt_head_fwd(emb, P.f32("backend.m_utt_level.weight"), P.f32("backend.m_utt_level.bias"), logp, B, HEAD_DIM, N_CLASS)
-        saved = dict(ectx=ectx, hb=hb, B=B, T=T, drop=drop, seeds=seeds, feats=feats, emb=emb, logp=logp, enc_out=enc_out)
-        return logp, feats, emb, saved
+        saved = dict(ectx=ectx, hb=hb, B=B, L=L, T=T, drop=drop, feats=feats, emb=emb, logp=logp, enc_out=enc_out, st=st)
+        return saved, drop_descs
 
     def _run_backward(self, sv, d_logp, d_feats, d_emb):
-        P, E = self.P, self.cfg.embed
+        P = self.P
         P.rebind_grads()
+        st, seeds = sv["st"], sv["seeds"]
+        for name, g in (("d_logp", d_logp), ("d_feats", d_feats), ("d_emb", d_emb)):
+            if g is None:
+                st[name].zero_()
+            else:
+                st[name].copy_(g)
+        if self.grad_sync is not None:
+            self.encoder.on_grads_ready = self.grad_sync.ready_above
+        use_plan = not sv["ectx"]["skipped"] and self.cfg.encoder_layerdrop == 0
+        pk = ("bwd", sv["drop"] > 0, self.grad_sync is not None)
+        plan = st["plans"].get(pk) if use_plan else None
+        if plan is not None:
+            plan["drop_descs"][0].drop_seed = seeds[1]
+            plan["drop_descs"][1].drop_seed = seeds[0]
+            plan["meanpool_entry"][1][8] = seeds[2]
+            ops.replay(plan["calls"])
+            return
+        if use_plan:
+            ops.start_recording()
+        extra = self._backward_kernels(sv, st, seeds)
+        if use_plan:
+            st["plans"][pk] = dict(calls=ops.stop_recording(), **extra)
+
+    def _backward_kernels(self, sv, st, seeds):
+        P, E = self.P, self.cfg.embed
         B, T, hb = sv["B"], sv["T"], sv["hb"]
         M = B * T
-        dev = self.device
-        if d_logp is None:
-            d_logp = torch.zeros(B, N_CLASS, device=dev)
         W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
-        ops.utt_head_bwd(d_logp.contiguous(), sv["logp"], sv["emb"], P.f32("backend.m_utt_level.weight"),
-                         None if d_emb is None else d_emb.contiguous(), hb["demb"], P.g("backend.m_utt_level.weight"),
-                         P.g("backend.m_utt_level.bias"), hb["ws"], B, HEAD_DIM, N_CLASS)
-        ops.meanpool_bwd(hb["demb"], hb["pre"][2], hb["dpre"][2], B, T, HEAD_DIM, ACT_LEAKY, sv["drop"], sv["seeds"][2])
+        ops.utt_head_bwd(st["d_logp"], sv["logp"], sv["emb"], P.f32("backend.m_utt_level.weight"), st["d_emb"], hb["demb"],
+                         P.g("backend.m_utt_level.weight"), P.g("backend.m_utt_level.bias"), hb["ws"], B, HEAD_DIM, N_CLASS)
+        mp_entry = ops.meanpool_bwd(hb["demb"], hb["pre"][2], hb["dpre"][2], B, T, HEAD_DIM, ACT_LEAKY, sv["drop"], seeds[2])
         ncs = ops.colsum_nparts(M)
+        drop_descs = []
         for j, idx in reversed(list(enumerate((0, 3, 6)))):
             dpre = hb["dpre"][j]
             inp = hb["h"][j - 1] if j > 0 else hb["r0"]
@@ -199,22 +251,21 @@ class Model(nn.Module):
                                 HEAD_DIM, HEAD_DIM, M)
             wj = W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM)
             if j > 0:
-                ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dpre"][j - 1], M, HEAD_DIM, HEAD_DIM, b_t=True, R=hb["pre"][j - 1], rmode=2,
-                         ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=sv["seeds"][j - 1])
+                drop_descs.append(ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dpre"][j - 1], M, HEAD_DIM, HEAD_DIM, b_t=True, R=hb["pre"][j - 1],
+                                           rmode=2, ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=seeds[j - 1]))
             else:
                 ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dfe"], M, HEAD_DIM, HEAD_DIM, b_t=True, R=sv["feats"], rmode=2, ract=ACT_RELU)
         # total gradient at feats = ReLU path + SupCon path
-        ops.add_f32(hb["dfe"], None if d_feats is None else d_feats.contiguous(), hb["dfe"], hb["dfe_bf"], M * HEAD_DIM)
+        ops.add_f32(hb["dfe"], st["d_feats"], hb["dfe"], hb["dfe_bf"], M * HEAD_DIM)
         ops.colsum(hb["dfe"], hb["cs"], M, HEAD_DIM)
         ops.colreduce(hb["cs"], P.g("LL.bias"), ncs, HEAD_DIM)
         self.encoder._wgrad(sv["ectx"]["d"], Op(hb["dfe_bf"], HEAD_DIM), Op(sv["enc_out"], E), P.g("LL.weight"), HEAD_DIM, E, M)
-        if self.flag_fix_ssl:
-            return
-        ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)
-        if self.grad_sync is not None:      # head gradients (the END of the flat buffer) are final: start their all-reduce
-            self.grad_sync.ready_above(P.off("LL.weight"))
-            self.encoder.on_grads_ready = self.grad_sync.ready_above
-        self.encoder.backward(sv["ectx"], hb["denc"])
+        if not self.flag_fix_ssl:
+            ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)
+            if self.grad_sync is not None:      # head gradients (the END of the flat buffer) are final: start their all-reduce
+                ops.host_callback(self.grad_sync.ready_above, P.off("LL.weight"))
+            self.encoder.backward(sv["ectx"], hb["denc"])
+        return dict(drop_descs=drop_descs, meanpool_entry=mp_entry)
 
     def _forward(self, x):
         if x.dim() == 3:
@@ -224,6 +275,7 @@ class Model(nn.Module):
             out, feats, emb = _ModelFn.apply(self, x, self._anchor)
         else:
             out, feats, emb, _ = self._run_forward(x)
+            out, feats, emb = out.clone(), feats.clone(), emb.clone()
         if self.is_train:
             return out, feats, emb
         return out

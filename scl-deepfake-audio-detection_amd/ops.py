@@ -12,6 +12,54 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- launch plans ---------------------------------------------------------------------------------
+# Every buffer of a train step is static per (batch, length), so the ~1100 C-ABI calls of a step are
+# identical from step to step.  The first step RECORDS them as (function, argument list) pairs; later
+# steps REPLAY the list (a ctypes call with pre-built arguments costs ~2 us instead of ~40 us of Python
+# descriptor building), which keeps the host ahead of the GPU.
+_REC = None
+
+
+def start_recording():
+    global _REC
+    _REC = []
+    return _REC
+
+
+def stop_recording():
+    global _REC
+    plan, _REC = _REC, None
+    return plan
+
+
+def replay(plan):
+    for fn, args, name, _keep in plan:
+        rc = fn(*args)
+        if rc != 0:
+            L.check(rc, name)
+
+
+def host_callback(fn, *args):
+    """Run a Python callback now and, when recording, at the same position of every replay (DP bucket launches)."""
+    fn(*args)
+    if _REC is not None:
+        def _cb(*a, _fn=fn):
+            _fn(*a)
+            return 0
+        _REC.append((_cb, list(args), getattr(fn, "__name__", "callback"), None))
+
+
+def _call(name, *args, keep=None):
+    fn = getattr(L.load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        L.check(rc, name)
+    if _REC is not None:
+        _REC.append((fn, list(args), name, keep))   # `keep` holds objects the arguments point into (GEMM descriptors)
+        return _REC[-1]
+    return None
+
+
 def _ptr(t, offset=0):
     return t.data_ptr() + offset * t.element_size()
 
@@ -34,9 +82,8 @@ class Op:
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0):
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
-    lib = L.load()
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
     flags = 0
@@ -65,25 +112,28 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
         d.bias = _ptr(bias, bias_offset)
     if drop_p > 0.0:
         flags |= L.GEMM_DROPOUT
+    if no_dma:
+        flags |= L.GEMM_NO_DMA
     flags |= (act << L.ACT_SHIFT) | (rmode << L.RMODE_SHIFT) | (ract << L.RACT_SHIFT)
     d.c_bs1, d.c_bs2, d.c_rbstride, d.c_split_stride, d.bias_bs2 = c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2
     d.c_rpb, d.ldc = c_rpb, (N if ldc is None else ldc)
     d.M, d.N, d.K, d.nb1, d.nb2, d.splitk = M, N, K, nb1, nb2, splitk
     d.flags, d.alpha, d.drop_p, d.drop_seed = flags, alpha, drop_p, drop_seed
-    L.check(lib.scl_gemm_bf16(ctypes.byref(d), _stream()), "scl_gemm_bf16")
+    _call("scl_gemm_bf16", ctypes.byref(d), _stream(), keep=d)
+    return d
 
 
 def reduce_slabs(slabs, out, n, nslabs, stride):
-    L.check(L.load().scl_reduce_slabs_f32(_ptr(slabs), _ptr(out), n, nslabs, stride, _stream()), "scl_reduce_slabs_f32")
+    _call("scl_reduce_slabs_f32", _ptr(slabs), _ptr(out), n, nslabs, stride, _stream())
 
 
 def prof_enable(kid, on):
-    L.check(L.load().scl_prof_enable(kid, 1 if on else 0), "scl_prof_enable")
+    _call("scl_prof_enable", kid, 1 if on else 0)
 
 
 def prof_read(kid):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
-    L.check(L.load().scl_prof_read(kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "scl_prof_read")
+    _call("scl_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     return n.value, ms.value, fl.value
 
 
@@ -99,8 +149,8 @@ def _isf32(t):
 
 
 def layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, C, act=0, ldx=None, ldy=None, eps=1e-5):
-    L.check(L.load().scl_layernorm_fwd(_p(x), _isf32(x), _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), _p(mean), _p(rstd),
-                                       M, C, ldx or C, ldy or C, eps, act, _stream()), "scl_layernorm_fwd")
+    _call("scl_layernorm_fwd", _p(x), _isf32(x), _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), _p(mean), _p(rstd),
+                                       M, C, ldx or C, ldy or C, eps, act, _stream())
 
 
 def layernorm_bwd_nparts(M):
@@ -108,14 +158,13 @@ def layernorm_bwd_nparts(M):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, dgamma_part, dbeta_part, M, C, act=0):
-    L.check(L.load().scl_layernorm_bwd(_p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
+    _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                        _p(dres), _p(dx_f32), _p(dx_bf16), _p(dgamma_part), _p(dbeta_part), M, C, C, C, C,
-                                       act, _stream()), "scl_layernorm_bwd")
+                                       act, _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):
-    L.check(L.load().scl_colreduce_f32(_p(part), _p(out), nparts, C, pstride or C, 1 if accumulate else 0, _stream()),
-            "scl_colreduce_f32")
+    _call("scl_colreduce_f32", _p(part), _p(out), nparts, C, pstride or C, 1 if accumulate else 0, _stream())
 
 
 def colsum_nparts(M):
@@ -123,70 +172,68 @@ def colsum_nparts(M):
 
 
 def colsum(x, part, M, N, ld=None):
-    L.check(L.load().scl_colsum(_p(x), _isf32(x), _p(part), M, N, ld or N, _stream()), "scl_colsum")
+    _call("scl_colsum", _p(x), _isf32(x), _p(part), M, N, ld or N, _stream())
 
 
 def cast_bf16(src, dst, n=None):
-    L.check(L.load().scl_cast_f32_bf16(_p(src), _p(dst), n or src.numel(), _stream()), "scl_cast_f32_bf16")
+    _call("scl_cast_f32_bf16", _p(src), _p(dst), n or src.numel(), _stream())
 
 
 def add_f32(a, b, out, out_bf16, n):
-    L.check(L.load().scl_add_f32(_p(a), _p(b), _p(out), _p(out_bf16), n, _stream()), "scl_add_f32")
+    _call("scl_add_f32", _p(a), _p(b), _p(out), _p(out_bf16), n, _stream())
 
 
 def pad_rows(src, dst, B, T, C, rows_out, pad_before, pre=None, ract=0):
-    L.check(L.load().scl_pad_rows_bf16(_p(src), _isf32(src), _p(dst), _p(pre), ract, B, T, C, rows_out, pad_before, _stream()),
-            "scl_pad_rows_bf16")
+    _call("scl_pad_rows_bf16", _p(src), _isf32(src), _p(dst), _p(pre), ract, B, T, C, rows_out, pad_before, _stream())
 
 
 def col2im(dcol, dz, B, Tin, Tout, C, k, s):
-    L.check(L.load().scl_col2im_bf16(_p(dcol), _p(dz), B, Tin, Tout, C, k, s, _stream()), "scl_col2im_bf16")
+    _call("scl_col2im_bf16", _p(dcol), _p(dz), B, Tin, Tout, C, k, s, _stream())
 
 
 def conv_weight_pack(w, wk, Co, Ci, k):
-    L.check(L.load().scl_conv_weight_pack(_p(w), _p(wk), Co, Ci, k, _stream()), "scl_conv_weight_pack")
+    _call("scl_conv_weight_pack", _p(w), _p(wk), Co, Ci, k, _stream())
 
 
 def conv_weight_unpack_grad(dwk, dw, Co, Ci, k):
-    L.check(L.load().scl_conv_weight_unpack_grad(_p(dwk), _p(dw), Co, Ci, k, _stream()), "scl_conv_weight_unpack_grad")
+    _call("scl_conv_weight_unpack_grad", _p(dwk), _p(dw), Co, Ci, k, _stream())
 
 
 def posconv_weight_pack(v, g, norm, wf, wd, E, Cg, K):
-    L.check(L.load().scl_posconv_weight_pack(_p(v), _p(g), _p(norm), _p(wf), _p(wd), E, Cg, K, _stream()), "scl_posconv_weight_pack")
+    _call("scl_posconv_weight_pack", _p(v), _p(g), _p(norm), _p(wf), _p(wd), E, Cg, K, _stream())
 
 
 def posconv_weight_bwd(dwf, v, g, norm, sdot_ws, dv, dg, E, Cg, K):
-    L.check(L.load().scl_posconv_weight_bwd(_p(dwf), _p(v), _p(g), _p(norm), _p(sdot_ws), _p(dv), _p(dg), E, Cg, K, _stream()),
-            "scl_posconv_weight_bwd")
+    _call("scl_posconv_weight_bwd", _p(dwf), _p(v), _p(g), _p(norm), _p(sdot_ws), _p(dv), _p(dg), E, Cg, K, _stream())
 
 
 def meanpool_fwd(h, emb, B, T, C):
-    L.check(L.load().scl_meanpool_fwd(_p(h), _p(emb), B, T, C, _stream()), "scl_meanpool_fwd")
+    _call("scl_meanpool_fwd", _p(h), _p(emb), B, T, C, _stream())
 
 
 def meanpool_bwd(demb, pre, dpre, B, T, C, ract, drop_p=0.0, seed=0):
-    L.check(L.load().scl_meanpool_bwd(_p(demb), _p(pre), _p(dpre), B, T, C, ract, drop_p, seed, _stream()), "scl_meanpool_bwd")
+    return _call("scl_meanpool_bwd", _p(demb), _p(pre), _p(dpre), B, T, C, ract, drop_p, seed, _stream())
 
 
 def utt_head_fwd(emb, W, bias, logp, B, C, NC):
-    L.check(L.load().scl_utt_head_fwd(_p(emb), _p(W), _p(bias), _p(logp), B, C, NC, _stream()), "scl_utt_head_fwd")
+    _call("scl_utt_head_fwd", _p(emb), _p(W), _p(bias), _p(logp), B, C, NC, _stream())
 
 
 def utt_head_bwd(dlogp, logp, emb, W, demb_in, demb, dW, db, ws, B, C, NC):
-    L.check(L.load().scl_utt_head_bwd(_p(dlogp), _p(logp), _p(emb), _p(W), _p(demb_in), _p(demb), _p(dW), _p(db), _p(ws),
-                                      B, C, NC, _stream()), "scl_utt_head_bwd")
+    _call("scl_utt_head_bwd", _p(dlogp), _p(logp), _p(emb), _p(W), _p(demb_in), _p(demb), _p(dW), _p(db), _p(ws),
+                                      B, C, NC, _stream())
 
 
 def softmax_fwd(S, P, R, T, ldS, Tp):
-    L.check(L.load().scl_softmax_fwd(_p(S), _p(P), R, T, ldS, Tp, _stream()), "scl_softmax_fwd")
+    _call("scl_softmax_fwd", _p(S), _p(P), R, T, ldS, Tp, _stream())
 
 
 def softmax_bwd(P, dP, dS, R, T, lddP, Tp):
-    L.check(L.load().scl_softmax_bwd(_p(P), _p(dP), _p(dS), R, T, lddP, Tp, _stream()), "scl_softmax_bwd")
+    _call("scl_softmax_bwd", _p(P), _p(dP), _p(dS), R, T, lddP, Tp, _stream())
 
 
 def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5):
-    L.check(L.load().scl_conv0_fwd(_p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), B, Lx, C, k, stride, eps, _stream()), "scl_conv0_fwd")
+    _call("scl_conv0_fwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), B, Lx, C, k, stride, eps, _stream())
 
 
 def conv0_bwd_nparts(B, Lx, k, stride):
@@ -194,8 +241,8 @@ def conv0_bwd_nparts(B, Lx, k, stride):
 
 
 def conv0_bwd(x, w, b, gamma, beta, dz, part_ws, dW, db, dgamma, dbeta, B, Lx, C, k, stride, eps=1e-5):
-    L.check(L.load().scl_conv0_bwd(_p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(dz), _p(part_ws), _p(dW), _p(db), _p(dgamma),
-                                   _p(dbeta), B, Lx, C, k, stride, eps, _stream()), "scl_conv0_bwd")
+    _call("scl_conv0_bwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(dz), _p(part_ws), _p(dW), _p(db), _p(dgamma),
+                                   _p(dbeta), B, Lx, C, k, stride, eps, _stream())
 
 
 def supcon_nchunks(K):
@@ -203,22 +250,22 @@ def supcon_nchunks(K):
 
 
 def supcon_fwd(F, labels, bz, K, ldF, Tprime, temperature, ws, G, loss_out, S_out=None):
-    L.check(L.load().scl_supcon_fwd(_p(F), _p(labels), bz, K, ldF, Tprime, temperature, _p(ws), _p(G), _p(loss_out), _p(S_out),
-                                    _stream()), "scl_supcon_fwd")
+    _call("scl_supcon_fwd", _p(F), _p(labels), bz, K, ldF, Tprime, temperature, _p(ws), _p(G), _p(loss_out), _p(S_out),
+                                    _stream())
 
 
 def supcon_bwd(F, G, upstream, coef, bz, K, ldF, Tprime, temperature, dF, dF_bf16=None, accumulate=False):
-    L.check(L.load().scl_supcon_bwd(_p(F), _p(G), _p(upstream), coef, bz, K, ldF, Tprime, temperature, _p(dF), _p(dF_bf16),
-                                    1 if accumulate else 0, _stream()), "scl_supcon_bwd")
+    _call("scl_supcon_bwd", _p(F), _p(G), _p(upstream), coef, bz, K, ldF, Tprime, temperature, _p(dF), _p(dF_bf16),
+                                    1 if accumulate else 0, _stream())
 
 
 def nll_fwd(logp, labels, bz, NC, loss_out, dlogp_coef):
-    L.check(L.load().scl_nll_fwd(_p(logp), _p(labels), bz, NC, _p(loss_out), _p(dlogp_coef), _stream()), "scl_nll_fwd")
+    _call("scl_nll_fwd", _p(logp), _p(labels), bz, NC, _p(loss_out), _p(dlogp_coef), _stream())
 
 
 def adamw_flat(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
-    L.check(L.load().scl_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, wd, step, grad_scale,
-                                    _stream()), "scl_adamw_flat")
+    _call("scl_adamw_flat", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, wd, step, grad_scale,
+                                    _stream())
 
 
 def fir_nblocks(Lout):
@@ -226,40 +273,38 @@ def fir_nblocks(Lout):
 
 
 def fir_multi(x, ldx, Lin, taps, tap_off, tap_len, tap_h, nclip, nf, use_pow, y, ldy, Lout, part=None):
-    L.check(L.load().scl_fir_multi_f32(_p(x), ldx, Lin, _p(taps), _p(tap_off), _p(tap_len), _p(tap_h), nclip, nf,
-                                       1 if use_pow else 0, _p(y), ldy, Lout, _p(part), _stream()), "scl_fir_multi_f32")
+    _call("scl_fir_multi_f32", _p(x), ldx, Lin, _p(taps), _p(tap_off), _p(tap_len), _p(tap_h), nclip, nf,
+                                       1 if use_pow else 0, _p(y), ldy, Lout, _p(part), _stream())
 
 
 def clip_stats(x, ldx, Lx, nclip, part):
-    L.check(L.load().scl_clip_stats_f32(_p(x), ldx, Lx, nclip, _p(part), _stream()), "scl_clip_stats_f32")
+    _call("scl_clip_stats_f32", _p(x), ldx, Lx, nclip, _p(part), _stream())
 
 
 def isd_scatter(y, ldy, pos, fr, clip_off, nclip, max_per_clip, g_sd):
-    L.check(L.load().scl_isd_scatter_f32(_p(y), ldy, _p(pos), _p(fr), _p(clip_off), nclip, max_per_clip, g_sd, _stream()),
-            "scl_isd_scatter_f32")
+    _call("scl_isd_scatter_f32", _p(y), ldy, _p(pos), _p(fr), _p(clip_off), nclip, max_per_clip, g_sd, _stream())
 
 
 AFF_CENTER_PEAK_COND, AFF_PEAK_COND, AFF_PEAK_ALWAYS, AFF_SSI_MIX, AFF_PEAK_QUANT_I16 = 0, 1, 2, 3, 4
 
 
 def clip_affine(mode, x, ldx, partx, out, ldo, Lx, nclip, z=None, ldz=0, partz=None, snr_db=None):
-    L.check(L.load().scl_clip_affine_f32(mode, _p(x), ldx, _p(z), ldz, _p(partx), _p(partz), _p(snr_db), _p(out), ldo, Lx, nclip,
-                                         _stream()), "scl_clip_affine_f32")
+    _call("scl_clip_affine_f32", mode, _p(x), ldx, _p(z), ldz, _p(partx), _p(partz), _p(snr_db), _p(out), ldo, Lx, nclip,
+                                         _stream())
 
 
 def f32_to_i16_wrap(x, out_i16, n):
-    L.check(L.load().scl_f32_to_i16_wrap(_p(x), _p(out_i16), n, _stream()), "scl_f32_to_i16_wrap")
+    _call("scl_f32_to_i16_wrap", _p(x), _p(out_i16), n, _stream())
 
 
 def i16_sumsq(x_i16, n, part64, nparts):
-    L.check(L.load().scl_i16_sumsq(_p(x_i16), n, _p(part64), nparts, _stream()), "scl_i16_sumsq")
+    _call("scl_i16_sumsq", _p(x_i16), n, _p(part64), nparts, _stream())
 
 
 def i16_gain_overlay(speech_i16, n, noise_i16, nn, factor, out_f32=None, out_i16=None):
-    L.check(L.load().scl_i16_gain_overlay(_p(speech_i16), n, _p(noise_i16), nn, factor, _p(out_f32), _p(out_i16), _stream()),
-            "scl_i16_gain_overlay")
+    _call("scl_i16_gain_overlay", _p(speech_i16), n, _p(noise_i16), nn, factor, _p(out_f32), _p(out_i16), _stream())
 
 
 def multiview_crop(src, off, lens, V, firstlen, start, out_len, repeat_pad, out, ldo):
-    L.check(L.load().scl_multiview_crop_f32(_p(src), _p(off), _p(lens), V, firstlen, start, out_len, 1 if repeat_pad else 0,
-                                            _p(out), ldo, _stream()), "scl_multiview_crop_f32")
+    _call("scl_multiview_crop_f32", _p(src), _p(off), _p(lens), V, firstlen, start, out_len, 1 if repeat_pad else 0,
+                                            _p(out), ldo, _stream())

@@ -58,6 +58,28 @@ def test_layouts(dev, a_t, b_t, M, N, K):
     _close(C, ref, 2e-3, "layout a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(304, 200, 136), (128, 128, 64), (264, 136, 200), (72, 64, 1000), (1000, 520, 264)])
+def test_lds_dma_staging_equals_register_staging(dev, a_t, b_t, M, N, K):
+    """All dims % 8 == 0 -> the LDS-DMA kernel is selected; it must agree BIT FOR BIT with the register-staged
+    kernel (same LDS image, same MFMA order) and with the fp32 reference; memory around the operands is NaN."""
+    A = _rand((M, K), dev, 21); B = _rand((N, K), dev, 22)
+    ref = A.float() @ B.float().t()
+    def padded(mat, rows, cols):
+        buf = torch.full((rows + 3, cols + 8), float("nan"), dtype=torch.bfloat16, device=dev)
+        buf[:rows, :cols] = mat
+        return buf, cols + 8
+    bufA, ldA = padded(A.t().contiguous(), K, M) if a_t else padded(A, M, K)
+    bufB, ldB = padded(B.t().contiguous(), K, N) if b_t else padded(B, N, K)
+    outs = []
+    for no_dma in (False, True):
+        C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(ops.Op(bufA, ldA), ops.Op(bufB, ldB), C, M, N, K, a_t=a_t, b_t=b_t, no_dma=no_dma)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], ref, 2e-3, "dma a_t=%s b_t=%s" % (a_t, b_t))
+
+
 def test_kcontig_tail_needs_no_zero_padding(dev):
     # K = 199: the last 16-byte vector is partially valid; garbage (NaN) beyond K must be masked
     M, N, K = 70, 90, 199
