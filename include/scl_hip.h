@@ -74,6 +74,7 @@ typedef struct SclOperand {
 #define SCL_GEMM_HAS_C2   0x00000040  /* also store the pre-activation value */
 #define SCL_GEMM_DROPOUT  0x00000080  /* multiply by keep-mask(seed,row,col)/(1-p) after act / grad-mul */
 #define SCL_GEMM_NO_DMA   0x00100000  /* force the register-staged kernel (testing / A-B comparison) */
+#define SCL_GEMM_NO_BIG   0x00200000  /* do not pick the 256x128 / 3-stage variant */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
 #define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */
 #define SCL_GEMM_RACT_SHIFT  16
@@ -159,6 +160,12 @@ int scl_utt_head_bwd(const float* dlogp, const float* logp, const float* emb, co
 /* ------------------------------------------------------------------------------------------ */
 int scl_softmax_fwd(const float* S, void* P, int64_t R, int T, int ldS, int Tp, void* stream);
 int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, int lddP, int Tp, void* stream);
+/* Fused attention for head dim 64 (scores stay on chip).  qkv / dqkv: bf16 [B, T, 3, H, 64]; ctx / dctx: bf16 [B, T, H*64];
+ * lse: f32 [B, H, T] row log-sum-exp of the scaled scores.  fwd: T <= 256; bwd: T <= 224 (LDS budget).
+ * Replaces F.multi_head_attention_forward inside fairseq's TransformerSentenceEncoderLayer (model/xlsr.py:41) and its backward. */
+int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream);
+int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int B, int T, int H, int D,
+                 float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* feature-extractor layer 0 (Conv1d(1,C,10,5) + LayerNorm + GELU), fused fwd / bwd            */

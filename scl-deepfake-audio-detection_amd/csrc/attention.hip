@@ -81,3 +81,387 @@ extern "C" int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)P, dP, (bf16_t*)dS, R, T, lddP, Tp);
     return scl_check_launch("scl_softmax_bwd");
 }
+
+// =====================================================================================================
+// Fused attention (head dim 64, T <= 256): scores never leave the chip.
+//
+// Forward, one workgroup per (utterance, head), 4 waves.  K and V of the head are staged once in LDS
+// (K with the GEMM's 16-byte-slot swizzle for ds_read_b128 row reads, V with a 32-byte-chunk swizzle for
+// ds_read_b64_tr_b16 transposed reads).  A wave takes 16 queries at a time:
+//   S^T[key][q] = K Q^T      MFMA(A = K rows from LDS, B = Q rows straight from global)  -> lane owns ONE query
+//                            (column q = lane&15) and keys 16t + 4*(lane>>4) + reg: the row softmax is an in-lane
+//                            reduction plus two cross-lane steps (xor 16, xor 32), fp32, exp via the scaled max.
+//   O^T[d][q]   = V^T P^T    the normalised probabilities, packed to bf16, ARE the B operand of the next MFMA
+//                            (k index permuted; the A operand = V^T is fetched with the same permutation by the
+//                            transposed LDS read), so P never goes through LDS.
+// Writes ctx (bf16, [B,T,H*64] slice) and the row log-sum-exp (fp32) that the backward recomputes P from.
+// Reference arithmetic: fairseq MultiheadAttention inside Wav2Vec2Model.forward (model/xlsr.py:41):
+// softmax((q*scale) k^T) v with fp32 softmax.
+// =====================================================================================================
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_a;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4a;
+constexpr int ATT_D = 64;
+constexpr int ATT_NTMAX = 16;   // key tiles of 16 -> T <= 256
+
+__device__ __forceinline__ int att_k_off(int key, int c) { return key * 128 + ((c ^ ((key >> 1) & 7)) << 4); }          // row-read image
+__device__ __forceinline__ int att_t_off(int key, int d) { return key * 128 + ((((d >> 4) ^ ((key >> 1) & 3))) << 5) + ((d & 15) << 1); }  // tr-read image
+
+__device__ __forceinline__ bf16x8 att_frag_rows(const char* tile, int rowblk, int ks, int lane) {
+    const int row = rowblk * 16 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(tile + att_k_off(row, 4 * ks + (lane >> 4)));
+}
+// A operand [i = d (16 of them, block dt)][k = 8 keys]: keys rowa + 4g + 0..3 and rowb + 4g + 0..3
+__device__ __forceinline__ bf16x8 att_frag_tr(const char* tile, int rowa, int rowb, int dt, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int ra = rowa + 4 * g + (i >> 2), rb = rowb + 4 * g + (i >> 2);
+    const int col = 16 * dt + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_a*)(tile + att_t_off(ra, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_a*)(tile + att_t_off(rb, col)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                       int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char asmem[];
+    const int E = H * ATT_D;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int NT = (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
+    char* Kt = asmem;                 // [rows][128 B] row-read image
+    char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
+    const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
+    for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            kv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
+            vv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+        }
+        *reinterpret_cast<uint4*>(Kt + att_k_off(key, c)) = kv;
+        *reinterpret_cast<uint4*>(Vt + att_t_off(key, 8 * c)) = vv;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lc = lane & 15, g = lane >> 4;
+    const float sl2 = scale * 1.4426950408889634f;
+    for (int qb = wave; qb < NT; qb += 4) {
+        const int q = qb * 16 + lc;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (q < T) u = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 32 * ks + 8 * g);
+            qf[ks] = __builtin_bit_cast(bf16x8, u);
+        }
+        f32x4 s[ATT_NTMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < ATT_NTMAX; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < NT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows(Kt, t, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
+                    m = fmaxf(m, s[t][r]);
+                }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < ATT_NTMAX; ++t) {
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][r] = exp2f((s[t][r] - m) * sl2); l += s[t][r]; }
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (g == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = scale * m + __logf(l);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < ATT_NTMAX / 2; ++u) {
+            if (u < NT2) {
+                const int ta = 2 * u, tb = 2 * u + 1;
+                float pb[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tb < NT) { pb[0] = s[tb][0] * inv; pb[1] = s[tb][1] * inv; pb[2] = s[tb][2] * inv; pb[3] = s[tb][3] * inv; }
+                u32x4a pk;
+                pk[0] = pack_bf2(s[ta][0] * inv, s[ta][1] * inv); pk[1] = pack_bf2(s[ta][2] * inv, s[ta][3] * inv);
+                pk[2] = pack_bf2(pb[0], pb[1]); pk[3] = pack_bf2(pb[2], pb[3]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_tr(Vt, 16 * ta, 16 * tb, dt, lane), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < T) {
+            bf16_t* dst = ctx + ((int64_t)b * T + q) * E + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3]));
+        }
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------------------
+// Backward, one workgroup per (utterance, head), 4 waves, T <= 224.  Wave w OWNS keys 64w..64w+63 and keeps
+// dK^T and dV^T of those keys in 128 accumulator registers while the workgroup sweeps the queries 32 at a time:
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T         (lane owns one key column, registers hold 4 queries)
+//   P = exp(scale*S - LSE[q]),  dS = P * (dP - delta[q]),  delta[q] = <dO[q], O[q]>   (computed here, in the tile loader)
+//   dV^T += dO^T P,  dK^T += Q^T dS                (P / dS accumulators ARE the B operands; dO^T / Q^T by transposed LDS reads)
+//   dQ    = dS K                                   (dS crosses LDS once per wave; the 4 waves' partials are summed in fixed order)
+// Scores, probabilities and their gradients never touch HBM.  dQ/dK carry the softmax scale.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 att_frag_tr_nat(const char* tile, int base, int dt, int lane) {   // k = base + 8g + 0..7
+    const int i = lane & 15, g = lane >> 4;
+    const int ra = base + 8 * g + (i >> 2);
+    const int col = 16 * dt + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_a*)(tile + att_t_off(ra, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_a*)(tile + att_t_off(ra + 4, col)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 att_pack8(const f32x4& a, const f32x4& b) {
+    u32x4a pk;
+    pk[0] = pack_bf2(a[0], a[1]); pk[1] = pack_bf2(a[2], a[3]); pk[2] = pack_bf2(b[0], b[1]); pk[3] = pack_bf2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, pk);
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                          const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char asmem[];
+    const int E = H * ATT_D;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int NT = (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
+    char* Kk = asmem;
+    char* Kt = Kk + rows * 128;
+    char* Vk = Kt + rows * 128;
+    char* Qk = Vk + rows * 128;            // 4 KiB each
+    char* Qt = Qk + 4096;
+    char* Ok = Qt + 4096;
+    char* Ot = Ok + 4096;
+    char* dSs = Ot + 4096;                 // [4 waves][32 q][128 B]
+    float* dQp = reinterpret_cast<float*>(dSs + 4 * 4096);   // [4 waves][32 q][64 d]
+    float* lseS = dQp + 4 * 32 * 64;       // [32]
+    float* delS = lseS + 32;               // [32]
+    const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
+    for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            kv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
+            vv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+        }
+        *reinterpret_cast<uint4*>(Kk + att_k_off(key, c)) = kv;
+        *reinterpret_cast<uint4*>(Kt + att_t_off(key, 8 * c)) = kv;
+        *reinterpret_cast<uint4*>(Vk + att_k_off(key, c)) = vv;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lc = lane & 15, g = lane >> 4;
+    int nkt = NT - 4 * wave; nkt = nkt < 0 ? 0 : (nkt > 4 ? 4 : nkt);     // key tiles this wave owns
+    const int nks = (rows - 64 * wave) >= 64 ? 2 : ((rows - 64 * wave) >= 32 ? 1 : 0);   // 32-key steps inside the K image
+    char* dSw = dSs + wave * 4096;
+    float* dQw = dQp + wave * 32 * 64;
+
+    f32x4 dVt[4][4], dKt[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int u = 0; u < NT2; ++u) {
+        __syncthreads();   // previous step's readers are done with the q-tiles / dQ partials (and K/V staging on u == 0)
+        {   // ---- stage 32 queries: Q, dO (both images), LSE, delta
+            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+            const int q = 32 * u + r;
+            uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), cv = make_uint4(0, 0, 0, 0);
+            if (q < T) {
+                qv = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * c);
+                ov = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * c);
+                cv = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * c);
+            }
+            *reinterpret_cast<uint4*>(Qk + att_k_off(r, c)) = qv;
+            *reinterpret_cast<uint4*>(Qt + att_t_off(r, 8 * c)) = qv;
+            *reinterpret_cast<uint4*>(Ok + att_k_off(r, c)) = ov;
+            *reinterpret_cast<uint4*>(Ot + att_t_off(r, 8 * c)) = ov;
+            const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w}, cw[4] = {cv.x, cv.y, cv.z, cv.w};
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dot += __uint_as_float(ow[k] << 16) * __uint_as_float(cw[k] << 16);
+                dot += __uint_as_float(ow[k] & 0xFFFF0000u) * __uint_as_float(cw[k] & 0xFFFF0000u);
+            }
+            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+            if (c == 0) {
+                delS[r] = dot;
+                lseS[r] = q < T ? lse[((int64_t)b * H + h) * T + q] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (nkt > 0) {
+            bf16x8 qa[2][2], oa[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { qa[a][ks] = att_frag_rows(Qk, a, ks, lane); oa[a][ks] = att_frag_rows(Ok, a, ks, lane); }
+            float lq[2][4], dq_[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r]; dq_[a][r] = delS[16 * a + 4 * g + r]; }
+            f32x4 P[2][4], dS[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) { P[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dS[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (j < nkt) {
+                    const int kb = 4 * wave + j;
+                    const bf16x8 k0 = att_frag_rows(Kk, kb, 0, lane), k1 = att_frag_rows(Kk, kb, 1, lane);
+                    const bf16x8 v0 = att_frag_rows(Vk, kb, 0, lane), v1 = att_frag_rows(Vk, kb, 1, lane);
+                    const int key = 16 * kb + lc;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][0], k0, sv, 0, 0, 0);
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][1], k1, sv, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][0], v0, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][1], v1, dp, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qq = 32 * u + 16 * a + 4 * g + r;
+                            const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
+                            P[a][j][r] = p;
+                            dS[a][j][r] = p * (dp[r] - dq_[a][r]);
+                        }
+                    }
+                }
+            }
+            // ---- dV^T += dO^T P ; dK^T += Q^T dS   (k = 32 queries of this step)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 ot = att_frag_tr(Ot, 0, 16, dt, lane);
+                const bf16x8 qt = att_frag_tr(Qt, 0, 16, dt, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nkt) {
+                        dVt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, att_pack8(P[0][j], P[1][j]), dVt[dt][j], 0, 0, 0);
+                        dKt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, att_pack8(dS[0][j], dS[1][j]), dKt[dt][j], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- dS -> LDS (row-read image [32 q][64 keys]) for the dQ product
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = 16 * a + 4 * g + r, kl = 16 * j + lc;
+                        *reinterpret_cast<bf16_t*>(dSw + att_k_off(ql, kl >> 3) + ((kl & 7) << 1)) = f2bf(dS[a][j][r]);
+                    }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's dS writes are in LDS before it reads them back
+        __builtin_amdgcn_wave_barrier();
+        {
+            f32x4 dq[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nkt > 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks < nks) {
+                        const bf16x8 d0 = att_frag_rows(dSw, 0, ks, lane), d1 = att_frag_rows(dSw, 1, ks, lane);
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const bf16x8 kf = att_frag_tr_nat(Kt, 64 * wave + 32 * ks, dt, lane);
+                            dq[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, kf, dq[0][dt], 0, 0, 0);
+                            dq[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, kf, dq[1][dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // partial dQ[q = 16a + 4g + r][d = 16dt + lc] of this wave's keys
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dQw[(16 * a + 4 * g + r) * 64 + 16 * dt + lc] = dq[a][dt][r];
+        }
+        __syncthreads();
+        {   // ---- sum the 4 waves' partials (fixed order), scale, store dQ
+            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+            const int q = 32 * u + r;
+            if (q < T) {
+                float acc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+                for (int w = 0; w < 4; ++w) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(dQp + (w * 32 + r) * 64 + 8 * c);
+                    const float4 x1 = *reinterpret_cast<const float4*>(dQp + (w * 32 + r) * 64 + 8 * c + 4);
+                    acc[0] += x0.x; acc[1] += x0.y; acc[2] += x0.z; acc[3] += x0.w; acc[4] += x1.x; acc[5] += x1.y; acc[6] += x1.z; acc[7] += x1.w;
+                }
+                uint4 o;
+                o.x = pack_bf2(acc[0] * scale, acc[1] * scale); o.y = pack_bf2(acc[2] * scale, acc[3] * scale);
+                o.z = pack_bf2(acc[4] * scale, acc[5] * scale); o.w = pack_bf2(acc[6] * scale, acc[7] * scale);
+                *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * T + q) * 3 * E + h * ATT_D + 8 * c) = o;
+            }
+        }
+    }
+    // ---- dK, dV of this wave's keys: lane owns key 16(4w+j)+lc, d = 16dt + 4g + 0..3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = 16 * (4 * wave + j) + lc;
+        if (j < nkt && key < T) {
+            bf16_t* dst = dqkv + ((int64_t)b * T + key) * 3 * E + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<uint2*>(dst + E + 16 * dt) = make_uint2(pack_bf2(dKt[dt][j][0] * scale, dKt[dt][j][1] * scale),
+                                                                         pack_bf2(dKt[dt][j][2] * scale, dKt[dt][j][3] * scale));
+                *reinterpret_cast<uint2*>(dst + 2 * E + 16 * dt) = make_uint2(pack_bf2(dVt[dt][j][0], dVt[dt][j][1]),
+                                                                             pack_bf2(dVt[dt][j][2], dVt[dt][j][3]));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream) {
+    SCL_REQUIRE(qkv && ctx && lse && B > 0 && H > 0, "attn_fwd: bad args");
+    SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 256, "attn_fwd: fused path needs head dim 64 and T <= 256 (got D=%d, T=%d)", D, T);
+    const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
+    const size_t lds = (size_t)2 * rows * 128;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale);
+    return scl_check_launch("scl_attn_fwd");
+}
+
+extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int B, int T, int H, int D,
+                            float scale, void* stream) {
+    SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0, "attn_bwd: bad args");
+    SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 224, "attn_bwd: fused path needs head dim 64 and T <= 224 (got D=%d, T=%d)", D, T);
+    const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
+    const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 4 * 4096 + 4 * 32 * 64 * 4 + 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, H, scale);
+    return scl_check_launch("scl_attn_bwd");
+}

@@ -517,6 +517,161 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
     gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
 }
 
+
+// ---- "big" variant: 256x128 tile, 8 waves, 3-stage LDS-DMA ring --------------------------------------
+// The 128x128 kernels above are latency-bound on the K loop (rocprofv3: 48 % of wave cycles in
+// s_waitcnt/barrier, MFMA pipe 22 % busy, ~3300 cycles per 64-deep K step with 64 KiB in flight per CU).
+// This variant keeps TWO 48 KiB stages (A 256x64 + B 128x64) in flight per CU behind a counted
+// `s_waitcnt vmcnt(6)` and raw `s_barrier`s (a __syncthreads() would drain the DMA queue), raises the
+// arithmetic intensity of a stage by a third, and still runs 2 waves per SIMD (512 threads, 1 block/CU,
+// 144 KiB of the 160 KiB LDS).  Per K step: wait(tile kt) -> barrier -> issue(tile kt+2) -> 32 MFMA/wave.
+// Loads past the last tile are issued at offset 0xFFFFFFFF (no fetch, zeros) so the vmcnt arithmetic is
+// the same in every iteration.
+constexpr int BIG_BM = 256;
+constexpr int BIG_STAGE = 3 * TILE_BYTES;   // A(2 x 16 KiB) + B(16 KiB)
+constexpr int BIG_LDS = 3 * BIG_STAGE;      // 147456 B
+
+template <int NSUB>   // K-contiguous operand with NSUB*128 rows; wave owns pieces wave*(2*NSUB) + i
+struct BigK {
+    static constexpr int NP = 2 * NSUB;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned rowoff[NP];
+    int kc[NP];
+    int kcur, kend;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int row0, int rowlimit, int kbegin, int kend_, int lane, int wave) {
+        rsrc = make_rsrc(base);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = wave * NP + i;
+            const int row = 8 * p + (lane >> 3);
+            const int r = row0 + row;
+            rowoff[i] = r < rowlimit ? row_off(o, (unsigned)r) : OOB;
+            kc[i] = (lane & 7) ^ ((row >> 1) & 7);
+        }
+        kcur = kbegin; kend = kend_;
+    }
+    __device__ __forceinline__ void issue(const OpK& o, char* tile, int wave) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = kcur + 8 * kc[i];
+            const unsigned off = (k < kend && rowoff[i] != OOB) ? rowoff[i] + col_off(o, (unsigned)k) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(tile + (wave * NP + i) * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance() { kcur += BK; }
+};
+
+template <int NSUB>   // transposed operand with NSUB sub-tiles of [64 k][128 cols]
+struct BigT {
+    static constexpr int NP = 2 * NSUB;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned coloff[NP];
+    int krow[NP];
+    int kcur, kend;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int col0, int collimit, int kbegin, int kend_, int lane, int wave) {
+        rsrc = make_rsrc(base);
+        const int s16 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = wave * NP + i;
+            const int sub = p >> 4, pp = p & 15;
+            const int kr = 4 * pp + (lane >> 4);
+            const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
+            const int col = col0 + sub * 128 + 8 * ((((s16 >> 1) ^ sw) << 1) | (s16 & 1));
+            krow[i] = kr;
+            coloff[i] = col < collimit ? col_off(o, (unsigned)col) : OOB;
+        }
+        kcur = kbegin; kend = kend_;
+    }
+    __device__ __forceinline__ void issue(const OpK& o, char* tile, int wave) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int rr = kcur + krow[i];
+            const unsigned off = (rr < kend && coloff[i] != OOB) ? row_off(o, (unsigned)rr) + coloff[i] : OOB;
+            // pieces of sub-tile `sub` start at sub*16 KiB; within it piece pp is at pp*1 KiB: (wave*NP+i)*1024 covers both
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(tile + (wave * NP + i) * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance() { kcur += BK; }
+};
+
+template <bool T, int NSUB> struct BigSel { typedef BigK<NSUB> type; };
+template <int NSUB> struct BigSel<true, NSUB> { typedef BigT<NSUB> type; };
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int wr = wave >> 1, wc = wave & 1;                      // 4 x 2 waves of 64x64
+    const int ntiles = gridDim.x;
+    int tile;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BIG_BM, n0 = tn * BN;
+    int z = blockIdx.z;
+    const int ksplit = z % d.splitk; z /= d.splitk;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + BK - 1) / BK;
+    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int kbegin = ksplit * nk_per * BK;
+    int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    typename BigSel<AT, 2>::type sa;
+    typename BigSel<BT, 1>::type sb;
+    sa.init(d.A, Ab, m0, d.M, kbegin, kend, lane, wave);
+    sb.init(d.B, Bb, n0, d.N, kbegin, kend, lane, wave);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tiles 0 and 1 (OOB no-ops when nk < 2)
+    sa.issue(d.A, smem, wave); sb.issue(d.B, smem + 2 * TILE_BYTES, wave);
+    sa.advance(); sb.advance();
+    sa.issue(d.A, smem + BIG_STAGE, wave); sb.issue(d.B, smem + BIG_STAGE + 2 * TILE_BYTES, wave);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed (this wave's pieces); tile kt+1 stays in flight
+        __builtin_amdgcn_s_barrier();                       // ... for every wave; all waves are done with stage (kt+2)%3
+        {
+            sa.advance(); sb.advance();
+            int ns = stage + 2; if (ns >= 3) ns -= 3;
+            char* nb = smem + ns * BIG_STAGE;
+            sa.issue(d.A, nb, wave); sb.issue(d.B, nb + 2 * TILE_BYTES, wave);
+        }
+        const char* tA = smem + stage * BIG_STAGE;
+        const char* tB = tA + 2 * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = AT ? frag_t(tA + (wr >> 1) * TILE_BYTES, (wr & 1) * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
+                fb[i] = BT ? frag_t(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1 == 3 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may still target this block's LDS when it retires
+    gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
+}
+
 __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
                                         int nslabs, int64_t stride) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -615,7 +770,24 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
         const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
         const bool dma = a_whole && b_whole && !(d.flags & SCL_GEMM_NO_DMA);
-        if (dma) {
+        // 256x128 tiles when the problem fills the chip with them (one 8-wave block per CU)
+        const long long big_tiles = (long long)((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN) * zdim;
+        const bool big = dma && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 512 && d.N >= 128 && d.K >= 192 && big_tiles >= 160;
+        if (big) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute((const void*)scl_gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+                attr_set = true;
+            }
+            dim3 bgrid(((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN), 1, (unsigned)zdim), bblock(512);
+            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_big_kernel<false, false>), bgrid, bblock, BIG_LDS, s, k);
+            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_big_kernel<false, true>), bgrid, bblock, BIG_LDS, s, k);
+            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_big_kernel<true, false>), bgrid, bblock, BIG_LDS, s, k);
+            else hipLaunchKernelGGL((scl_gemm_big_kernel<true, true>), bgrid, bblock, BIG_LDS, s, k);
+        } else if (dma) {
             if (!at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);
             else if (!at && bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, true>), grid, block, lds, s, k);
             else if (at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<true, false>), grid, block, lds, s, k);

@@ -155,8 +155,12 @@ class Encoder:
         d["h1"] = [bf(M * E) for _ in range(cfg.layers)]
         d["m1"], d["r1"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
         d["qkv"] = [bf(M * 3 * E + slack) for _ in range(cfg.layers)]
-        d["S"] = f32(B * H * T * Tp)   # row stride Tp keeps the 4-wide epilogue stores aligned
-        d["P"] = [bf(B * H * T * Tp + 1024) for _ in range(cfg.layers)]
+        d["fused_attn"] = (E // H == 64) and T <= 224      # scores stay on chip (csrc/attention.hip); else materialised path
+        if d["fused_attn"]:
+            d["lse"] = [f32(B * H * T) for _ in range(cfg.layers)]
+        else:
+            d["S"] = f32(B * H * T * Tp)   # row stride Tp keeps the 4-wide epilogue stores aligned
+            d["P"] = [bf(B * H * T * Tp + 1024) for _ in range(cfg.layers)]
         d["ctx"] = [bf(M * E) for _ in range(cfg.layers)]
         d["x1"] = [f32(M * E) for _ in range(cfg.layers)]
         d["m2"], d["r2"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
@@ -171,7 +175,7 @@ class Encoder:
         d["d_h"] = bf(M * E + slack)
         d["d_ctx"] = bf(M * E + slack)
         d["dqkv"] = bf(M * 3 * E + slack)
-        d["dS"] = bf(B * H * T * Tp + 1024)
+        d["dS"] = None if d["fused_attn"] else bf(B * H * T * Tp + 1024)
         d["dcpad"] = bf(B * (T + K) * E + slack)
         d["dz"] = [bf(B * t * C + slack) for t in Ts]
         d["dy"] = bf(B * Ts[1] * C + slack) if len(Ts) > 1 else None
@@ -255,11 +259,14 @@ class Encoder:
             ops.gemm(Op(d["h1"][n], E), self.W(pn + "self_attn.q_proj.weight", E), d["qkv"][n], M, 3 * E, E,
                      bias=self.b(pn + "self_attn.q_proj.bias"))  # q,k,v biases are adjacent in the flat buffer
             qkv = d["qkv"][n]
-            ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
-                     nb1=B, nb2=H, alpha=D ** -0.5, ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
-            ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, Tp, Tp)
-            ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
-                     d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
+            if d["fused_attn"]:
+                ops.attn_fwd(qkv, d["ctx"][n], d["lse"][n], B, T, H, D, D ** -0.5)
+            else:
+                ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
+                         nb1=B, nb2=H, alpha=D ** -0.5, ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
+                ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, Tp, Tp)
+                ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
+                         d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
             ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
                      bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
             ops.layernorm_fwd(d["x1"][n], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"),
@@ -313,21 +320,25 @@ class Encoder:
             self._bias_grad(d, dx, M, E, pn + "self_attn.out_proj.bias")
             self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M)
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
-            qkv, dqkv, Pn = d["qkv"][n], d["dqkv"], d["P"][n]
-            bq = dict(nb1=B, nb2=H)
-            # dV[j] = sum_i P[i][j] dctx[i]
-            ops.gemm(Op(Pn, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(d["d_ctx"], E, bs1=T * E, bs2=D), dqkv, T, D, T, a_t=True, b_t=True,
-                     ldc=3 * E, c_bs1=T * 3 * E, c_bs2=D, c_offset=2 * E, **bq)
-            # dP = dctx V^T
-            ops.gemm(Op(d["d_ctx"], E, bs1=T * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["S"], T, T, D,
-                     ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp, **bq)
-            ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, Tp, Tp)
-            sc = D ** -0.5
-            dS = Op(d["dS"], Tp, bs1=H * T * Tp, bs2=T * Tp)
-            ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), dqkv, T, D, T, b_t=True, alpha=sc, ldc=3 * E,
-                     c_bs1=T * 3 * E, c_bs2=D, c_offset=0, **bq)                                   # dQ = s dS K
-            ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=0), dqkv, T, D, T, a_t=True, b_t=True, alpha=sc, ldc=3 * E,
-                     c_bs1=T * 3 * E, c_bs2=D, c_offset=E, **bq)                                   # dK = s dS^T Q
+            qkv, dqkv = d["qkv"][n], d["dqkv"]
+            if d["fused_attn"]:
+                ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5)
+            else:
+                Pn = d["P"][n]
+                bq = dict(nb1=B, nb2=H)
+                # dV[j] = sum_i P[i][j] dctx[i]
+                ops.gemm(Op(Pn, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(d["d_ctx"], E, bs1=T * E, bs2=D), dqkv, T, D, T, a_t=True, b_t=True,
+                         ldc=3 * E, c_bs1=T * 3 * E, c_bs2=D, c_offset=2 * E, **bq)
+                # dP = dctx V^T
+                ops.gemm(Op(d["d_ctx"], E, bs1=T * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["S"], T, T, D,
+                         ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp, **bq)
+                ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, Tp, Tp)
+                sc = D ** -0.5
+                dS = Op(d["dS"], Tp, bs1=H * T * Tp, bs2=T * Tp)
+                ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), dqkv, T, D, T, b_t=True, alpha=sc, ldc=3 * E,
+                         c_bs1=T * 3 * E, c_bs2=D, c_offset=0, **bq)                                   # dQ = s dS K
+                ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=0), dqkv, T, D, T, a_t=True, b_t=True, alpha=sc, ldc=3 * E,
+                         c_bs1=T * 3 * E, c_bs2=D, c_offset=E, **bq)                                   # dK = s dS^T Q
             ops.colsum(dqkv, d["cs_part"], M, 3 * E)
             ops.colreduce(d["cs_part"], self._qkv_view(pn, "bias"), ops.colsum_nparts(M), 3 * E)
             self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)

@@ -42,6 +42,7 @@ class SclGemmDesc(ctypes.Structure):
 GEMM_A_T, GEMM_B_T, GEMM_C_F32, GEMM_C2_F32, GEMM_R_F32 = 1, 2, 4, 8, 16
 GEMM_HAS_BIAS, GEMM_HAS_C2, GEMM_DROPOUT = 0x20, 0x40, 0x80
 GEMM_NO_DMA = 0x00100000
+GEMM_NO_BIG = 0x00200000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 KID_GEMM = 0
@@ -85,6 +86,8 @@ def _protos():
         # attention.hip
         "scl_softmax_fwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
+        "scl_attn_fwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         # conv0.hip
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_conv0_bwd_nparts": ([_i32, _i32, _i32, _i32], _i32),

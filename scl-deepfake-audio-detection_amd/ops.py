@@ -82,7 +82,7 @@ class Op:
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False):
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
@@ -114,6 +114,8 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
         flags |= L.GEMM_DROPOUT
     if no_dma:
         flags |= L.GEMM_NO_DMA
+    if no_big:
+        flags |= L.GEMM_NO_BIG
     flags |= (act << L.ACT_SHIFT) | (rmode << L.RMODE_SHIFT) | (ract << L.RACT_SHIFT)
     d.c_bs1, d.c_bs2, d.c_rbstride, d.c_split_stride, d.bias_bs2 = c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2
     d.c_rpb, d.ldc = c_rpb, (N if ldc is None else ldc)
@@ -230,6 +232,14 @@ def softmax_fwd(S, P, R, T, ldS, Tp):
 
 def softmax_bwd(P, dP, dS, R, T, lddP, Tp):
     _call("scl_softmax_bwd", _p(P), _p(dP), _p(dS), R, T, lddP, Tp, _stream())
+
+
+def attn_fwd(qkv, ctx, lse, B, T, H, D, scale):
+    _call("scl_attn_fwd", _p(qkv), _p(ctx), _p(lse), B, T, H, D, scale, _stream())
+
+
+def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale):
+    _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, T, H, D, scale, _stream())
 
 
 def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5):

@@ -255,3 +255,28 @@ def test_adamw_matches_torch(dev):
         ops.adamw_flat(p, gr, m, v, pb, n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
         assert rel(p, p_ref.detach()) < 1e-6
     assert torch.equal(pb[:n], p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 199, 3), (1, 201, 2), (3, 49, 2), (2, 16, 1), (1, 224, 1)])
+def test_fused_attention_fwd_bwd(dev, B, T, H):
+    """scl_attn_fwd / scl_attn_bwd (head dim 64) vs fp32 softmax attention on the same bf16-rounded q, k, v."""
+    D, E = 64, H * 64
+    qkv = (0.7 * torch.randn(B, T, 3, H, D, generator=g(1))).to(torch.bfloat16).to(dev)
+    ctx = torch.full((B, T, E), float("nan"), dtype=torch.bfloat16, device=dev)
+    lse = torch.full((B, H, T), float("nan"), device=dev)
+    scale = D ** -0.5
+    ops.attn_fwd(qkv, ctx, lse, B, T, H, D, scale)
+    q, k, v = (qkv[:, :, i].float().permute(0, 2, 1, 3).clone().requires_grad_(True) for i in range(3))   # [B,H,T,D]
+    s = (q @ k.transpose(-1, -2)) * scale
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, E)
+    assert rel(ctx, ref) < 1.2e-2
+    assert rel(lse, torch.logsumexp(s, -1)) < 1e-5
+    dctx = torch.randn(B, T, E, generator=g(2)).to(torch.bfloat16).to(dev)
+    ref.backward(dctx.float())
+    dqkv = torch.full((B, T, 3, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale)
+    for i, gr in enumerate((q.grad, k.grad, v.grad)):
+        got = dqkv[:, :, i].float().permute(0, 2, 1, 3)
+        assert rel(got, gr) < 2.5e-2, ("qkv"[i], rel(got, gr))
+        cos = torch.nn.functional.cosine_similarity(got.flatten().cpu(), gr.flatten().cpu(), dim=0).item()
+        assert cos > 0.999, ("qkv"[i], cos)

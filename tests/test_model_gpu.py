@@ -162,3 +162,33 @@ def test_state_dict_names_follow_the_reference(dev):
         assert k in keys, k
     ref_names = {"ssl_model.model." + n for n, _, _ in W.param_shapes(W.W2VConfig.tiny())}
     assert ref_names <= keys
+
+
+def test_head_dim_64_config_uses_fused_attention_and_matches_oracle(dev):
+    """A small encoder with 64-wide heads takes the fused attention kernels (scores stay on chip): forward, losses and
+    gradients must still match the oracle's autograd."""
+    from scl_amd.encoder import W2VConfig
+    kw = dict(conv_dim=32, embed=128, layers=2, heads=2, ffn=256, pos_k=16, pos_groups=4, final_dim=16, latent_vars=8, latent_groups=2)
+    ocfg, cfg = W.W2VConfig(**kw), W2VConfig(**kw)
+    ssl, head = W.init_state(ocfg, seed=41), OH.init_head(ocfg.embed, seed=42)
+    m = Model(ARGS, dev, w2v_cfg=cfg)
+    sd = {"ssl_model.model." + k: v for k, v in ssl.items()}
+    sd.update(head)
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    x = 0.1 * torch.randn(5, 6000, generator=torch.Generator().manual_seed(3))
+    y = torch.tensor([1, 1, 1, 0, 0])
+    out, feats, emb = m(x.to(dev))
+    assert m.encoder.bufs(5, 6000)["fused_attn"]
+    losses = m.loss(out, feats, emb, y.to(dev), CONF)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    ref_losses, ref_grads, (ro, rf, re), _ = OH.train_step(ssl, head, ocfg, x, y)
+    assert close_bf16(out, ro) and close_bf16(feats, rf) and close_bf16(emb, re), (rl2(feats, rf), relerr(feats, rf))
+    for k, v in ref_losses.items():
+        assert abs(losses[k].item() - v) <= 2e-2 * max(abs(v), 1e-3), k
+    for name in ("ssl_model.model.encoder.layers.0.self_attn.q_proj.weight", "ssl_model.model.encoder.layers.0.self_attn.v_proj.weight",
+                 "ssl_model.model.encoder.layers.1.self_attn.k_proj.weight", "ssl_model.model.encoder.layers.1.self_attn.out_proj.weight",
+                 "ssl_model.model.feature_extractor.conv_layers.2.0.weight", "LL.weight"):
+        c = cosine(m.P.g(name), ref_grads[name])
+        assert c > 0.995, (name, c)
