@@ -118,12 +118,11 @@ int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float*
                       float* mean, float* rstd, int M, int C, int64_t ldx, int64_t ldy, float eps, int act, void* stream);
 /* number of row-slab partials scl_layernorm_bwd writes for M rows */
 int scl_layernorm_bwd_nparts(int M);
-/* dx = LN'(dy [* gelu'(.)]) (+ dres); per-slab partial sums of dgamma/dbeta into dgamma_part/dbeta_part
- * [nparts, C] (combine with scl_colreduce_f32).  Autograd backward of the above (main.py:79). */
+/* dx = LN'(dy [* gelu'(.)]) (+ dres); per-slab partial sums into part[nparts][2*C] = (dgamma | dbeta) per slab
+ * (one scl_colreduce_f32 over 2*C columns finishes both).  Autograd backward of the above (main.py:79). */
 int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
-                      float* dgamma_part, float* dbeta_part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx,
-                      int act, void* stream);
+                      float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream);
 int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream);
 /* bias gradients: part[p][n] = sum over row slab p of x[m][n]; nparts = scl_colsum_nparts(M) */
 int scl_colsum_nparts(int M);

@@ -164,6 +164,24 @@ struct StageT {
 template <bool T> struct StageSel { typedef StageK type; };
 template <> struct StageSel<true> { typedef StageT type; };
 
+
+// workgroup id -> output tile.  (1) XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD gets a
+// contiguous run of tile ids; (2) grouped order inside the run: 8 tile-rows are walked for one tile-column before moving to
+// the next column, so the ~64 tiles resident on an XCD at a time touch 8 A row-panels and 8 B column-panels (~4 MiB = its L2).
+__device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = tile / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsize = min(tiles_m - first_m, GROUP_M);
+    const int in_group = tile - group * per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
+
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // fragment of a K-contiguous tile: 16 rows x 32 k; lane l holds row (l&15), k = 8*(l>>4)+0..7
@@ -281,17 +299,9 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // XCD-aware tile id: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
-    // contiguous run of tiles (neighbouring tiles share the A row-panel / B column-panel in its L2)
-    const int ntiles = gridDim.x;
-    int tile;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     int z = blockIdx.z;
@@ -455,15 +465,9 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int ntiles = gridDim.x;
-    int tile;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     int z = blockIdx.z;
     const int ksplit = z % d.splitk; z /= d.splitk;
@@ -604,15 +608,9 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 1, wc = wave & 1;                      // 4 x 2 waves of 64x64
-    const int ntiles = gridDim.x;
-    int tile;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BIG_BM - 1) / BIG_BM, tiles_n, tm, tn);
     const int m0 = tm * BIG_BM, n0 = tn * BN;
     int z = blockIdx.z;
     const int ksplit = z % d.splitk; z /= d.splitk;
@@ -772,7 +770,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool dma = a_whole && b_whole && !(d.flags & SCL_GEMM_NO_DMA);
         // 256x128 tiles when the problem fills the chip with them (one 8-wave block per CU)
         const long long big_tiles = (long long)((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN) * zdim;
-        const bool big = dma && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 512 && d.N >= 128 && d.K >= 192 && big_tiles >= 160;
+        const bool big = dma && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 512 && d.N >= 128 && d.K >= 192 && big_tiles >= 1000;
         if (big) {
             static bool attr_set = false;
             if (!attr_set) {

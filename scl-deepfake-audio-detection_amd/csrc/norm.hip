@@ -101,8 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
-                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ dgamma_part,
-                                                     float* __restrict__ dbeta_part, int M, int C, int64_t ldx,
+                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ part, int M, int C, int64_t ldx,
                                                      int64_t lddy, int64_t lddx, int rows_per_block, int act) {
     extern __shared__ float red[];  // [4][2][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -185,8 +184,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         float g = 0.f, b = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { g += red[(ww * 2 + 0) * C + c]; b += red[(ww * 2 + 1) * C + c]; }
-        dgamma_part[(int64_t)blockIdx.x * C + c] = g;
-        dbeta_part[(int64_t)blockIdx.x * C + c] = b;
+        part[(int64_t)blockIdx.x * 2 * C + c] = g;          // [block][dgamma (C) | dbeta (C)]
+        part[(int64_t)blockIdx.x * 2 * C + C + c] = b;
     }
 }
 
@@ -255,28 +254,34 @@ extern "C" int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, c
     return scl_check_launch("scl_layernorm_fwd");
 }
 
+static int ln_bwd_rows_per_block(int M) {
+    // ~768 blocks keep all 256 CUs busy (3 blocks each); at least one row per wave, at most 1024 partial rows to reduce
+    int rpb = (M + 767) / 768;
+    rpb = (rpb + 3) / 4 * 4;
+    if (rpb < 4) rpb = 4;
+    while ((M + rpb - 1) / rpb > 1024) rpb *= 2;
+    return rpb;
+}
 extern "C" int scl_layernorm_bwd_nparts(int M) {
-    int rows_per_block = 32;
-    while ((M + rows_per_block - 1) / rows_per_block > 1024) rows_per_block *= 2;
-    return (M + rows_per_block - 1) / rows_per_block;
+    const int rpb = ln_bwd_rows_per_block(M);
+    return (M + rpb - 1) / rpb;
 }
 
 extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, const float* dres,
-                                 float* dx_f32, void* dx_bf16, float* dgamma_part, float* dbeta_part, int M, int C,
+                                 float* dx_f32, void* dx_bf16, float* part, int M, int C,
                                  int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream) {
-    SCL_REQUIRE(dy && x && mean && rstd && gamma && dgamma_part && dbeta_part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
+    SCL_REQUIRE(dy && x && mean && rstd && gamma && part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SCL_REQUIRE(act == 0 || beta, "layernorm_bwd: gelu variant needs beta");
     SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0,
                 "layernorm_bwd: need 8 <= C <= 2048 and multiples of 8");
-    int rows_per_block = 32;
-    while ((M + rows_per_block - 1) / rows_per_block > 1024) rows_per_block *= 2;
+    const int rows_per_block = ln_bwd_rows_per_block(M);
     const int nblk = (M + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)8 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nblk), block(256);
 #define LN_BWD(XF, DF) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
-                                          dx_f32, (bf16_t*)dx_bf16, dgamma_part, dbeta_part, M, C, ldx, lddy, lddx, rows_per_block, act)
+                                          dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act)
     if (x_f32 && dy_f32) LN_BWD(true, true);
     else if (x_f32) LN_BWD(true, false);
     else if (dy_f32) LN_BWD(false, true);

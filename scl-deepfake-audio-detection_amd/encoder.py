@@ -182,7 +182,7 @@ class Encoder:
         kmax = max(cfg.conv_kernels[1:]) if len(cfg.conv_kernels) > 1 else 1
         d["dcol"] = bf(B * Ts[1] * kmax * C + slack) if len(Ts) > 1 else None
         nln = max(ops.layernorm_bwd_nparts(B * t) for t in Ts)
-        d["ln_pg"], d["ln_pb"] = f32(nln * max(C, E)), f32(nln * max(C, E))
+        d["ln_part"] = f32(nln * 2 * max(C, E))
         ncs = max(ops.colsum_nparts(B * max(Ts[1:] + [T + K])), 1)
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
         d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
@@ -213,8 +213,10 @@ class Encoder:
         ops.colreduce(d["cs_part"], self.P.g(self.n(gname)), n, N)
 
     def _ln_grads(self, d, nparts, C, wname, bname):
-        ops.colreduce(d["ln_pg"], self.P.g(self.n(wname)), nparts, C)
-        ops.colreduce(d["ln_pb"], self.P.g(self.n(bname)), nparts, C)
+        """weight and bias of a LayerNorm are adjacent in the flat buffer: one reduction over the (dgamma | dbeta) partials."""
+        ow, ob = self.P.off(self.n(wname)), self.P.off(self.n(bname))
+        assert ob == ow + C
+        ops.colreduce(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, x, training=True, refresh=True):
@@ -292,7 +294,7 @@ class Encoder:
         # final LayerNorm
         dx, dxb = d["dx_a"], d["dxbf_a"]
         ops.layernorm_bwd(d_out, d["xin"][cfg.layers], d["omean"], d["orstd"], self.b("encoder.layer_norm.weight"), None, None,
-                          dx, dxb, d["ln_pg"], d["ln_pb"], M, E)
+                          dx, dxb, d["ln_part"], M, E)
         self._ln_grads(d, nlnM, E, "encoder.layer_norm.weight", "encoder.layer_norm.bias")
         other, otherb = d["dx_b"], d["dxbf_b"]
         for n in reversed(range(cfg.layers)):
@@ -313,7 +315,7 @@ class Encoder:
             self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_pg"], d["ln_pb"], M, E)
+                              other, otherb, d["ln_part"], M, E)
             self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
@@ -344,7 +346,7 @@ class Encoder:
             self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_pg"], d["ln_pb"], M, E)
+                              other, otherb, d["ln_part"], M, E)
             self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d xin
             if self.on_grads_ready is not None:
@@ -371,7 +373,7 @@ class Encoder:
         self._wgrad(d, Op(otherb, E), Op(d["h0"], C), P.g(self.n("post_extract_proj.weight")), E, C, M)
         ops.gemm(Op(otherb, E), self.W("post_extract_proj.weight", C), d["d_h"], M, C, E, b_t=True)
         ops.layernorm_bwd(d["d_h"], d["z"][-1], d["fmean"], d["frstd"], self.b("layer_norm.weight"), None, None, None, d["dz"][-1],
-                          d["ln_pg"], d["ln_pb"], M, C)
+                          d["ln_part"], M, C)
         self._ln_grads(d, nlnM, C, "layer_norm.weight", "layer_norm.bias")
         # ---- conv stack, layers 6..1
         fe = "feature_extractor.conv_layers.%d."
@@ -379,7 +381,7 @@ class Encoder:
             k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
             Mi = B * Tout
             ops.layernorm_bwd(d["dz"][i], d["y"][i], d["cmean"][i], d["crstd"][i], self.b(fe % i + "2.1.weight"),
-                              self.b(fe % i + "2.1.bias"), None, None, d["dy"], d["ln_pg"], d["ln_pb"], Mi, C, act=1)
+                              self.b(fe % i + "2.1.bias"), None, None, d["dy"], d["ln_part"], Mi, C, act=1)
             self._ln_grads(d, ops.layernorm_bwd_nparts(Mi), C, fe % i + "2.1.weight", fe % i + "2.1.bias")
             self._bias_grad(d, d["dy"], Mi, C, fe % i + "0.bias")
             dwk = d["dwk"][: C * k * C].view(C, k * C)

@@ -159,10 +159,10 @@ def layernorm_bwd_nparts(M):
     return L.load().scl_layernorm_bwd_nparts(M)
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, dgamma_part, dbeta_part, M, C, act=0):
+def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0):
+    """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums."""
     _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                                       _p(dres), _p(dx_f32), _p(dx_bf16), _p(dgamma_part), _p(dbeta_part), M, C, C, C, C,
-                                       act, _stream())
+          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):

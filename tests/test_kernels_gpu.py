@@ -43,17 +43,18 @@ def test_layernorm_fwd_bwd(dev, C, M, xdt, act):
     dres = torch.randn(M, C, generator=g(5)).to(dev)
     ref.backward(dy)
     nparts = ops.layernorm_bwd_nparts(M)
-    dgp = torch.empty(nparts, C, device=dev); dbp = torch.empty(nparts, C, device=dev)
+    part = torch.empty(nparts, 2 * C, device=dev)
     dx_f = torch.empty(M, C, device=dev); dx_b = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
-    ops.layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f, dx_b, dgp, dbp, M, C, act=act)
-    dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
-    ops.colreduce(dgp, dgam, nparts, C); ops.colreduce(dbp, dbet, nparts, C)
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f, dx_b, part, M, C, act=act)
+    both = torch.empty(2 * C, device=dev)
+    ops.colreduce(part, both, nparts, 2 * C)
+    dgam, dbet = both[:C], both[C:]
     assert rel(dx_f, xr.grad + dres) < 5e-5
     assert rel(dx_b, xr.grad + dres) < 8e-3
     assert rel(dgam, gr.grad) < 5e-5 and rel(dbet, br.grad) < 5e-5
     # bf16 dy variant
     dyb = dy.to(torch.bfloat16)
-    ops.layernorm_bwd(dyb, x, mean, rstd, gamma, beta, None, dx_f, None, dgp, dbp, M, C, act=act)
+    ops.layernorm_bwd(dyb, x, mean, rstd, gamma, beta, None, dx_f, None, part, M, C, act=act)
     xr.grad = None
     ref2 = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
     if act:
