@@ -103,7 +103,7 @@ def main():
         rb_args = default_rawboost_args()
 
     def step():
-        xs = augment.rawboost_batch(x, rb_args, args.rawboost, 16000) if args.rawboost else x
+        xs = augment.rawboost_batch(x, rb_args, args.rawboost, 16000, sampler="fast") if args.rawboost else x
         out, feats, emb = model(xs)
         losses = model.loss(out, feats, emb, y, conf)
         total = None

@@ -71,3 +71,42 @@ def test_configs_keep_the_reference_keys():
         assert c["model"]["name"] == "wav2vec2_linear_nll" and c["model"]["contra_mode"] == "all" and c["model"]["loss_type"] == 1
         assert c["data"]["name"] == plugin and c["data"]["kwargs"]["trim_length"] == 64000
         assert os.path.exists(os.path.join(ROOT, "datautils", plugin + ".py"))
+
+
+def test_batched_notch_design_matches_scipy_per_filter_design():
+    """The throughput-mode sampler designs all notch filters of a batch at once (closed-form firwin, FFT product,
+    FFT freqz); given the same (fc, bw, c, G) it must reproduce genNotchCoeffs (RawBoost.py:28-48) to round-off."""
+    from scipy import signal
+    from scl_amd import augment
+    rs = np.random.RandomState(0)
+    n, nb, fs = 12, 5, 16000
+    fc = rs.uniform(20, 8000, (n, nb)); bw = rs.uniform(100, 1000, (n, nb))
+    c = rs.uniform(10, 100, (n, nb)).astype(np.int64); c = np.where(c % 2 == 0, c + 1, c)
+    G = rs.uniform(-20, 0, n)
+    got = augment.design_notch_filters(fc, bw, c, G, fs)
+    for i in range(n):
+        b = 1
+        for j in range(nb):
+            f1, f2 = fc[i, j] - bw[i, j] / 2, fc[i, j] + bw[i, j] / 2
+            f1 = 1 / 1000 if f1 <= 0 else f1
+            f2 = fs / 2 - 1 / 1000 if f2 >= fs / 2 else f2
+            b = np.convolve(signal.firwin(int(c[i, j]), [f1, f2], window="hamming", fs=fs), b)
+        _, h = signal.freqz(b, 1, fs=fs)
+        ref = 10 ** (G[i] / 20) * b / np.amax(np.abs(h))
+        assert got[i].shape == ref.shape
+        np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-12)
+
+
+def test_fast_sampler_statistics():
+    from scl_amd import augment
+    from scl_amd.datautils_common import default_rawboost_args
+    a = default_rawboost_args()
+    augment.seed_fast_sampler(7)
+    taps = augment._fast_lnl(a, 40, 16000)
+    assert all(len(t) == 5 for t in taps)
+    lens = np.array([len(b) for t in taps for b in t])
+    assert lens.min() >= 5 * 11 - 4 and lens.max() <= 501 and 200 < lens.mean() < 340      # reference: mean 268.5 (SURVEY §6)
+    isd = augment._fast_isd(a, 50, 64000)
+    frac = np.array([len(p) / 64000 for p, _ in isd])
+    assert 0 <= frac.min() and frac.max() <= 0.10 and 0.03 < frac.mean() < 0.07
+    assert all(len(np.unique(p)) == len(p) for p, _ in isd)
