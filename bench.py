@@ -142,6 +142,16 @@ def main():
     utt_s = world * B * args.steps / dt
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM traffic per GEMM launch cannot be read live (PMC needs rocprofv3): take it from the committed counter pass of this
+    # same command (profiles/r1_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
+            pmc = json.load(f)
+        if B == 32 and L == 64000 and not args.tiny and not args.rawboost:
+            traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        traffic = None
     res = {
         "metric": "train-step utterances/sec (64000-sample clips)", "value": utt_s, "unit": "utterances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -151,8 +161,9 @@ def main():
                    "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
         "final_loss": loss_val,
         "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
-        "roofline": {"bound": "mfma", "kernel": "scl_gemm_kernel (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
-                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{dma,big,}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
                      "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
                      "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
                      "gemm_share_of_step_time": gemm_ms * 1e-3 / dt},

@@ -192,3 +192,24 @@ def test_head_dim_64_config_uses_fused_attention_and_matches_oracle(dev):
                  "ssl_model.model.feature_extractor.conv_layers.2.0.weight", "LL.weight"):
         c = cosine(m.P.g(name), ref_grads[name])
         assert c > 0.995, (name, c)
+
+
+def test_full_size_xlsr_forward_matches_oracle(dev):
+    """XLS-R-300M shape (24 layers, 1024 wide, 16 heads of 64), seeded random weights, 2 x 16000-sample clips (BASELINE
+    config-1 length): log-probs / feats / emb of the HIP path against the fp32 CPU oracle at the bf16 bar (1e-2 rel-L2)."""
+    from scl_amd.encoder import W2VConfig
+    ocfg = W.W2VConfig()
+    ssl, head = W.init_state(ocfg, seed=51), OH.init_head(ocfg.embed, seed=52)
+    m = Model(ARGS, dev, w2v_cfg=W2VConfig())
+    sd = {"ssl_model.model." + k: v for k, v in ssl.items()}
+    sd.update(head)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m.eval()
+    x = 0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        ro, rf, re = OH.full_forward(ssl, head, ocfg, x)
+        out, feats, emb = m(x.to(dev))
+    print("full-size rel-L2: out %.2e feats %.2e emb %.2e ; max-rel feats %.2e" % (rl2(out, ro), rl2(feats, rf), rl2(emb, re), relerr(feats, rf)))
+    assert rl2(out, ro) < 1e-2 and rl2(feats, rf) < 1e-2 and rl2(emb, re) < 1e-2
+    assert (out.argmax(1).cpu() == ro.argmax(1)).all()
