@@ -7,7 +7,8 @@ fp32 gradient buffer — before the (replicated) AdamW step.  The buffer is cut 
 buckets; because the hand-written backward finishes gradients from the END of the buffer (head,
 then encoder layers 23..0, then the conv stack), each bucket's all-reduce is launched as soon as the
 backward has passed its lower edge and overlaps with the rest of the backward.  xGMI is
-point-to-point, so buckets are big (64 Mi elements = 256 MiB) to amortise per-collective latency.
+point-to-point, so buckets are large (16 Mi elements = 64 MiB: per-collective latency is amortised, and only the
+last bucket — the conv stack, finished at the very end of backward — is exposed).
 Works with any torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
 import torch
@@ -26,7 +27,7 @@ def shard_indices(n_items, rank, world, epoch_seed=None, drop_last=True):
 
 
 class GradSync:
-    def __init__(self, flat_grad, group=None, bucket_elems=64 * 1024 * 1024):
+    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024):
         self.grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

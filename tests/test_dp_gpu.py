@@ -1,0 +1,84 @@
+"""Data-parallel train step on the GPU path with two processes (both on cuda:0, gloo transport — the box has one GPU;
+the code path is the one RCCL takes on a multi-GPU node): bucketed all-reduce launched from the backward's callbacks
+(also when the step is REPLAYED from a recorded launch plan), 1/world scaling inside AdamW, replicated weights."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ARGS = {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1, "w2v_arch": "tiny"}
+CONF = {"model": {"contra_mode": "all", "loss_type": 1}}
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return 0.1 * torch.randn(4, 4000, generator=g), torch.tensor([1, 1, 0, 0])
+
+
+def _step(model, opt, x, y, sync=None):
+    out, feats, emb = model(x)
+    losses = model.loss(out, feats, emb, y, CONF)
+    total = sum(losses.values())
+    opt.zero_grad()
+    if sync is not None:
+        sync.begin()
+    total.backward()
+    opt.step()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.model_linear import Model
+    from scl_amd.optim import FusedAdamW
+    from scl_amd.parallel import GradSync
+    dev = torch.device("cuda:0")
+    m = Model(ARGS, dev, seed=0)
+    m.eval()                                   # dropout off so the single-process reference below is comparable
+    sync = GradSync(m.P.grad, bucket_elems=40000)   # several buckets even for the tiny model
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4, grad_sync=sync)
+    x, y = _data(rank)
+    for _ in range(3):                         # step 2 and 3 replay the recorded plan (with its bucket callbacks)
+        _step(m, opt, x.to(dev), y.to(dev), sync)
+    torch.cuda.synchronize()
+    q.put((rank, m.P.flat[: m.P.n_train].cpu(), len(sync.bounds)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_mean_gradient_step(dev):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (w, nb)) for r, w, nb in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] > 3                                    # really bucketed
+    assert torch.equal(res[0][0], res[1][0])                # replicas stay bit-identical
+    # single-process reference: same three steps on the MEAN of the two ranks' gradients
+    from scl_amd.model_linear import Model
+    from scl_amd.optim import FusedAdamW
+    m = Model(ARGS, dev, seed=0)
+    m.eval()
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4)
+    for _ in range(3):
+        grads = []
+        for r in range(world):
+            x, y = _data(r)
+            out, feats, emb = m(x.to(dev))
+            sum(m.loss(out, feats, emb, y.to(dev), CONF).values()).backward()
+            grads.append(m.P.grad.clone())
+        m.P.grad.copy_((grads[0] + grads[1]) / world)
+        opt.step()
+    ref = m.P.flat[: m.P.n_train].cpu()
+    err = (res[0][0] - ref).abs().max().item()
+    assert err < 2e-6, err
