@@ -31,6 +31,13 @@ class _Any(types.ModuleType):
 def import_reference():
     if REF not in sys.path:
         sys.path.insert(0, REF)
+    # the reference's datautils/ has no __init__.py (it ships "__inti__.py"), so this repo's regular package of the same
+    # name would win the import; pin the name to the reference's directory explicitly
+    pkg = types.ModuleType("datautils")
+    pkg.__path__ = [os.path.join(REF, "datautils")]
+    sys.modules["datautils"] = pkg
+    for name in [k for k in sys.modules if k.startswith("datautils.")]:
+        del sys.modules[name]
     for name in ["fairseq", "librosa", "librosa.effects", "torchaudio", "torchaudio.functional", "torchaudio.io",
                  "torchaudio.transforms", "torchaudio.sox_effects", "soundfile", "pydub", "pydub.effects",
                  "tensorboardX"]:
@@ -131,6 +138,57 @@ def gen_pack():
         out["pack%d_id" % idx] = np.array(uid)
     np.savez_compressed(os.path.join(OUT, "pack.npz"), **out)
     print("pack.npz", len(out), "arrays")
+
+
+def gen_pack_variants():
+    """The sibling data plugins (aug_2, SCL_normal, augall_5): same procedure as gen_pack, RawBoost12 online only.
+    os.listdir is made order-stable (sorted) because SCL_normal / augall_5 index the spoof directory by position."""
+    import importlib
+    import random
+    import tempfile
+    out = {}
+    ids = ["a.flac", "b.flac", "c.flac", "d.flac", "e.flac"]
+    vocoders = ["hifigan", "waveglow"]
+    root = tempfile.mkdtemp()
+    rs = np.random.RandomState(2)
+    files = {}
+    for sub in ("bonafide", "vocoded", "spoof_train", "spoof_dev", "spoof"):
+        os.makedirs(os.path.join(root, sub))
+    for i, u in enumerate(ids):
+        files[os.path.join(root + "/", "bonafide", u)] = (0.1 * rs.randn(2600 + 300 * i)).astype(np.float32)
+        for v in vocoders:
+            files[os.path.join(root + "/", "vocoded", v + "_" + u)] = (0.1 * rs.randn(2500 + 300 * i)).astype(np.float32)
+    for j in range(4):
+        name = "s%d.wav" % j
+        wav = (0.1 * rs.randn(2400 + 200 * j)).astype(np.float32)
+        for sub in ("spoof_train", "spoof"):
+            open(os.path.join(root, sub, name), "w").close()
+            files[os.path.join(root + "/", sub, name)] = wav
+    for k, v in files.items():
+        out["file:" + os.path.relpath(k, root)] = v
+    out["ids"], out["vocoders"] = np.array(ids), np.array(vocoders)
+    real_listdir = os.listdir
+    for modname, kw in (("asvspoof_2019_aug_2", dict(vocoders=vocoders, num_additional_real=2)),
+                        ("SCL_normal", dict(vocoders=vocoders, num_additional_real=2, num_additional_spoof=2)),
+                        ("asvspoof_2019_augall_5", dict(vocoders=vocoders, num_additional_real=1, num_additional_spoof=2))):
+        D = importlib.import_module("datautils." + modname)
+        D.librosa.load = lambda path, sr=16000, mono=True: (files[path], sr)
+        D.os.listdir = lambda p: sorted(real_listdir(p))
+        args = Args()
+        args.is_train = True
+        try:
+            ds = D.Dataset_for(args, list_IDs=ids, labels=[], base_dir=root + "/", algo=5, augmentation_methods=["RawBoost12"],
+                               trim_length=1500, wav_samp_rate=16000, online_aug=True, aug_dir="/tmp/x", repeat_pad=True, **kw)
+        finally:
+            D.os.listdir = real_listdir
+        for idx in (1, 3):
+            np.random.seed(60 + idx)
+            random.seed(70 + idx)
+            uid, data, label = ds[idx]
+            out["%s:pack%d_data" % (modname, idx)] = data.numpy()
+            out["%s:pack%d_label" % (modname, idx)] = label.numpy()
+    np.savez_compressed(os.path.join(OUT, "pack_variants.npz"), **out)
+    print("pack_variants.npz", len(out), "arrays")
 
 
 def gen_head_loss():
@@ -335,6 +393,7 @@ if __name__ == "__main__":
     gen_rawboost()
     gen_multiview()
     gen_pack()
+    gen_pack_variants()
     gen_head_loss()
     gen_train_step()
     gen_eer()

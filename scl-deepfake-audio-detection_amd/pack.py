@@ -199,7 +199,9 @@ class PackDataset(Dataset):
         self.num_additional_real, self.num_additional_spoof = num_additional_real, num_additional_spoof
         self.methods = list(augmentation_methods) if len(augmentation_methods) >= 1 else ["RawBoost12"]
         if recipe in ("scl_normal", "augall_5"):
-            self.spoof_dir = os.path.join(base_dir, "spoof_train" if getattr(args, "is_train", is_train) else "spoof_dev")
+            # SCL_normal.py:69-71 switches on args.is_train; asvspoof_2019_augall_5.py:82 always reads <base>/spoof
+            self.spoof_dir = os.path.join(base_dir, "spoof") if recipe == "augall_5" else \
+                os.path.join(base_dir, "spoof_train" if getattr(args, "is_train", is_train) else "spoof_dev")
             self.spoof_list = [f for f in sorted(os.listdir(self.spoof_dir)) if f.endswith(".wav") or f.endswith(".flac")] \
                 if os.path.isdir(self.spoof_dir) else []
         print("vocoders:", self.vocoders)
