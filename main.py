@@ -24,9 +24,10 @@ import torch
 import yaml
 from torch.utils.data import DataLoader, Subset
 
+from model.wav2vec2_aasist import Model as wav2vec2_aasist
 from model.wav2vec2_linear_nll import Model as wav2vec2_linear_nll
 
-MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll}
+MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll, "wav2vec2_aasist": wav2vec2_aasist}
 
 
 class EarlyStop:

@@ -386,14 +386,67 @@ def gen_eer():
     print("eer.npz", len(out), "arrays")
 
 
+def gen_aasist():
+    """Reference wav2vec2_aasist.Model (graph-attention back-end) with an injected encoder; parameters filled by
+    oracle/aasist.py::fill_state.  Case `eval`: model.eval().  Case `train`: model.train() with every Dropout p set to 0
+    (BatchNorm batch statistics, running-stat updates and the discarded bn1 of Residual_block are exercised)."""
+    import model.wav2vec2_aasist as M
+    from oracle.aasist import fill_state
+    E = 16
+
+    class Enc(torch.nn.Module):
+        out_dim = E
+
+        def extract_feat(self, x):
+            return x
+
+    M.SSLModel = lambda device: Enc()
+    cfg = {"filts": [128, [1, 32], [32, 32], [32, 64], [64, 64]], "gat_dims": [64, 32], "pool_ratios": [0.5, 0.5, 0.5, 0.5],
+           "temperatures": [2.0, 2.0, 100.0, 100.0], "nclasses": 2}
+    out = {}
+    B, T = 4, 61
+    rs = np.random.RandomState(11)
+    x0 = rs.standard_normal((B, T, E)).astype(np.float32)
+    wl = rs.standard_normal((B, 2)).astype(np.float32)
+    wh = rs.standard_normal((B, 160)).astype(np.float32)
+    out.update(x=x0, w_logits=wl, w_hidden=wh)
+    for case in ("eval", "train"):
+        m = M.Model({"aasist": cfg}, "cpu", is_train=True)
+        sd = m.state_dict()
+        filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=5)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+        if case == "eval":
+            m.eval()
+        else:
+            m.train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+        x = torch.from_numpy(x0).clone().requires_grad_(True)
+        logits, hidden = m(x)
+        (logits * torch.from_numpy(wl)).sum().add((hidden * torch.from_numpy(wh)).sum()).backward()
+        out[case + ":logits"] = logits.detach().numpy()
+        out[case + ":hidden"] = hidden.detach().numpy()
+        out[case + ":grad_x"] = x.grad.numpy()
+        for k in ("LL.weight", "out_layer.weight", "pos_S", "master1", "encoder.0.0.conv1.weight", "encoder.3.0.conv2.weight",
+                  "attention.0.weight", "GAT_layer_T.att_weight", "HtrgGAT_layer_ST11.att_weight12", "HtrgGAT_layer_ST22.proj_with_attM.weight",
+                  "pool_hS1.proj.weight", "first_bn1.weight"):
+            out[case + ":grad:" + k] = dict(m.named_parameters())[k].grad.numpy()
+        if case == "train":
+            for k in ("first_bn.running_mean", "encoder.1.0.bn1.running_mean", "encoder.1.0.bn1.running_var", "HtrgGAT_layer_ST12.bn.running_var"):
+                out["train:buf:" + k] = m.state_dict()[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "aasist.npz"), **out)
+    print("aasist.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
+    only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
+    want = lambda name: not only or name in only
+    if want("w2v_hf"):
+        gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
-    gen_rawboost()
-    gen_multiview()
-    gen_pack()
-    gen_pack_variants()
-    gen_head_loss()
-    gen_train_step()
-    gen_eer()
+    for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist)):
+        if want(name):
+            fn()

@@ -1,0 +1,154 @@
+"""`wav2vec2_aasist` plugin on the GPU: HIP encoder + LL behind one autograd boundary, torch-composed AASIST back-end on
+flat-buffer parameter views.  Reference = oracle wav2vec2 restatement (fp32, CPU) -> LL -> the same AasistHead class that
+tests/test_aasist_cpu.py pins to the reference's own Model.  Tolerance: the bf16 bar of BASELINE.json (rel-L2 < 1e-2 on the
+encoder-side tensors); the back-end's top-k graph pooling is discontinuous, so tensors after it get 5e-2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import head as OH  # noqa: E402
+from oracle import wav2vec2 as W  # noqa: E402
+from oracle.aasist import fill_state  # noqa: E402
+from scl_amd.aasist_head import UPSTREAM_AASIST, AasistHead  # noqa: E402
+from scl_amd.encoder import W2VConfig  # noqa: E402
+from scl_amd.model_aasist import Model  # noqa: E402
+from scl_amd.optim import FusedAdamW  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ARGS = {"contra_mode": "all", "loss_type": 1, "aasist": UPSTREAM_AASIST}
+CONF = {"model": {"contra_mode": "all", "loss_type": 1}}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rl2(got, ref):
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+
+
+class CpuRef(torch.nn.Module):
+    def __init__(self, ssl_sd, cfg, head_sd):
+        super().__init__()
+        self.cfg = cfg
+        self.ssl = {k: v.clone() for k, v in ssl_sd.items()}
+        self.LL = torch.nn.Linear(cfg.embed, 128)
+        head = AasistHead(UPSTREAM_AASIST)
+        for n, c in head.named_children():
+            self.add_module(n, c)
+        for n in ("pos_S", "master1", "master2"):
+            self.register_parameter(n, getattr(head, n))
+        self.load_state_dict(head_sd)
+
+    def forward(self, x):
+        feats = self.LL(W.forward(self.ssl, self.cfg, x))
+        out, hid = AasistHead.forward(self, feats)
+        return out, feats, hid
+
+
+def make(dev, seed, drop0=True):
+    cfg = W.W2VConfig.tiny()
+    ssl = W.init_state(cfg, seed=seed)
+    m = Model(ARGS, dev, w2v_cfg=W2VConfig.tiny())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("ssl_model.")}
+    head_sd = {k: torch.from_numpy(v) for k, v in fill_state(shapes, seed=seed + 1).items()}
+    sd = {"ssl_model.model." + k: v for k, v in ssl.items()}
+    sd.update(head_sd)
+    m.load_state_dict(sd)
+    ref = CpuRef(ssl, cfg, head_sd)
+    if drop0:
+        for mod in list(m.modules()) + list(ref.modules()):
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    return m, ref, cfg
+
+
+def test_state_dict_names_and_flat_views(dev):
+    m = Model(ARGS, dev, w2v_cfg=W2VConfig.tiny())
+    keys = set(m.state_dict().keys())
+    for k in ("ssl_model.model.post_extract_proj.weight", "LL.weight", "first_bn.running_mean", "first_bn1.weight",
+              "encoder.0.0.conv1.weight", "encoder.1.0.bn1.running_var", "encoder.2.0.conv_downsample.bias", "attention.2.num_batches_tracked",
+              "pos_S", "master2", "GAT_layer_S.att_weight", "HtrgGAT_layer_ST12.att_weightM", "HtrgGAT_layer_ST21.proj_type2.bias",
+              "pool_hT2.proj.weight", "out_layer.bias"):
+        assert k in keys, k
+    lo, hi = m.P.flat.data_ptr(), m.P.flat.data_ptr() + 4 * m.P.n_total
+    for n, p in m.named_parameters():
+        assert lo <= p.data_ptr() < hi, n                      # every parameter (torch head included) is a flat-buffer view
+        if p.requires_grad:
+            assert p.grad is not None and m.P.grad.data_ptr() <= p.grad.data_ptr() < m.P.grad.data_ptr() + 4 * m.P.n_train, n
+
+
+def test_eval_forward_matches_cpu_reference(dev):
+    m, ref, cfg = make(dev, 41)
+    m.eval(); ref.eval()
+    x = 0.1 * torch.randn(3, 20000, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ro, rf, rh = ref(x)
+        out, feats, hid = m(x.to(dev))
+    assert out.shape == (3, 2) and hid.shape == (3, 160) and feats.shape == rf.shape
+    assert rl2(feats, rf) < 1e-2, rl2(feats, rf)
+    assert rl2(hid, rh) < 5e-2 and rl2(out, ro) < 5e-2, (rl2(hid, rh), rl2(out, ro))
+    m.is_train = False
+    with torch.no_grad():
+        lone = m(x.to(dev))
+    assert torch.equal(lone, out)
+    m.is_train = True
+
+
+def test_train_step_gradients_and_update(dev):
+    m, ref, cfg = make(dev, 51)
+    m.train(); ref.train()
+    x = 0.1 * torch.randn(6, 20000, generator=torch.Generator().manual_seed(3))
+    y = torch.tensor([1, 1, 1, 0, 0, 0])
+    train_names = [n for n, _, tr in W.param_shapes(cfg) if tr]
+    for n in train_names:
+        ref.ssl[n].requires_grad_(True)
+    ro, rf, rh = ref(x)
+    rl = OH.model_loss(ro, rf, rh, y, 1)
+    sum(rl.values()).backward()
+
+    opt = FusedAdamW(m, lr=1e-4, weight_decay=1e-4)
+    out, feats, hid = m(x.to(dev))
+    losses = m.loss(out, feats, hid, y.to(dev), CONF)
+    for k in rl:
+        assert abs(float(losses[k]) - float(rl[k])) < 2e-2 * abs(float(rl[k])) + 1e-4, (k, float(losses[k]), float(rl[k]))
+    opt.zero_grad()
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    refp = dict(ref.named_parameters())
+    for k in ("out_layer.weight", "HtrgGAT_layer_ST11.att_weight12", "GAT_layer_T.proj_with_att.weight", "encoder.0.0.conv1.weight", "LL.weight", "LL.bias"):
+        assert rl2(m.P.g(k), refp[k].grad) < 6e-2, (k, rl2(m.P.g(k), refp[k].grad))
+    for n in ("post_extract_proj.weight", "encoder.layers.1.fc1.weight", "encoder.layers.0.self_attn.q_proj.weight", "feature_extractor.conv_layers.0.0.weight"):
+        got, want = m.P.g("ssl_model.model." + n), ref.ssl[n].grad
+        assert rl2(got, want) < 8e-2, (n, rl2(got, want))
+    # a second backward after zero_grad gives the same head gradients (autograd accumulates into the flat views; zero_grad clears them)
+    g1 = m.P.grad[m._head_lo:].clone()
+    out, feats, hid = m(x.to(dev))
+    losses = m.loss(out, feats, hid, y.to(dev), CONF)
+    opt.zero_grad()
+    sum(losses.values()).backward()
+    assert torch.allclose(m.P.grad[m._head_lo:], g1, rtol=1e-3, atol=1e-6 + 1e-3 * g1.abs().max().item())
+    before = m.P.flat[: m.P.n_train].clone()
+    opt.step()
+    torch.cuda.synchronize()
+    delta = (m.P.flat[: m.P.n_train] - before).abs()
+    assert delta[m._head_lo:].max() > 0 and delta[: m._head_lo].max() > 0 and delta.max() <= 2.2e-4
+    # and the next forward sees the updated weights
+    out2, _, _ = m(x.to(dev))
+    assert not torch.equal(out2, out)
+
+
+def test_dropout_active_in_train_mode(dev):
+    m, _, _ = make(dev, 61, drop0=False)
+    m.train()
+    x = (0.1 * torch.randn(4, 20000, generator=torch.Generator().manual_seed(1))).to(dev)
+    a = m(x)[2]
+    b = m(x)[2]
+    assert not torch.equal(a, b)
