@@ -162,7 +162,7 @@ class Model(nn.Module):
         if use_plan:
             ops.start_recording()
         M = sv["B"] * st["T"]
-        ops.cast_f32_bf16(st["d_feats"], st["dfe_bf"], M * FEAT_DIM)
+        ops.cast_bf16(st["d_feats"], st["dfe_bf"], M * FEAT_DIM)
         ops.colsum(st["d_feats"], st["cs"], M, FEAT_DIM)
         ops.colreduce(st["cs"], P.g("LL.bias"), ops.colsum_nparts(M), FEAT_DIM)
         self.ssl._wgrad(sv["ectx"]["d"], Op(st["dfe_bf"], FEAT_DIM), Op(sv["enc_out"], E), P.g("LL.weight"), FEAT_DIM, E, M)

@@ -110,21 +110,30 @@ def test_train_step_gradients_and_update(dev):
     train_names = [n for n, _, tr in W.param_shapes(cfg) if tr]
     for n in train_names:
         ref.ssl[n].requires_grad_(True)
-    ro, rf, rh = ref(x)
-    rl = OH.model_loss(ro, rf, rh, y, 1)
-    sum(rl.values()).backward()
-
     opt = FusedAdamW(m, lr=1e-4, weight_decay=1e-4)
     out, feats, hid = m(x.to(dev))
     losses = m.loss(out, feats, hid, y.to(dev), CONF)
-    for k in rl:
-        assert abs(float(losses[k]) - float(rl[k])) < 2e-2 * abs(float(rl[k])) + 1e-4, (k, float(losses[k]), float(rl[k]))
     opt.zero_grad()
     sum(losses.values()).backward()
     torch.cuda.synchronize()
+    # (1) back-end + losses: the CPU copy of the head on the SAME features (the graph pooling's top-k is discontinuous, so the
+    #     bf16 encoder error must not enter this comparison): fp32 torch on both sides, 2e-3
+    f_leaf = feats.detach().cpu().requires_grad_(True)
+    ro, rh = AasistHead.forward(ref, f_leaf)
+    rl = OH.model_loss(ro, f_leaf, rh, y, 1)
+    sum(rl.values()).backward()
+    for k in rl:
+        assert abs(float(losses[k].detach()) - float(rl[k].detach())) < 2e-3 * abs(float(rl[k].detach())) + 1e-5, (k, float(losses[k].detach()), float(rl[k].detach()))
     refp = dict(ref.named_parameters())
-    for k in ("out_layer.weight", "HtrgGAT_layer_ST11.att_weight12", "GAT_layer_T.proj_with_att.weight", "encoder.0.0.conv1.weight", "LL.weight", "LL.bias"):
-        assert rl2(m.P.g(k), refp[k].grad) < 6e-2, (k, rl2(m.P.g(k), refp[k].grad))
+    for k in ("out_layer.weight", "HtrgGAT_layer_ST11.att_weight12", "GAT_layer_T.proj_with_att.weight", "encoder.0.0.conv1.weight",
+              "attention.0.weight", "pos_S", "master1", "pool_hT2.proj.weight"):
+        assert rl2(m.P.g(k), refp[k].grad) < 2e-3, (k, rl2(m.P.g(k), refp[k].grad))
+    # (2) encoder + LL: push the reference d(feats) through the fp32 oracle encoder; bf16 bar on the HIP side
+    rf = ref.LL(W.forward(ref.ssl, cfg, x))
+    assert rl2(feats, rf) < 1e-2
+    rf.backward(f_leaf.grad)
+    for k in ("LL.weight", "LL.bias"):
+        assert rl2(m.P.g(k), refp[k].grad) < 3e-2, (k, rl2(m.P.g(k), refp[k].grad))
     for n in ("post_extract_proj.weight", "encoder.layers.1.fc1.weight", "encoder.layers.0.self_attn.q_proj.weight", "feature_extractor.conv_layers.0.0.weight"):
         got, want = m.P.g("ssl_model.model." + n), ref.ssl[n].grad
         assert rl2(got, want) < 8e-2, (n, rl2(got, want))
