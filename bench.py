@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (configs[1]: 32; configs[2]: 64)")
     ap.add_argument("--samples", type=int, default=64000)
     ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo applied on the GPU inside the step (0 = off)")
+    ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist"], default="wav2vec2_linear_nll",
+                    help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist is an extra workload")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -80,12 +82,15 @@ def main():
     from scl_amd import augment, ops
     from scl_amd.encoder import W2VConfig
     from scl_amd.lib import KID_GEMM
-    from scl_amd.model_linear import Model
+    if args.model == "wav2vec2_aasist":
+        from scl_amd.model_aasist import Model
+    else:
+        from scl_amd.model_linear import Model
     from scl_amd.optim import FusedAdamW
     from scl_amd.parallel import GradSync
 
     cfg = W2VConfig.tiny() if args.tiny else W2VConfig()
-    margs = {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}
+    margs = {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}     # the aasist plugin falls back to the upstream AASIST-SSL sizes
     conf = {"model": {"contra_mode": "all", "loss_type": 1}}
     model = Model(margs, dev, w2v_cfg=cfg, seed=0)          # same seed on every rank = replicated weights
     model.train()                                            # dropout on, as train_epoch does (main.py:48)
@@ -148,7 +153,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
             pmc = json.load(f)
-        if B == 32 and L == 64000 and not args.tiny and not args.rawboost:
+        if B == 32 and L == 64000 and not args.tiny and not args.rawboost and args.model == "wav2vec2_linear_nll":
             traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
     except (OSError, KeyError, ValueError):
         traffic = None
@@ -156,8 +161,8 @@ def main():
         "metric": "train-step utterances/sec (64000-sample clips)", "value": utt_s, "unit": "utterances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "wav2vec2_linear_nll (XLS-R-300M shape, random init) full train step: fwd + NLL/SupCon + bwd + "
-                               "AdamW, batch %d x %d-sample clips per GPU, RawBoost %s" % (B, L, ("algo %d on-GPU" % args.rawboost) if args.rawboost else "off"),
+        "config": {"workload": "%s (XLS-R-300M shape, random init) full train step: fwd + NLL/SupCon + bwd + "
+                               "AdamW, batch %d x %d-sample clips per GPU, RawBoost %s" % (args.model, B, L, ("algo %d on-GPU" % args.rawboost) if args.rawboost else "off"),
                    "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
         "final_loss": loss_val,
         "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
@@ -168,7 +173,7 @@ def main():
                      "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
                      "gemm_share_of_step_time": gemm_ms * 1e-3 / dt},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(res))
 
