@@ -183,6 +183,7 @@ __device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, in
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
 
 // fragment of a K-contiguous tile: 16 rows x 32 k; lane l holds row (l&15), k = 8*(l>>4)+0..7
 __device__ __forceinline__ bf16x8 frag_k(const char* tile, int rowblk, int ks, int lane) {
@@ -199,6 +200,24 @@ __device__ __forceinline__ bf16x8 frag_t(const char* tile, int colblk, int ks, i
     const char* p = tile + krow * 256 + ((colblk ^ sw) << 5) + ((i & 3) << 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// The same fragment for kernels that keep LDS-DMA writes in flight across their ds_reads: hipcc (ROCm 7.2) cannot prove
+// that the tr-read builtin does not alias a pending `buffer_load ... lds` and puts `s_waitcnt vmcnt(0)` in front of it, which
+// drains the prefetch every K step (seen in the ISA of the dma / big / p8 kernels; plain ds_read_b128 is not affected).
+// Issued as inline asm the read is invisible to that pass — and to the compiler's lgkmcnt bookkeeping, so the CALLER must
+// execute `s_waitcnt lgkmcnt(0)` between these reads and the first use of their results.
+__device__ __forceinline__ bf16x8 frag_t_raw(const char* tile, int colblk, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int krow = 32 * ks + 8 * g + (i >> 2);
+    const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+    const char* p = tile + krow * 256 + ((colblk ^ sw) << 5) + ((i & 3) << 3);
+    const unsigned a = (unsigned)(uintptr_t)(lds_void*)(p);
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -396,7 +415,6 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
 // chunk that belongs at physical position (p, l).  Out-of-range rows / reduction indices fetch at
 // offset 0xFFFFFFFF (hardware range check -> zeros land in LDS).  Used whenever no 16-byte vector can
 // be partially valid (K % 8 == 0 for K-contiguous operands, M / N % 8 == 0 for transposed ones).
-typedef __attribute__((address_space(3))) void lds_void;
 
 struct DmaK {   // K-contiguous operand: piece p = rows 8p..8p+7; this wave owns pieces wave*4 + i
     __amdgpu_buffer_rsrc_t rsrc;
@@ -508,9 +526,10 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = AT ? frag_t(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
-                fb[i] = BT ? frag_t(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
+                fa[i] = AT ? frag_t_raw(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
+                fb[i] = BT ? frag_t_raw(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
             }
+            if (AT || BT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -655,9 +674,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = AT ? frag_t(tA + (wr >> 1) * TILE_BYTES, (wr & 1) * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
-                fb[i] = BT ? frag_t(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
+                fa[i] = AT ? frag_t_raw(tA + (wr >> 1) * TILE_BYTES, (wr & 1) * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
+                fb[i] = BT ? frag_t_raw(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
             }
+            if (AT || BT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -669,6 +689,133 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may still target this block's LDS when it retires
     gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
 }
+
+// ---- "p8" variant: 256x256 tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave, two wave groups in ping-pong ------
+// In the kernels above every wave of a block reaches the K-step barrier together, then all of them read LDS (MFMA pipe
+// idle), then all of them issue MFMAs (LDS idle).  Here the block's two wave groups (wr = 0 / 1, one wave of each per
+// SIMD) run half a phase apart: while one group issues its 16 MFMAs of a phase (one 64x32 quadrant x K=64) under
+// s_setprio(1), the other group does its ds_reads and LDS-DMA issues for the next phase.  Four phases per K tile:
+//   p0: read A(rows 0-63) + B(cols 0-31)   | DMA: A halves of tile t+1 -> other buffer   | MFMA quadrant (0,0)
+//   p1: read B(cols 32-63)                  |                                              | MFMA quadrant (0,1)
+//   p2: read A(rows 64-127)                 |                                              | MFMA quadrant (1,1)
+//   p3: (B cols 0-31 still in registers)    | vmcnt(0): tile t+1 landed; DMA: B halves of tile t+2 -> this buffer | (1,0)
+// LDS: 2 buffers x {A0, A1, B0, B1} half-tiles of 16 KiB (128 KiB).  Hazards (raw s_barrier, counted waits):
+//   RAW — a tile is waited for (vmcnt) before the FIRST barrier of phase p3 and first read in the next phase, so every
+//         wave's wait precedes a barrier every reader has passed, also across the half-phase stagger;
+//   WAR — a half-tile is re-staged >= 2 phases after its last ds_read (B: read p0/p1 -> staged p3; A: read p0/p2 ->
+//         staged p0 of the next tile), which covers the group that runs half a phase behind.
+// Accumulation order per output element is the same as in the 128x128 kernels (k ascending), so results are bit-identical.
+constexpr int P8_BM = 256, P8_BN = 256;
+constexpr int P8_BUF = 4 * TILE_BYTES;
+constexpr int P8_LDS = 2 * P8_BUF;          // 131072 B
+
+#define P8_PHASE(MH, NH, FBSEL)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
+                acc[MH][i][2 * (NH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FBSEL[j][ks], fa[i][ks], acc[MH][i][2 * (NH) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(512, 2) void scl_gemm_p8_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (d.N + P8_BN - 1) / P8_BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + P8_BM - 1) / P8_BM, tiles_n, tm, tn);
+    const int m0 = tm * P8_BM, n0 = tn * P8_BN;
+    int z = blockIdx.z;
+    const int ksplit = z % d.splitk; z /= d.splitk;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + BK - 1) / BK;
+    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int kbegin = ksplit * nk_per * BK;
+    int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    typename BigSel<AT, 1>::type la0, la1;
+    typename BigSel<BT, 1>::type lb0, lb1;
+    la0.init(d.A, Ab, m0, d.M, kbegin, kend, lane, wave);
+    la1.init(d.A, Ab, m0 + 128, d.M, kbegin, kend, lane, wave);
+    lb0.init(d.B, Bb, n0, d.N, kbegin, kend, lane, wave);
+    lb1.init(d.B, Bb, n0 + 128, d.N, kbegin, kend, lane, wave);
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define P8_ISSUE_A(BUF) { la0.issue(d.A, (BUF), wave); la1.issue(d.A, (BUF) + TILE_BYTES, wave); la0.advance(); la1.advance(); }
+#define P8_ISSUE_B(BUF) { lb0.issue(d.B, (BUF) + 2 * TILE_BYTES, wave); lb1.issue(d.B, (BUF) + 3 * TILE_BYTES, wave); lb0.advance(); lb1.advance(); }
+
+    // prologue: all of tile 0, B halves of tile 1 (loads past the last tile are offset-0xFFFFFFFF no-ops: counts stay uniform)
+    P8_ISSUE_A(smem) P8_ISSUE_B(smem) P8_ISSUE_B(smem + P8_BUF)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs half a phase behind group 0
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    for (int kt = 0; kt < nk; ++kt) {
+        char* buf = smem + (kt & 1) * P8_BUF;
+        char* obuf = smem + ((kt & 1) ^ 1) * P8_BUF;
+        const char* tA = buf + wr * TILE_BYTES;
+        const char* tB = buf + (2 + (wc >> 1)) * TILE_BYTES;
+        const int nb = (wc & 1) * 4;
+        // ---- p0
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb0[j][ks] = BT ? frag_t_raw(tB, nb + j, ks, lane) : frag_k(tB, nb + j, ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][ks] = AT ? frag_t_raw(tA, i, ks, lane) : frag_k(tA, i, ks, lane);
+        }
+        P8_ISSUE_A(obuf)
+        P8_PHASE(0, 0, fb0)
+        // ---- p1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb1[j][ks] = BT ? frag_t_raw(tB, nb + 2 + j, ks, lane) : frag_k(tB, nb + 2 + j, ks, lane);
+        }
+        P8_PHASE(0, 1, fb1)
+        // ---- p2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][ks] = AT ? frag_t_raw(tA, 4 + i, ks, lane) : frag_k(tA, 4 + i, ks, lane);
+        }
+        P8_PHASE(1, 1, fb1)
+        // ---- p3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed (this wave's pieces); read from the next phase on
+        P8_ISSUE_B(buf)
+        P8_PHASE(1, 0, fb0)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();           // balance the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may still target this block's LDS when it retires
+    gemm_epilogue(d, acc[0], m0 + wr * 128, n0 + wc * 64, z1, z2, ksplit, lane, 0, 0);
+    gemm_epilogue(d, acc[1], m0 + wr * 128 + 64, n0 + wc * 64, z1, z2, ksplit, lane, 0, 0);
+}
+#undef P8_PHASE
+#undef P8_ISSUE_A
+#undef P8_ISSUE_B
 
 __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
                                         int nslabs, int64_t stride) {
@@ -771,7 +918,26 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         // 256x128 tiles when the problem fills the chip with them (one 8-wave block per CU)
         const long long big_tiles = (long long)((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN) * zdim;
         const bool big = dma && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 512 && d.N >= 128 && d.K >= 192 && big_tiles >= 1000;
-        if (big) {
+        // 256x256 ping-pong tiles: opt-in (SCL_GEMM_FORCE_P8).  Measured on MI355X (tools/gemm_square.py, tools/gemm_p8_ab.py):
+        // 1093 / 1308 TFLOP/s at 4096^3 / 8192^3 (128x128 kernel: 811 / 1041), but on the encoder's M = 6368, K = 1024 shapes
+        // 400 tiles = 1.56 rounds of 256 CUs and a 16-step K loop leave it behind the 128x128 kernel (fc1 fwd 576 vs 694).
+        const long long p8_tiles = (long long)((d.M + P8_BM - 1) / P8_BM) * ((d.N + P8_BN - 1) / P8_BN) * zdim;
+        const bool p8 = dma && (d.flags & SCL_GEMM_FORCE_P8) && !(d.flags & SCL_GEMM_NO_P8);
+        if (p8) {
+            static bool p8_attr_set = false;
+            if (!p8_attr_set) {
+                hipFuncSetAttribute((const void*)scl_gemm_p8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_p8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_p8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_p8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+                p8_attr_set = true;
+            }
+            dim3 pgrid((unsigned)(p8_tiles / zdim), 1, (unsigned)zdim), pblock(512);
+            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<false, false>), pgrid, pblock, P8_LDS, s, k);
+            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<false, true>), pgrid, pblock, P8_LDS, s, k);
+            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<true, false>), pgrid, pblock, P8_LDS, s, k);
+            else hipLaunchKernelGGL((scl_gemm_p8_kernel<true, true>), pgrid, pblock, P8_LDS, s, k);
+        } else if (big) {
             static bool attr_set = false;
             if (!attr_set) {
                 hipFuncSetAttribute((const void*)scl_gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);

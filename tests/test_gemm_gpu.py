@@ -98,6 +98,31 @@ def test_big_tile_ring_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K):
     _close(outs[0], torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 8e-3, "big a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(5128, 1288, 264, 1), (6368, 1024, 1024, 1), (520, 776, 4096, 3), (256, 256, 64, 1), (1000, 3072, 512, 1)])
+def test_pingpong_256_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
+    """The opt-in 256x256 two-wave-group kernel (raw barriers, counted vmcnt, LDS-DMA in flight across ds_reads): same K order
+    per output element as the 128x128 kernels => bit-identical, on ragged M / N edges, with split-K slabs, repeated to give a
+    mis-ordered LDS read a chance to show."""
+    A = _rand((M, K), dev, 41, 0.3); B = _rand((N, K), dev, 42, 0.3)
+    opA = ops.Op(A.t().contiguous(), M) if a_t else ops.Op(A, K)
+    opB = ops.Op(B.t().contiguous(), N) if b_t else ops.Op(B, K)
+    outs = []
+    for kw in (dict(no_p8=True, no_big=True), dict(force_p8=True), dict(force_p8=True), dict(force_p8=True)):
+        if splitk > 1:
+            C = torch.full((splitk, M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N, **kw)
+        else:
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, act=2, **kw)
+        outs.append(C)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    ref = A.float() @ B.float().t()
+    got = outs[1].sum(0) if splitk > 1 else outs[1]
+    _close(got, ref if splitk > 1 else torch.relu(ref), 8e-3, "p8 a_t=%s b_t=%s" % (a_t, b_t))
+
+
 def test_kcontig_tail_needs_no_zero_padding(dev):
     # K = 199: the last 16-byte vector is partially valid; garbage (NaN) beyond K must be masked
     M, N, K = 70, 90, 199
