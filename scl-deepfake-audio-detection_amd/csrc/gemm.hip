@@ -541,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
 }
 
 
+// (A 128x128 / BK = 32 / 5-stage variant that doubles the bytes in flight per CU was measured 4-19 % SLOWER than the kernel
+// above on every encoder shape — the extra barrier per 16 MFMAs costs more than the deeper prefetch returns — and removed.)
+
 // ---- "big" variant: 256x128 tile, 8 waves, 3-stage LDS-DMA ring --------------------------------------
 // The 128x128 kernels above are latency-bound on the K loop (rocprofv3: 48 % of wave cycles in
 // s_waitcnt/barrier, MFMA pipe 22 % busy, ~3300 cycles per 64-deep K step with 64 KiB in flight per CU).
