@@ -126,9 +126,19 @@ int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, cons
                       const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
                       float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream);
 int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream);
+/* the same reduction spread over SCL_COLREDUCE_SEGMENTS x more blocks, finished in-launch by the last block of each 32-column group;
+ * scratch: f32 [SCL_COLREDUCE_SEGMENTS][C]; counters: as for scl_colsum_reduce (C <= 32 * SCL_COLSUM_MAX_GROUPS) */
+#define SCL_COLREDUCE_SEGMENTS 8
+#define SCL_COLSUM_MAX_GROUPS 64
+int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, float* scratch, int* counters,
+                          void* stream);
 /* bias gradients: part[p][n] = sum over row slab p of x[m][n]; nparts = scl_colsum_nparts(M) */
 int scl_colsum_nparts(int M);
 int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream);
+/* the same plus the final sum in one launch: out[n] = sum_m x[m][n] (the `.sum(0)` autograd runs for every nn.Linear / Conv1d bias,
+ * e.g. fairseq fc1/fc2/q,k,v,out_proj reached from model/xlsr.py:41).  `counters`: SCL_COLSUM_MAX_GROUPS int32, zero before the
+ * first use, left zero by every launch; launches sharing one counter array must be ordered on one stream. */
+int scl_colsum_reduce(const void* x, int x_f32, float* part, int* counters, float* out, int M, int N, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* element-wise glue                                                                           */

@@ -208,11 +208,61 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
-// column sums of a [M, N] matrix (bias gradients): part[rowchunk][n]
+// The same sum with the partial rows split over gridDim.y segments (8x the blocks of the kernel above, which is latency-bound
+// on 64 blocks): each block reduces its segment into scratch[seg][c]; the last block of a column group (ticket, agent-scope
+// release / acquire) adds the segments in order.  Deterministic; the counters return to zero.
+__global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
+                                                            int64_t pstride, int accumulate, float* __restrict__ scratch,
+                                                            int* __restrict__ counters) {
+    __shared__ float red[8][33];
+    __shared__ int last_flag;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int nseg = gridDim.y, seg = blockIdx.y;
+    const int per = (nparts + nseg - 1) / nseg;
+    const int p0 = seg * per, p1 = min(nparts, p0 + per);
+    float s = 0.f;
+    if (c < C)
+        for (int p = p0 + ty; p < p1; p += 8) s += part[(int64_t)p * pstride + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        scratch[(int64_t)seg * C + c] = t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int is_last = t == nseg - 1;
+        if (is_last) {
+            __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = is_last;
+    }
+    __syncthreads();
+    if (last_flag && ty == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < nseg; ++k) t += scratch[(int64_t)k * C + c];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// column sums of a [M, N] matrix (bias gradients): part[rowchunk][n].  With `out` != null the launch also finishes the sum:
+// every block publishes its partial row (agent-scope release) and draws a ticket of its column group; the block that draws
+// the last one acquires and adds the group's partials in row-chunk order (fixed order => deterministic), then re-arms the
+// counter.  That replaces a separate 10 us, 64-block reduce launch per bias gradient (108 per XLS-R train step).
 template <bool F32>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ part, int M, int N,
-                                                     int64_t ld, int rows_per_block) {
+                                                     int64_t ld, int rows_per_block, int* __restrict__ counters, float* __restrict__ out) {
     __shared__ float red[16][128 + 1];
+    __shared__ int last_flag;
     const int cg = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c0 = blockIdx.x * 128 + cg * 8;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -228,14 +278,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[ty][cg * 8 + i] = acc[i];
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int c = blockIdx.x * 128 + threadIdx.x;
-        if (c < N) {
-            float s = 0.f;
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (threadIdx.x < 128 && c < N) {
+        float s = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];
-            part[(int64_t)blockIdx.y * N + c] = s;
+        for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];
+        part[(int64_t)blockIdx.y * N + c] = s;
+    }
+    if (out == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int is_last = t == (int)gridDim.y - 1;
+        if (is_last) {
+            __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        last_flag = is_last;
+    }
+    __syncthreads();
+    if (last_flag && threadIdx.x < 128 && c < N) {
+        float s = 0.f;
+        for (int p = 0; p < (int)gridDim.y; ++p) s += part[(int64_t)p * N + c];
+        out[c] = s;
     }
 }
 
@@ -296,6 +365,16 @@ extern "C" int scl_colreduce_f32(const float* part, float* out, int nparts, int 
     return scl_check_launch("scl_colreduce_f32");
 }
 
+extern "C" int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, float* scratch,
+                                     int* counters, void* stream) {
+    SCL_REQUIRE(part && out && scratch && counters && nparts >= 1 && C >= 1, "colreduce_seg: bad args");
+    SCL_REQUIRE((C + 31) / 32 <= SCL_COLSUM_MAX_GROUPS, "colreduce_seg: C too large for the counter array (%d)", C);
+    const int nseg = nparts >= 64 ? SCL_COLREDUCE_SEGMENTS : 1;
+    hipLaunchKernelGGL(colreduce_seg_kernel, dim3((C + 31) / 32, nseg), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride,
+                       accumulate, scratch, counters);
+    return scl_check_launch("scl_colreduce_seg_f32");
+}
+
 extern "C" int scl_colsum_nparts(int M) {
     int rows_per_block = 256;
     while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
@@ -308,7 +387,19 @@ extern "C" int scl_colsum(const void* x, int x_f32, float* part, int M, int N, i
     while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
     dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block);
-    else hipLaunchKernelGGL((colsum_kernel<false>), grid, block, 0, s, x, part, M, N, ld, rows_per_block);
+    if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, (int*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((colsum_kernel<false>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, (int*)nullptr, (float*)nullptr);
     return scl_check_launch("scl_colsum");
+}
+
+extern "C" int scl_colsum_reduce(const void* x, int x_f32, float* part, int* counters, float* out, int M, int N, int64_t ld, void* stream) {
+    SCL_REQUIRE(x && part && counters && out && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum_reduce: bad args (N, ld multiples of 8)");
+    SCL_REQUIRE((N + 127) / 128 <= SCL_COLSUM_MAX_GROUPS, "colsum_reduce: N too large for the counter array (%d)", N);
+    int rows_per_block = 256;
+    while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, counters, out);
+    else hipLaunchKernelGGL((colsum_kernel<false>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, counters, out);
+    return scl_check_launch("scl_colsum_reduce");
 }

@@ -208,15 +208,13 @@ class Encoder:
         ops.reduce_slabs(d["slab"], out, n, sk, n)
 
     def _bias_grad(self, d, dy, Mrows, N, gname):
-        n = ops.colsum_nparts(Mrows)
-        ops.colsum(dy, d["cs_part"], Mrows, N)
-        ops.colreduce(d["cs_part"], self.P.g(self.n(gname)), n, N)
+        ops.colsum_reduce(dy, d["cs_part"], self.P.g(self.n(gname)), Mrows, N)
 
     def _ln_grads(self, d, nparts, C, wname, bname):
         """weight and bias of a LayerNorm are adjacent in the flat buffer: one reduction over the (dgamma | dbeta) partials."""
         ow, ob = self.P.off(self.n(wname)), self.P.off(self.n(bname))
         assert ob == ow + C
-        ops.colreduce(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
+        ops.colreduce_seg(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, x, training=True, refresh=True):
@@ -341,8 +339,7 @@ class Encoder:
                          c_bs1=T * 3 * E, c_bs2=D, c_offset=0, **bq)                                   # dQ = s dS K
                 ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=0), dqkv, T, D, T, a_t=True, b_t=True, alpha=sc, ldc=3 * E,
                          c_bs1=T * 3 * E, c_bs2=D, c_offset=E, **bq)                                   # dK = s dS^T Q
-            ops.colsum(dqkv, d["cs_part"], M, 3 * E)
-            ops.colreduce(d["cs_part"], self._qkv_view(pn, "bias"), ops.colsum_nparts(M), 3 * E)
+            ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
             self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
@@ -354,9 +351,7 @@ class Encoder:
         # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
         pb = K // 2 - 1
         ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)
-        n_cs = ops.colsum_nparts(B * (T + K))
-        ops.colsum(d["dcpad"], d["cs_part"], B * (T + K), E)
-        ops.colreduce(d["cs_part"], P.g(self.n("encoder.pos_conv.0.bias")), n_cs, E)
+        ops.colsum_reduce(d["dcpad"], d["cs_part"], P.g(self.n("encoder.pos_conv.0.bias")), B * (T + K), E)
         dwf = d["dwf"]
         self._wgrad(d, Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=pb * E),
                     Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), dwf, Cg, K * Cg, M,

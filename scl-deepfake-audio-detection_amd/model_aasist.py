@@ -163,8 +163,7 @@ class Model(nn.Module):
             ops.start_recording()
         M = sv["B"] * st["T"]
         ops.cast_bf16(st["d_feats"], st["dfe_bf"], M * FEAT_DIM)
-        ops.colsum(st["d_feats"], st["cs"], M, FEAT_DIM)
-        ops.colreduce(st["cs"], P.g("LL.bias"), ops.colsum_nparts(M), FEAT_DIM)
+        ops.colsum_reduce(st["d_feats"], st["cs"], P.g("LL.bias"), M, FEAT_DIM)
         self.ssl._wgrad(sv["ectx"]["d"], Op(st["dfe_bf"], FEAT_DIM), Op(sv["enc_out"], E), P.g("LL.weight"), FEAT_DIM, E, M)
         ops.gemm(Op(st["dfe_bf"], FEAT_DIM), Op(P.bf16, E, offset=P.off("LL.weight")), st["denc"], M, E, FEAT_DIM, b_t=True)
         if self.grad_sync is not None:     # LL and the torch head's gradients (the END of the flat buffer) are final here

@@ -240,13 +240,11 @@ class Model(nn.Module):
         ops.utt_head_bwd(st["d_logp"], sv["logp"], sv["emb"], P.f32("backend.m_utt_level.weight"), st["d_emb"], hb["demb"],
                          P.g("backend.m_utt_level.weight"), P.g("backend.m_utt_level.bias"), hb["ws"], B, HEAD_DIM, N_CLASS)
         mp_entry = ops.meanpool_bwd(hb["demb"], hb["pre"][2], hb["dpre"][2], B, T, HEAD_DIM, ACT_LEAKY, sv["drop"], seeds[2])
-        ncs = ops.colsum_nparts(M)
         drop_descs = []
         for j, idx in reversed(list(enumerate((0, 3, 6)))):
             dpre = hb["dpre"][j]
             inp = hb["h"][j - 1] if j > 0 else hb["r0"]
-            ops.colsum(dpre, hb["cs"], M, HEAD_DIM)
-            ops.colreduce(hb["cs"], P.g("backend.m_frame_level.%d.bias" % idx), ncs, HEAD_DIM)
+            ops.colsum_reduce(dpre, hb["cs"], P.g("backend.m_frame_level.%d.bias" % idx), M, HEAD_DIM)
             self.encoder._wgrad(sv["ectx"]["d"], Op(dpre, HEAD_DIM), Op(inp, HEAD_DIM), P.g("backend.m_frame_level.%d.weight" % idx),
                                 HEAD_DIM, HEAD_DIM, M)
             wj = W("backend.m_frame_level.%d.weight" % idx, HEAD_DIM)
@@ -257,8 +255,7 @@ class Model(nn.Module):
                 ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dfe"], M, HEAD_DIM, HEAD_DIM, b_t=True, R=sv["feats"], rmode=2, ract=ACT_RELU)
         # total gradient at feats = ReLU path + SupCon path
         ops.add_f32(hb["dfe"], st["d_feats"], hb["dfe"], hb["dfe_bf"], M * HEAD_DIM)
-        ops.colsum(hb["dfe"], hb["cs"], M, HEAD_DIM)
-        ops.colreduce(hb["cs"], P.g("LL.bias"), ncs, HEAD_DIM)
+        ops.colsum_reduce(hb["dfe"], hb["cs"], P.g("LL.bias"), M, HEAD_DIM)
         self.encoder._wgrad(sv["ectx"]["d"], Op(hb["dfe_bf"], HEAD_DIM), Op(sv["enc_out"], E), P.g("LL.weight"), HEAD_DIM, E, M)
         if not self.flag_fix_ssl:
             ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)

@@ -181,6 +181,35 @@ def colsum(x, part, M, N, ld=None):
     _call("scl_colsum", _p(x), _isf32(x), _p(part), M, N, ld or N, _stream())
 
 
+_COUNTERS = {}
+
+
+def _counters(device):
+    """Ticket counters of the self-finishing reductions (zero between launches; one array per device, launches are stream-ordered)."""
+    key = (device.type, device.index)
+    if key not in _COUNTERS:
+        _COUNTERS[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return _COUNTERS[key]
+
+
+_SCRATCH = {}
+
+
+def colreduce_seg(part, out, nparts, C, pstride=None, accumulate=False):
+    """colreduce over 8x more blocks, finished in-launch (LayerNorm parameter gradients: 768 partial rows x 2C)."""
+    key = (part.device.type, part.device.index)
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.empty(8 * 2048, dtype=torch.float32, device=part.device)
+    assert C <= 2048
+    _call("scl_colreduce_seg_f32", _p(part), _p(out), nparts, C, pstride or C, 1 if accumulate else 0, _p(_SCRATCH[key]),
+          _p(_counters(part.device)), _stream())
+
+
+def colsum_reduce(x, part, out, M, N, ld=None):
+    """out[n] = sum_m x[m][n] in one launch (part: f32 [colsum_nparts(M), N] scratch)."""
+    _call("scl_colsum_reduce", _p(x), _isf32(x), _p(part), _p(_counters(x.device)), _p(out), M, N, ld or N, _stream())
+
+
 def cast_bf16(src, dst, n=None):
     _call("scl_cast_f32_bf16", _p(src), _p(dst), n or src.numel(), _stream())
 

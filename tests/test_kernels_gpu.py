@@ -84,6 +84,38 @@ def test_colsum_and_cast_and_add(dev):
     assert torch.equal(o, a + b) and torch.equal(ob, (a + b).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,N", [(1000, 264), (6368, 4096), (300, 8), (70000, 512)])
+def test_self_finishing_reductions(dev, M, N):
+    """colsum_reduce / colreduce_seg finish their sum inside the launch (ticket + agent-scope release/acquire): same numbers as
+    the two-launch path bit for bit, repeatable (the counters re-arm themselves), deterministic."""
+    x = torch.randn(M, N, generator=g(5)).to(dev).to(torch.bfloat16)
+    n = ops.colsum_nparts(M)
+    part = torch.empty(n, N, device=dev); ref = torch.empty(N, device=dev)
+    ops.colsum(x, part, M, N)
+    ops.colreduce(part, ref, n, N)
+    for _ in range(4):
+        part2 = torch.full((n, N), float("nan"), device=dev); out = torch.full((N,), float("nan"), device=dev)
+        ops.colsum_reduce(x, part2, out, M, N)
+        assert torch.equal(part2, part)
+        assert rel(out, x.float().sum(0)) < 1e-5
+        first = out.clone() if _ == 0 else first
+        assert torch.equal(out, first)
+    # LayerNorm-style partial rows [nparts, C]
+    nparts, C = 768, min(N, 2048)
+    pr = torch.randn(nparts, C, generator=g(6)).to(dev)
+    want = torch.empty(C, device=dev)
+    ops.colreduce(pr, want, nparts, C)
+    for _ in range(3):
+        got = torch.full((C,), float("nan"), device=dev)
+        ops.colreduce_seg(pr, got, nparts, C)
+        assert rel(got, pr.double().sum(0).float()) < 1e-5 and rel(got, want) < 1e-5
+    ops.colreduce_seg(pr, got, nparts, C, accumulate=True)
+    assert rel(got, 2 * pr.double().sum(0).float()) < 1e-5
+    small = torch.randn(5, C, generator=g(7)).to(dev)           # fewer than 64 partial rows: single segment
+    ops.colreduce_seg(small, got, 5, C)
+    assert rel(got, small.sum(0)) < 1e-5
+
+
 def test_pad_rows_col2im_weight_packs(dev):
     B, T, C = 3, 21, 32
     x = torch.randn(B, T, C, generator=g(1)).to(dev)
