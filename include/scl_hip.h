@@ -181,12 +181,14 @@ int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
 /* ------------------------------------------------------------------------------------------ */
 /* feature-extractor layer 0 (Conv1d(1,C,10,5) + LayerNorm + GELU), fused fwd / bwd            */
 /* ------------------------------------------------------------------------------------------ */
-int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, void* z,
+/* stats (optional, may be NULL): f32 [B*T0][2] = per-frame (mean, rstd) of the LayerNorm, written by the forward and read
+ * back by the backward instead of being recomputed */
+int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, void* z, float* stats,
                   int B, int L, int C, int k, int stride, float eps, void* stream);
 int scl_conv0_bwd_nparts(int B, int L, int k, int stride);
 int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const void* dz,
-                  float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L, int C, int k, int stride,
-                  float eps, void* stream);
+                  const float* stats, float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L, int C, int k,
+                  int stride, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */

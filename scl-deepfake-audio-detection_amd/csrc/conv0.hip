@@ -30,8 +30,8 @@ __device__ __forceinline__ void conv0_stage(float* wT, float* xs, const float* _
 
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* __restrict__ z, int L, int T0,
-                                                        int C, int k, int stride, int rows_per_block, float eps) {
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ z, float* __restrict__ stats,
+                                                        int L, int T0, int C, int k, int stride, int rows_per_block, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm0[];
     float* wT = sm0;
     float* xs = sm0 + k * C;
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             }
         }
         const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (stats && lane == 0) {
+            stats[2 * ((int64_t)b * T0 + t0 + r)] = mean;
+            stats[2 * ((int64_t)b * T0 + t0 + r) + 1] = rstd;
+        }
 #pragma unroll
         for (int ch = 0; ch < MAXCH0; ++ch) {
             const int c = ch * 512 + lane * 8;
@@ -89,68 +93,84 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 }
 
 // part[blk][c*(k+3) + q]: q < k -> dW[c][q]; q == k -> dbias; k+1 -> dgamma; k+2 -> dbeta
-__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const bf16_t* __restrict__ dz,
-                                                        float* __restrict__ part, int L, int T0, int C, int k, int stride,
-                                                        int rows_per_block, float eps) {
+// STATS: the forward's per-frame (mean, rstd) are read back (8 B per frame) instead of being recomputed with two more
+// wave reductions; the 4-wave combine buffer re-uses the tap / waveform LDS once the frame loop is done (30 KiB per block
+// instead of 57 KiB; the 104 accumulators per lane keep it at 2 waves per SIMD).
+// KT: compile-time bound of the tap loops (10 for wav2vec2's layer 0: exactly 13 accumulators per channel; 16 = generic)
+template <bool STATS, int KT>
+__global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const bf16_t* __restrict__ dz,
+                                                           const float* __restrict__ stats, float* __restrict__ part, int L, int T0, int C,
+                                                           int k, int stride, int rows_per_block, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm0[];
     float* wT = sm0;
-    float* red = sm0 + k * C;
-    float* xs = red + C * (k + 3);
+    float* xs = sm0 + k * C;
+    float* red = sm0;                 // valid only after the frame loop (barrier below)
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * rows_per_block;
     const int nrows = min(rows_per_block, T0 - t0);
     const int nx = nrows * stride + k;
     conv0_stage(wT, xs, w, x + (int64_t)b * L, C, k, L, t0 * stride, nx);
-    for (int i = threadIdx.x; i < C * (k + 3); i += blockDim.x) red[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float aw[8][MAXK + 3];
-    if (C > 512) return;  // backward supports C <= 512 (one chunk of 8 channels per lane)
+    float aw[8][KT + 3];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int q = 0; q < MAXK + 3; ++q) aw[i][q] = 0.f;
+        for (int q = 0; q < KT + 3; ++q) aw[i][q] = 0.f;
     const int c = lane * 8;
     const bool act = c < C;
     for (int r = wv; r < nrows; r += 4) {
-        float y[8], g8[8], dzv[8];
-        float s = 0.f;
+        float y[8], g8[8], dzv[8], xr[KT];
+        const int64_t row = (int64_t)b * T0 + t0 + r;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) xr[j] = j < k ? xs[r * stride + j] : 0.f;
         if (act) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = bias[c + i];
-            for (int j = 0; j < k; ++j) {
-                const float xv = xs[r * stride + j];
-                const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
-                const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
-                y[0] += w0.x * xv; y[1] += w0.y * xv; y[2] += w0.z * xv; y[3] += w0.w * xv;
-                y[4] += w1.x * xv; y[5] += w1.y * xv; y[6] += w1.z * xv; y[7] += w1.w * xv;
-            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += y[i];
-            const uint4 u = *reinterpret_cast<const uint4*>(dz + ((int64_t)b * T0 + t0 + r) * C + c);
+            for (int j = 0; j < KT; ++j) {
+                if (j < k) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
+                    y[0] += w0.x * xr[j]; y[1] += w0.y * xr[j]; y[2] += w0.z * xr[j]; y[3] += w0.w * xr[j];
+                    y[4] += w1.x * xr[j]; y[5] += w1.y * xr[j]; y[6] += w1.z * xr[j]; y[7] += w1.w * xr[j];
+                }
+            }
+            const uint4 u = *reinterpret_cast<const uint4*>(dz + row * C + c);
             const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dzv[2 * i] = __uint_as_float(uw[i] << 16); dzv[2 * i + 1] = __uint_as_float(uw[i] & 0xFFFF0000u); }
-        }
-        const float mean = wave_sum(s) / (float)C;
-        float q = 0.f;
-        if (act) {
+        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float d = y[i] - mean; q += d * d; }
+            for (int i = 0; i < 8; ++i) { y[i] = 0.f; dzv[i] = 0.f; }
         }
-        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float mean, rstd;
+        if (STATS) {
+            mean = stats[2 * row]; rstd = stats[2 * row + 1];
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += y[i];
+            mean = wave_sum(s) / (float)C;
+            float q = 0.f;
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float dd = y[i] - mean; q += dd * dd; }
+            }
+            rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        }
         float s1 = 0.f, s2 = 0.f;
         if (act) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float h = (y[i] - mean) * rstd;
-                const float gm = gamma[c + i];
-                const float dyn = dzv[i] * gelu_grad_f(h * gm + beta[c + i]);
-                aw[i][MAXK + 1] += dyn * h;  // dgamma
-                aw[i][MAXK + 2] += dyn;      // dbeta
-                const float dh = dyn * gm;
+                const float gmi = gamma[c + i];
+                const float dyn = dzv[i] * gelu_grad_f(h * gmi + beta[c + i]);
+                aw[i][KT + 1] += dyn * h;  // dgamma
+                aw[i][KT + 2] += dyn;      // dbeta
+                const float dh = dyn * gmi;
                 y[i] = h;      // xhat
                 g8[i] = dh;    // dxhat
                 s1 += dh; s2 += dh * h;
@@ -162,24 +182,27 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float dy = rstd * (g8[i] - s1 - y[i] * s2);
-                aw[i][MAXK] += dy;  // dbias
+                aw[i][KT] += dy;  // dbias
 #pragma unroll
-                for (int j = 0; j < MAXK; ++j)
-                    if (j < k) aw[i][j] += dy * xs[r * stride + j];
+                for (int j = 0; j < KT; ++j)
+                    if (j < k) aw[i][j] += dy * xr[j];
             }
         }
     }
+    __syncthreads();   // every wave is done with wT / xs: the combine buffer takes their place
+    for (int i = threadIdx.x; i < C * (k + 3); i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
     // deterministic combine of the 4 waves
     for (int ww = 0; ww < 4; ++ww) {
         if (wv == ww && act) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int j = 0; j < MAXK; ++j)
+                for (int j = 0; j < KT; ++j)
                     if (j < k) red[(c + i) * (k + 3) + j] += aw[i][j];
-                red[(c + i) * (k + 3) + k] += aw[i][MAXK];
-                red[(c + i) * (k + 3) + k + 1] += aw[i][MAXK + 1];
-                red[(c + i) * (k + 3) + k + 2] += aw[i][MAXK + 2];
+                red[(c + i) * (k + 3) + k] += aw[i][KT];
+                red[(c + i) * (k + 3) + k + 1] += aw[i][KT + 1];
+                red[(c + i) * (k + 3) + k + 2] += aw[i][KT + 2];
             }
         }
         __syncthreads();
@@ -204,36 +227,49 @@ __global__ void conv0_reduce_kernel(const float* __restrict__ part, int nparts, 
 
 }  // namespace
 
-static const int CONV0_BWD_ROWS = 512;
+// frames per backward block: ~512 blocks in all (2 resident blocks x 256 CUs), 64 <= rows <= 1024
+static int conv0_bwd_rows(int B, int T0) {
+    int chunks = 512 / (B > 0 ? B : 1); if (chunks < 1) chunks = 1;
+    int rows = (T0 + chunks - 1) / chunks;
+    if (rows < 64) rows = 64;
+    if (rows > 1024) rows = 1024;
+    return rows;
+}
 
 extern "C" int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                             void* z, int B, int L, int C, int k, int stride, float eps, void* stream) {
+                             void* z, float* stats, int B, int L, int C, int k, int stride, float eps, void* stream) {
     SCL_REQUIRE(x && w && bias && gamma && beta && z, "conv0_fwd: null pointer");
     SCL_REQUIRE(B > 0 && L >= k && C >= 8 && C <= 1024 && (C & 7) == 0 && k >= 1 && k <= MAXK && stride >= 1, "conv0_fwd: bad dims");
     const int T0 = (L - k) / stride + 1;
     const int rows = 128;
     dim3 grid((T0 + rows - 1) / rows, B), block(256);
     const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
-    hipLaunchKernelGGL(conv0_fwd_kernel, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (bf16_t*)z, L, T0, C, k, stride, rows, eps);
+    hipLaunchKernelGGL(conv0_fwd_kernel, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (bf16_t*)z, stats, L, T0, C, k, stride, rows, eps);
     return scl_check_launch("scl_conv0_fwd");
 }
 
 extern "C" int scl_conv0_bwd_nparts(int B, int L, int k, int stride) {
     const int T0 = (L - k) / stride + 1;
-    return B * ((T0 + CONV0_BWD_ROWS - 1) / CONV0_BWD_ROWS);
+    const int rows = conv0_bwd_rows(B, T0);
+    return B * ((T0 + rows - 1) / rows);
 }
 
 extern "C" int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                             const void* dz, float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L,
-                             int C, int k, int stride, float eps, void* stream) {
+                             const void* dz, const float* stats, float* part_ws, float* dW, float* db, float* dgamma, float* dbeta,
+                             int B, int L, int C, int k, int stride, float eps, void* stream) {
     SCL_REQUIRE(x && w && bias && gamma && beta && dz && part_ws && dW && db && dgamma && dbeta, "conv0_bwd: null pointer");
     SCL_REQUIRE(B > 0 && L >= k && C >= 8 && C <= 512 && (C & 7) == 0 && k >= 1 && k <= MAXK && stride >= 1, "conv0_bwd: bad dims (C <= 512)");
     const int T0 = (L - k) / stride + 1;
-    const int rows = CONV0_BWD_ROWS;
+    const int rows = conv0_bwd_rows(B, T0);
     dim3 grid((T0 + rows - 1) / rows, B), block(256);
-    const size_t lds = (size_t)(k * C + C * (k + 3) + rows * stride + k) * sizeof(float);
+    const size_t a = (size_t)(k * C + rows * stride + k), r = (size_t)C * (k + 3);
+    const size_t lds = (a > r ? a : r) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv0_bwd_kernel, grid, block, lds, s, x, w, bias, gamma, beta, (const bf16_t*)dz, part_ws, L, T0, C, k, stride, rows, eps);
+#define CONV0_BWD(ST, KT) hipLaunchKernelGGL((conv0_bwd_kernel<ST, KT>), grid, block, lds, s, x, w, bias, gamma, beta, (const bf16_t*)dz, stats, \
+                                             part_ws, L, T0, C, k, stride, rows, eps)
+    if (k <= 10) { if (stats) CONV0_BWD(true, 10); else CONV0_BWD(false, 10); }
+    else { if (stats) CONV0_BWD(true, MAXK); else CONV0_BWD(false, MAXK); }
+#undef CONV0_BWD
     const int nparts = grid.x * grid.y, n = C * (k + 3);
     hipLaunchKernelGGL(conv0_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part_ws, nparts, C, k, dW, db, dgamma, dbeta);
     return scl_check_launch("scl_conv0_bwd");

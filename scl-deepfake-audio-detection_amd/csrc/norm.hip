@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 
 // The same sum with the partial rows split over gridDim.y segments (8x the blocks of the kernel above, which is latency-bound
 // on 64 blocks): each block reduces its segment into scratch[seg][c]; the last block of a column group (ticket, agent-scope
-// release / acquire) adds the segments in order.  Deterministic; the counters return to zero.
+// sc1 write-through hand-off) adds the segments in order.  Deterministic; the counters return to zero.
 __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
                                                             int64_t pstride, int accumulate, float* __restrict__ scratch,
                                                             int* __restrict__ counters) {
@@ -230,33 +230,28 @@ __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][tx];
-        scratch[(int64_t)seg * C + c] = t;
+        __hip_atomic_store(&scratch[(int64_t)seg * C + c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int is_last = t == nseg - 1;
-        if (is_last) {
-            __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (is_last) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = is_last;
     }
     __syncthreads();
     if (last_flag && ty == 0 && c < C) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float t = 0.f;
-        for (int k = 0; k < nseg; ++k) t += scratch[(int64_t)k * C + c];
+        for (int k = 0; k < nseg; ++k) t += __hip_atomic_load(&scratch[(int64_t)k * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out[c] = accumulate ? out[c] + t : t;
     }
 }
 
 // column sums of a [M, N] matrix (bias gradients): part[rowchunk][n].  With `out` != null the launch also finishes the sum:
-// every block publishes its partial row (agent-scope release) and draws a ticket of its column group; the block that draws
-// the last one acquires and adds the group's partials in row-chunk order (fixed order => deterministic), then re-arms the
+// every block stores its partial row write-through (sc1), drains, and draws a ticket of its column group; the block that
+// draws the last one adds the group's partials (sc1 loads) in row-chunk order (fixed order => deterministic) and re-arms the
 // counter.  That replaces a separate 10 us, 64-block reduce launch per bias gradient (108 per XLS-R train step).
 template <bool F32>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ part, int M, int N,
@@ -283,28 +278,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];
-        part[(int64_t)blockIdx.y * N + c] = s;
+        // self-finishing launches hand the partials over write-through (sc1): no agent-scope release fence, i.e. no L2
+        // write-back per block (with the fence every block paid ~10 us under load: measured, rocprofv3)
+        if (out) __hip_atomic_store(&part[(int64_t)blockIdx.y * N + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else part[(int64_t)blockIdx.y * N + c] = s;
     }
     if (out == nullptr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int is_last = t == (int)gridDim.y - 1;
-        if (is_last) {
-            __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (is_last) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         last_flag = is_last;
     }
     __syncthreads();
-    if (last_flag && threadIdx.x < 128 && c < N) {
+    if (last_flag) {    // block-uniform
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler ordering only; every load below is sc1 (bypasses this CU's L1)
+        // even / odd row chunks on the two thread halves, 8 loads in flight per thread, fixed association => deterministic
+        const int cc = threadIdx.x & 127, half = threadIdx.x >> 7, ny = gridDim.y;
+        const int col = blockIdx.x * 128 + cc;
         float s = 0.f;
-        for (int p = 0; p < (int)gridDim.y; ++p) s += part[(int64_t)p * N + c];
-        out[c] = s;
+        if (col < N) {
+            for (int p0 = half; p0 < ny; p0 += 16) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = p0 + 2 * j;
+                    v[j] = p < ny ? __hip_atomic_load(&part[(int64_t)p * N + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+        }
+        float* flat = &red[0][0];
+        flat[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 128 && col < N) out[col] = flat[threadIdx.x] + flat[threadIdx.x + 128];
     }
 }
 

@@ -186,6 +186,7 @@ class Encoder:
         ncs = max(ops.colsum_nparts(B * max(Ts[1:] + [T + K])), 1)
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
         d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
+        d["conv0_stats"] = f32(B * Ts[0] * 2)   # per-frame (mean, rstd) of layer 0's LayerNorm
         d["slab"] = None  # split-K slabs, sized on first use
         d["dwk"] = f32(C * kmax * C)
         d["dwf"] = f32(E * (E // cfg.pos_groups) * K)
@@ -230,7 +231,7 @@ class Encoder:
         fe = "feature_extractor.conv_layers.%d."
         # -- conv stack (M1)
         ops.conv0_fwd(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"),
-                      self.b(fe % 0 + "2.1.bias"), d["z"][0], B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0])
+                      self.b(fe % 0 + "2.1.bias"), d["z"][0], B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0], stats=d["conv0_stats"])
         for i in range(1, len(Ts)):
             k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
             ops.gemm(Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), Op(self.wk[i], k * C), d["y"][i], B * Tout, C, k * C,
@@ -387,7 +388,7 @@ class Encoder:
         ops.conv0_bwd(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"),
                       self.b(fe % 0 + "2.1.bias"), d["dz"][0], d["conv0_ws"], P.g(self.n(fe % 0 + "0.weight")),
                       P.g(self.n(fe % 0 + "0.bias")), P.g(self.n(fe % 0 + "2.1.weight")), P.g(self.n(fe % 0 + "2.1.bias")),
-                      B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0])
+                      B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0], stats=d["conv0_stats"])
 
     def _qkv_view(self, pn, kind):
         """q/k/v gradients are adjacent in the flat buffer: one [3E, E] wgrad / [3E] bias-grad output."""

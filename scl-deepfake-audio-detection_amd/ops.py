@@ -41,7 +41,12 @@ def replay(plan):
 
 def host_callback(fn, *args):
     """Run a Python callback now and, when recording, at the same position of every replay (DP bucket launches)."""
-    fn(*args)
+    global _REC
+    rec, _REC = _REC, None          # C-ABI calls the callback makes itself (optimizer slices) belong to the callback, not to the plan
+    try:
+        fn(*args)
+    finally:
+        _REC = rec
     if _REC is not None:
         def _cb(*a, _fn=fn):
             _fn(*a)
@@ -275,16 +280,16 @@ def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale):
     _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, T, H, D, scale, _stream())
 
 
-def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5):
-    _call("scl_conv0_fwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), B, Lx, C, k, stride, eps, _stream())
+def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5, stats=None):
+    _call("scl_conv0_fwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), _p(stats), B, Lx, C, k, stride, eps, _stream())
 
 
 def conv0_bwd_nparts(B, Lx, k, stride):
     return L.load().scl_conv0_bwd_nparts(B, Lx, k, stride)
 
 
-def conv0_bwd(x, w, b, gamma, beta, dz, part_ws, dW, db, dgamma, dbeta, B, Lx, C, k, stride, eps=1e-5):
-    _call("scl_conv0_bwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(dz), _p(part_ws), _p(dW), _p(db), _p(dgamma),
+def conv0_bwd(x, w, b, gamma, beta, dz, part_ws, dW, db, dgamma, dbeta, B, Lx, C, k, stride, eps=1e-5, stats=None):
+    _call("scl_conv0_bwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(dz), _p(stats), _p(part_ws), _p(dW), _p(db), _p(dgamma),
                                    _p(dbeta), B, Lx, C, k, stride, eps, _stream())
 
 

@@ -110,7 +110,7 @@ def test_train_step_gradients_and_update(dev):
     train_names = [n for n, _, tr in W.param_shapes(cfg) if tr]
     for n in train_names:
         ref.ssl[n].requires_grad_(True)
-    opt = FusedAdamW(m, lr=1e-4, weight_decay=1e-4)
+    opt = FusedAdamW(m, lr=1e-4, weight_decay=1e-4, overlap=False)   # two backward passes are inspected before the step
     out, feats, hid = m(x.to(dev))
     losses = m.loss(out, feats, hid, y.to(dev), CONF)
     opt.zero_grad()

@@ -216,8 +216,8 @@ def test_softmax_fwd_bwd(dev):
     assert rel(dS[:, :T], refd) < 8e-3 and (dS[:, T:] == 0).all()
 
 
-@pytest.mark.parametrize("C,L,B", [(512, 16000, 2), (32, 4000, 3)])
-def test_conv0_fwd_bwd(dev, C, L, B):
+@pytest.mark.parametrize("C,L,B,saved", [(512, 16000, 2, True), (32, 4000, 3, False), (512, 64000, 3, True), (64, 2000, 40, False)])
+def test_conv0_fwd_bwd(dev, C, L, B, saved):
     k, s = 10, 5
     x = (0.5 * torch.randn(B, L, generator=g(1))).to(dev)
     w = (torch.randn(C, 1, k, generator=g(2)) * (2.0 / k) ** 0.5).to(dev)
@@ -225,7 +225,8 @@ def test_conv0_fwd_bwd(dev, C, L, B):
     gamma = (1 + 0.1 * torch.randn(C, generator=g(4))).to(dev); beta = (0.1 * torch.randn(C, generator=g(5))).to(dev)
     T0 = (L - k) // s + 1
     z = torch.empty(B, T0, C, dtype=torch.bfloat16, device=dev)
-    ops.conv0_fwd(x, w, b, gamma, beta, z, B, L, C, k, s)
+    stats = torch.full((B * T0, 2), float("nan"), device=dev) if saved else None   # forward LayerNorm (mean, rstd) kept for the backward
+    ops.conv0_fwd(x, w, b, gamma, beta, z, B, L, C, k, s, stats=stats)
     wr, br_, gr, ber = (t.clone().requires_grad_(True) for t in (w, b, gamma, beta))
     ref = F.gelu(F.layer_norm(F.conv1d(x[:, None], wr, br_, stride=s).transpose(1, 2), (C,), gr, ber, 1e-5))
     assert rel(z, ref) < 8e-3
@@ -234,7 +235,10 @@ def test_conv0_fwd_bwd(dev, C, L, B):
     nparts = ops.conv0_bwd_nparts(B, L, k, s)
     ws = torch.empty(nparts * C * (k + 3), device=dev)
     dW = torch.empty(C, 1, k, device=dev); db = torch.empty(C, device=dev); dg = torch.empty(C, device=dev); dbe = torch.empty(C, device=dev)
-    ops.conv0_bwd(x, w, b, gamma, beta, dz, ws, dW, db, dg, dbe, B, L, C, k, s)
+    ops.conv0_bwd(x, w, b, gamma, beta, dz, ws, dW, db, dg, dbe, B, L, C, k, s, stats=stats)
+    if saved:
+        y = F.conv1d(x[:, None], w, b, stride=s).transpose(1, 2).reshape(B * T0, C)
+        assert rel(stats[:, 0], y.mean(1)) < 1e-4 and rel(stats[:, 1], (y.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
     assert rel(dW, wr.grad) < 2e-4 and rel(db, br_.grad) < 2e-4 and rel(dg, gr.grad) < 2e-4 and rel(dbe, ber.grad) < 2e-4
 
 
