@@ -12,6 +12,8 @@ same flat fp32 buffer, so the fused AdamW kernel and the data-parallel gradient 
 The reference's train-mode forward returns a 2-tuple while main.py:63 unpacks three values: this plugin
 returns the triple main.py and Model.loss need — feats is the LL output, exactly what the linear plugin hands to SupCon.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -38,6 +40,21 @@ class _FrontFn(torch.autograd.Function):
     def backward(ctx, d_feats):
         ctx.model._front_backward(ctx.saved, d_feats)
         return None, None, None
+
+
+class _HeadRunner(nn.Module):
+    """The graph back-end's sub-modules and parameters (shared objects, not copies) under one nn.Module: the unit that
+    torch.cuda.make_graphed_callables captures into a forward and a backward hipGraph."""
+
+    def __init__(self, owner):
+        super().__init__()
+        for n in owner._head_children:
+            self.add_module(n, owner._modules[n])
+        for n in ("pos_S", "master1", "master2"):
+            self.register_parameter(n, owner._parameters[n])
+
+    def forward(self, feats):
+        return AasistHead.forward(self, feats)
 
 
 class Model(nn.Module):
@@ -68,6 +85,7 @@ class Model(nn.Module):
         # graft the head's sub-modules at the root (reference state-dict names: encoder.0.0.conv1.weight, GAT_layer_S.…) and
         # swap every head parameter for its flat-buffer view
         head.to(self.device)
+        self._head_children = [n for n, _ in head.named_children()]
         for n, child in head.named_children():
             self.add_module(n, child)
         for name, p in self.P.params.items():
@@ -85,6 +103,10 @@ class Model(nn.Module):
         self._states = {}
         self.out_dim = self.cfg.embed
         self.grad_sync = None
+        # the back-end is ~450 small torch launches per step (host-bound): in training it is replayed as two hipGraphs per
+        # feature shape (forward, backward); SCL_AASIST_GRAPH=0 keeps it eager
+        self.use_graphs = os.environ.get("SCL_AASIST_GRAPH", "1") != "0"
+        self.__dict__["_graphed"] = {}
 
     # nn.Module plumbing ----------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):
@@ -181,10 +203,43 @@ class Model(nn.Module):
             feats = _FrontFn.apply(self, x, self._anchor)
         else:
             feats = self._front_forward(x)[0].clone()
-        output, last_hidden = AasistHead.forward(self, feats)
+        output, last_hidden = self._head(feats)
         if self.is_train:
             return output, feats, last_hidden
         return output
+
+    def _head(self, feats):
+        if not (self.use_graphs and self.training and torch.is_grad_enabled() and feats.requires_grad):
+            return AasistHead.forward(self, feats)
+        key = tuple(feats.shape)
+        runner = self._graphed.get(key)
+        if runner is None:
+            runner = self._capture_head(feats)
+            self._graphed[key] = runner
+        if runner is False:          # capture failed once for this shape: stay eager
+            return AasistHead.forward(self, feats)
+        out, hid = runner(feats)          # static graph outputs: hand out copies, successive calls must not alias
+        return out.clone(), hid.clone()
+
+    def _capture_head(self, feats):
+        """Warm-up + capture (torch runs the callable a few times on a side stream): BatchNorm running statistics and the RNG
+        offset it consumes are put back afterwards, so capturing is invisible to the training trajectory."""
+        runner = _HeadRunner(self)
+        runner.train()
+        saved = [b.detach().clone() for b in runner.buffers()]
+        rng = torch.cuda.get_rng_state(self.device)
+        try:
+            sample = feats.detach().clone().requires_grad_(True)
+            runner = torch.cuda.make_graphed_callables(runner, (sample,), allow_unused_input=True)   # bn1 of Residual_block is unused
+        except Exception as e:   # noqa: BLE001 - any capture problem degrades to the eager path, loudly
+            print("[scl_amd] AASIST back-end: hipGraph capture failed (%s: %s); running it eagerly" % (type(e).__name__, e))
+            runner = False
+        finally:
+            with torch.no_grad():
+                for b, v in zip(_HeadRunner(self).buffers(), saved):
+                    b.copy_(v)
+            torch.cuda.set_rng_state(rng, self.device)
+        return runner
 
     def loss(self, output, feats, emb, labels, config, info=None):
         # aasist.py:607-640: unweighted CrossEntropy on raw logits (the NLL kernel folds the log-softmax), SupCon over the
