@@ -26,8 +26,9 @@ from torch.utils.data import DataLoader, Subset
 
 from model.wav2vec2_aasist import Model as wav2vec2_aasist
 from model.wav2vec2_linear_nll import Model as wav2vec2_linear_nll
+from model.wav2vec2_resnet_nll import Model as wav2vec2_resnet_nll
 
-MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll, "wav2vec2_aasist": wav2vec2_aasist}
+MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll, "wav2vec2_aasist": wav2vec2_aasist, "wav2vec2_resnet_nll": wav2vec2_resnet_nll}
 
 
 class EarlyStop:

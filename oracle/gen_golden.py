@@ -439,6 +439,58 @@ def gen_aasist():
     print("aasist.npz", len(out), "arrays")
 
 
+def gen_resnet():
+    """Reference wav2vec2_resnet_nll.Model (pre-activation ResNet-18 back-end) with an injected encoder; parameters filled by
+    oracle/aasist.py::fill_state.  Cases `eval` / `train` (BatchNorm batch statistics; the model has no dropout), with the
+    reference's own Model.loss terms (CrossEntropy and SupCon without the linear plugin's 1/bz)."""
+    import model.wav2vec2_resnet_nll as M
+    from oracle.aasist import fill_state
+    E = 16
+
+    class Enc(torch.nn.Module):
+        out_dim = E
+
+        def extract_feat(self, x, is_train=True):
+            return x
+
+    M.SSLModel = lambda device: Enc()
+    args = {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1,
+            "resnet": {"num_nodes": 3, "enc_dim": 256, "resnet_type": "18", "nclasses": 2}}
+    out = {}
+    B, T = 4, 70
+    rs = np.random.RandomState(13)
+    x0 = rs.standard_normal((B, T, E)).astype(np.float32)
+    y = np.array([1, 1, 0, 0], dtype=np.int64)
+    out.update(x=x0, y=y)
+    for case in ("eval", "train"):
+        m = M.Model(args, "cpu", is_train=True)
+        sd = m.state_dict()
+        filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=7)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+        m.eval() if case == "eval" else m.train()
+        x = torch.from_numpy(x0).clone().requires_grad_(True)
+        logits, feats, emb = m(x)
+        losses = m.loss(logits, feats, emb, torch.from_numpy(y), {"model": args})
+        sum(losses.values()).backward()
+        out[case + ":logits"] = logits.detach().numpy()
+        out[case + ":emb"] = emb.detach().numpy()
+        out[case + ":feats"] = feats.detach().numpy()
+        out[case + ":grad_x"] = x.grad.numpy()
+        for k, v in losses.items():
+            out[case + ":loss:" + k] = np.array(v.item())
+        pd = dict(m.named_parameters())
+        for k in ("LL.weight", "first_bn.weight", "resnet.conv1.weight", "resnet.layer1.0.conv1.weight", "resnet.layer2.0.shortcut.0.weight",
+                  "resnet.layer4.1.bn2.weight", "resnet.fc.weight"):
+            out[case + ":grad:" + k] = pd[k].grad.numpy()
+        g5 = pd["resnet.conv5.weight"].grad        # 393 k elements: keep a fingerprint (norm, sum, first 16 values)
+        out[case + ":gradfp:resnet.conv5.weight"] = np.concatenate([[g5.norm().item(), g5.sum().item()], g5.flatten()[:16].numpy()]).astype(np.float64)
+        if case == "train":
+            for k in ("first_bn.running_mean", "resnet.bn1.running_var", "resnet.layer3.0.bn1.running_mean"):
+                out["train:buf:" + k] = m.state_dict()[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "resnet.npz"), **out)
+    print("resnet.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
@@ -447,6 +499,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet)):
         if want(name):
             fn()

@@ -163,6 +163,8 @@ def test_dropout_active_in_train_mode(dev):
     assert not torch.equal(a, b)
 
 
+@pytest.mark.skipif(os.environ.get("SCL_TEST_HEAD_GRAPH", "0") != "1",
+                    reason="opt-in: hipGraph capture of library convolutions can crash the process on ROCm 7.2 (see model_front.py)")
 def test_backend_as_hip_graphs_equals_eager(dev):
     """In training the back-end is replayed as captured forward / backward hipGraphs: same outputs, same gradients, same
     BatchNorm running statistics as the eager launch sequence (dropout p = 0 on both sides; capture warm-up must leave no trace)."""
