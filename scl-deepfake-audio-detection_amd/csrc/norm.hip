@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 // Backward.  dy -> dx (optionally + residual gradient), per-block partial sums of dgamma / dbeta.
 // Each wave walks rows row0 + w, row0 + w + 4, ... of its block's slab and keeps the per-column
 // sums in registers; the four waves are combined through LDS.
-template <bool XF32, bool DYF32>
+// NCH = chunks of 512 channels a wave covers (1: C <= 512, 2: C <= 1024, 4: C <= 2048): sized exactly, the accumulators take
+// 32*NCH + ... registers instead of 227 for every C, i.e. 4-7 waves per SIMD instead of 2 on this latency-bound kernel.
+template <bool XF32, bool DYF32, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -107,18 +109,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    float ag[MAXCH][8], ab[MAXCH][8];
+    float ag[NCH][8], ab[NCH][8];
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ag[ch][i] = 0.f; ab[ch][i] = 0.f; }
 
     for (int row = r0 + w; row < r1; row += 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float xh[MAXCH][8], dyv[MAXCH][8];
+        float xh[NCH][8], dyv[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
             const int c = ch * 512 + lane * 8;
             if (c < C) {
                 float xv[8], g[8];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
             const int c = ch * 512 + lane * 8;
             if (c < C) {
                 float o[8];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     // combine the 4 waves
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c = ch * 512 + lane * 8;
         if (c < C) {
 #pragma unroll
@@ -359,12 +361,14 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
     const size_t lds = (size_t)8 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nblk), block(256);
-#define LN_BWD(XF, DF) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
-                                          dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act)
-    if (x_f32 && dy_f32) LN_BWD(true, true);
-    else if (x_f32) LN_BWD(true, false);
-    else if (dy_f32) LN_BWD(false, true);
-    else LN_BWD(false, false);
+#define LN_BWD(XF, DF, NC) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF, NC>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
+                                              dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act)
+#define LN_BWD_C(XF, DF) do { if (C <= 512) LN_BWD(XF, DF, 1); else if (C <= 1024) LN_BWD(XF, DF, 2); else LN_BWD(XF, DF, 4); } while (0)
+    if (x_f32 && dy_f32) LN_BWD_C(true, true);
+    else if (x_f32) LN_BWD_C(true, false);
+    else if (dy_f32) LN_BWD_C(false, true);
+    else LN_BWD_C(false, false);
+#undef LN_BWD_C
 #undef LN_BWD
     return scl_check_launch("scl_layernorm_bwd");
 }
@@ -385,16 +389,22 @@ extern "C" int scl_colreduce_seg_f32(const float* part, float* out, int nparts, 
     return scl_check_launch("scl_colreduce_seg_f32");
 }
 
-extern "C" int scl_colsum_nparts(int M) {
+// row slab per block: 256 rows, doubled until at most 64 slabs remain (finer slabs were measured slower: the finishing block
+// reads one partial row per slab)
+static int colsum_rows(int M) {
     int rows_per_block = 256;
     while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    return rows_per_block;
+}
+
+extern "C" int scl_colsum_nparts(int M) {
+    const int rows_per_block = colsum_rows(M);
     return (M + rows_per_block - 1) / rows_per_block;
 }
 
 extern "C" int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream) {
     SCL_REQUIRE(x && part && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: bad args (N, ld multiples of 8)");
-    int rows_per_block = 256;
-    while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    const int rows_per_block = colsum_rows(M);
     dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, (int*)nullptr, (float*)nullptr);
@@ -405,8 +415,7 @@ extern "C" int scl_colsum(const void* x, int x_f32, float* part, int M, int N, i
 extern "C" int scl_colsum_reduce(const void* x, int x_f32, float* part, int* counters, float* out, int M, int N, int64_t ld, void* stream) {
     SCL_REQUIRE(x && part && counters && out && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum_reduce: bad args (N, ld multiples of 8)");
     SCL_REQUIRE((N + 127) / 128 <= SCL_COLSUM_MAX_GROUPS, "colsum_reduce: N too large for the counter array (%d)", N);
-    int rows_per_block = 256;
-    while ((M + rows_per_block - 1) / rows_per_block > 64) rows_per_block *= 2;
+    const int rows_per_block = colsum_rows(M);
     dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, counters, out);
