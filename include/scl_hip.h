@@ -124,14 +124,18 @@ int scl_layernorm_bwd_nparts(int M);
  * (one scl_colreduce_f32 over 2*C columns finishes both).  Autograd backward of the above (main.py:79). */
 int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
-                      float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream);
+                      float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, void* stream);
+/* sum_dres != 0: `part` rows are [dgamma | dbeta | colsum(dres)] (3*C floats per slab instead of 2*C) — the residual gradient
+ * entering a pre-LN block's LayerNorm backward is the output gradient of the preceding fc2 / out_proj, so its column sum is
+ * that layer's bias gradient (fairseq TransformerSentenceEncoderLayer, reached from model/xlsr.py:41) */
 int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream);
 /* the same reduction spread over SCL_COLREDUCE_SEGMENTS x more blocks, finished in-launch by the last block of each 32-column group;
  * scratch: f32 [SCL_COLREDUCE_SEGMENTS][C]; counters: as for scl_colsum_reduce (C <= 32 * SCL_COLSUM_MAX_GROUPS) */
 #define SCL_COLREDUCE_SEGMENTS 8
-#define SCL_COLSUM_MAX_GROUPS 64
+#define SCL_COLSUM_MAX_GROUPS 128
+/* out2 (optional): columns [split, C) are written to out2[0 .. C-split) instead of out[split ..) */
 int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, float* scratch, int* counters,
-                          void* stream);
+                          float* out2, int split, void* stream);
 /* bias gradients: part[p][n] = sum over row slab p of x[m][n]; nparts = scl_colsum_nparts(M) */
 int scl_colsum_nparts(int M);
 int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream);

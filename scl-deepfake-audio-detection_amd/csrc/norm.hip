@@ -104,16 +104,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
                                                      bf16_t* __restrict__ dx_bf, float* __restrict__ part, int M, int C, int64_t ldx,
-                                                     int64_t lddy, int64_t lddx, int rows_per_block, int act) {
-    extern __shared__ float red[];  // [4][2][C]
+                                                     int64_t lddy, int64_t lddx, int rows_per_block, int act, int sum_dres) {
+    // sum_dres: also emit the column sums of `dres` (third partial row).  In a pre-LN transformer block the residual gradient
+    // that enters this LayerNorm's backward IS the gradient of the preceding linear's output (fc2 / out_proj), so its column
+    // sum is that linear's bias gradient — read here anyway, summed for free instead of by a separate pass over [M, C].
+    extern __shared__ float red[];  // [4][2 + sum_dres][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    float ag[NCH][8], ab[NCH][8];
+    float ag[NCH][8], ab[NCH][8], ar[NCH][8];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ag[ch][i] = 0.f; ab[ch][i] = 0.f; }
+        for (int i = 0; i < 8; ++i) { ag[ch][i] = 0.f; ab[ch][i] = 0.f; ar[ch][i] = 0.f; }
+    const int np = 2 + (sum_dres ? 1 : 0);
 
     for (int row = r0 + w; row < r1; row += 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                     float r[8];
                     load8<true>(dres, (int64_t)row * lddx + c, r);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] += r[i];
+                    for (int i = 0; i < 8; ++i) { o[i] += r[i]; ar[ch][i] += r[i]; }
                 }
                 if (dx_f32) store8_f32(dx_f32, (int64_t)row * lddx + c, o);
                 if (dx_bf) store8_bf16(dx_bf, (int64_t)row * lddx + c, o);
@@ -176,18 +180,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         if (c < C) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                red[(w * 2 + 0) * C + c + i] = ag[ch][i];
-                red[(w * 2 + 1) * C + c + i] = ab[ch][i];
+                red[(w * np + 0) * C + c + i] = ag[ch][i];
+                red[(w * np + 1) * C + c + i] = ab[ch][i];
+                if (sum_dres) red[(w * np + 2) * C + c + i] = ar[ch][i];
             }
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        float g = 0.f, b = 0.f;
+        float g = 0.f, b = 0.f, r = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { g += red[(ww * 2 + 0) * C + c]; b += red[(ww * 2 + 1) * C + c]; }
-        part[(int64_t)blockIdx.x * 2 * C + c] = g;          // [block][dgamma (C) | dbeta (C)]
-        part[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+        for (int ww = 0; ww < 4; ++ww) {
+            g += red[(ww * np + 0) * C + c]; b += red[(ww * np + 1) * C + c];
+            if (sum_dres) r += red[(ww * np + 2) * C + c];
+        }
+        part[(int64_t)blockIdx.x * np * C + c] = g;          // [block][dgamma (C) | dbeta (C) | colsum(dres) (C, optional)]
+        part[(int64_t)blockIdx.x * np * C + C + c] = b;
+        if (sum_dres) part[(int64_t)blockIdx.x * np * C + 2 * C + c] = r;
     }
 }
 
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 // sc1 write-through hand-off) adds the segments in order.  Deterministic; the counters return to zero.
 __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
                                                             int64_t pstride, int accumulate, float* __restrict__ scratch,
-                                                            int* __restrict__ counters) {
+                                                            int* __restrict__ counters, float* __restrict__ out2, int split) {
     __shared__ float red[8][33];
     __shared__ int last_flag;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -247,7 +256,8 @@ __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float t = 0.f;
         for (int k = 0; k < nseg; ++k) t += __hip_atomic_load(&scratch[(int64_t)k * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[c] = accumulate ? out[c] + t : t;
+        float* o = (out2 && c >= split) ? out2 + (c - split) : out + c;     // columns >= split go to the second destination
+        *o = accumulate ? *o + t : t;
     }
 }
 
@@ -351,18 +361,19 @@ extern "C" int scl_layernorm_bwd_nparts(int M) {
 extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, const float* dres,
                                  float* dx_f32, void* dx_bf16, float* part, int M, int C,
-                                 int64_t ldx, int64_t lddy, int64_t lddx, int act, void* stream) {
+                                 int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, void* stream) {
+    SCL_REQUIRE(!sum_dres || dres, "layernorm_bwd: sum_dres needs dres");
     SCL_REQUIRE(dy && x && mean && rstd && gamma && part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SCL_REQUIRE(act == 0 || beta, "layernorm_bwd: gelu variant needs beta");
     SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0,
                 "layernorm_bwd: need 8 <= C <= 2048 and multiples of 8");
     const int rows_per_block = ln_bwd_rows_per_block(M);
     const int nblk = (M + rows_per_block - 1) / rows_per_block;
-    const size_t lds = (size_t)8 * C * sizeof(float);
+    const size_t lds = (size_t)4 * (2 + (sum_dres ? 1 : 0)) * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nblk), block(256);
 #define LN_BWD(XF, DF, NC) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF, NC>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
-                                              dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act)
+                                              dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act, sum_dres)
 #define LN_BWD_C(XF, DF) do { if (C <= 512) LN_BWD(XF, DF, 1); else if (C <= 1024) LN_BWD(XF, DF, 2); else LN_BWD(XF, DF, 4); } while (0)
     if (x_f32 && dy_f32) LN_BWD_C(true, true);
     else if (x_f32) LN_BWD_C(true, false);
@@ -380,12 +391,13 @@ extern "C" int scl_colreduce_f32(const float* part, float* out, int nparts, int 
 }
 
 extern "C" int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, float* scratch,
-                                     int* counters, void* stream) {
+                                     int* counters, float* out2, int split, void* stream) {
     SCL_REQUIRE(part && out && scratch && counters && nparts >= 1 && C >= 1, "colreduce_seg: bad args");
+    SCL_REQUIRE(!out2 || (split > 0 && split < C), "colreduce_seg: split must lie inside (0, C) when out2 is given");
     SCL_REQUIRE((C + 31) / 32 <= SCL_COLSUM_MAX_GROUPS, "colreduce_seg: C too large for the counter array (%d)", C);
     const int nseg = nparts >= 64 ? SCL_COLREDUCE_SEGMENTS : 1;
     hipLaunchKernelGGL(colreduce_seg_kernel, dim3((C + 31) / 32, nseg), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride,
-                       accumulate, scratch, counters);
+                       accumulate, scratch, counters, out2, split);
     return scl_check_launch("scl_colreduce_seg_f32");
 }
 

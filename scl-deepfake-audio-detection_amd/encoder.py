@@ -182,7 +182,7 @@ class Encoder:
         kmax = max(cfg.conv_kernels[1:]) if len(cfg.conv_kernels) > 1 else 1
         d["dcol"] = bf(B * Ts[1] * kmax * C + slack) if len(Ts) > 1 else None
         nln = max(ops.layernorm_bwd_nparts(B * t) for t in Ts)
-        d["ln_part"] = f32(nln * 2 * max(C, E))
+        d["ln_part"] = f32(nln * 3 * max(C, E))
         ncs = max(ops.colsum_nparts(B * max(Ts[1:] + [T + K])), 1)
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
         d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
@@ -211,11 +211,15 @@ class Encoder:
     def _bias_grad(self, d, dy, Mrows, N, gname):
         ops.colsum_reduce(dy, d["cs_part"], self.P.g(self.n(gname)), Mrows, N)
 
-    def _ln_grads(self, d, nparts, C, wname, bname):
-        """weight and bias of a LayerNorm are adjacent in the flat buffer: one reduction over the (dgamma | dbeta) partials."""
+    def _ln_grads(self, d, nparts, C, wname, bname, resid_bias=None):
+        """weight and bias of a LayerNorm are adjacent in the flat buffer: one reduction over the (dgamma | dbeta) partials;
+        with resid_bias also the third partial row, colsum(dres) = the bias gradient of the linear that feeds the residual."""
         ow, ob = self.P.off(self.n(wname)), self.P.off(self.n(bname))
         assert ob == ow + C
-        ops.colreduce_seg(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
+        if resid_bias is None:
+            ops.colreduce_seg(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
+        else:
+            ops.colreduce_seg(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 3 * C, out2=self.P.g(self.n(resid_bias)), split=2 * C)
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, x, training=True, refresh=True):
@@ -307,18 +311,17 @@ class Encoder:
                 continue
             xin = d["xin"][n]
             # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
-            self._bias_grad(d, dx, M, E, pn + "fc2.bias")
             self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
             ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU)
             self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
             self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
+            # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
             ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_part"], M, E)
-            self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias")
+                              other, otherb, d["ln_part"], M, E, sum_dres=True)
+            self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
-            self._bias_grad(d, dx, M, E, pn + "self_attn.out_proj.bias")
             self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M)
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
             qkv, dqkv = d["qkv"][n], d["dqkv"]
@@ -343,9 +346,11 @@ class Encoder:
             ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
             self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
+            # dx (= d x1) is the gradient of out_proj's output: out_proj.bias.grad rides on this LayerNorm backward
             ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_part"], M, E)
-            self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias")
+                              other, otherb, d["ln_part"], M, E, sum_dres=True)
+            self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
+                           resid_bias=pn + "self_attn.out_proj.bias")
             dx, dxb, other, otherb = other, otherb, dx, dxb      # dx = d xin
             if self.on_grads_ready is not None:
                 ops.host_callback(self.on_grads_ready, P.off(self.n(pn + "self_attn_layer_norm.weight")))

@@ -68,11 +68,11 @@ def _protos():
         "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
         "scl_layernorm_bwd_nparts": ([_i32], _i32),
         "scl_layernorm_bwd": ([_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64,
-                               _i64, _i32, _vp], _i32),
+                               _i64, _i32, _i32, _vp], _i32),
         "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
         "scl_colsum_nparts": ([_i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
-        "scl_colreduce_seg_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], _i32),
+        "scl_colreduce_seg_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp], _i32),
         "scl_colsum_reduce": ([_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp], _i32),
         # elementwise.hip
         "scl_cast_f32_bf16": ([_vp, _vp, _i64, _vp], _i32),

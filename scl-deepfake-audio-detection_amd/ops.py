@@ -168,10 +168,10 @@ def layernorm_bwd_nparts(M):
     return L.load().scl_layernorm_bwd_nparts(M)
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0):
-    """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0, sum_dres=False):
+    """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums; [nparts, 3*C] with sum_dres (| colsum(dres))."""
     _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, _stream())
+          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, 1 if sum_dres else 0, _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):
@@ -193,21 +193,22 @@ def _counters(device):
     """Ticket counters of the self-finishing reductions (zero between launches; one array per device, launches are stream-ordered)."""
     key = (device.type, device.index)
     if key not in _COUNTERS:
-        _COUNTERS[key] = torch.zeros(64, dtype=torch.int32, device=device)
+        _COUNTERS[key] = torch.zeros(128, dtype=torch.int32, device=device)
     return _COUNTERS[key]
 
 
 _SCRATCH = {}
 
 
-def colreduce_seg(part, out, nparts, C, pstride=None, accumulate=False):
-    """colreduce over 8x more blocks, finished in-launch (LayerNorm parameter gradients: 768 partial rows x 2C)."""
+def colreduce_seg(part, out, nparts, C, pstride=None, accumulate=False, out2=None, split=0):
+    """colreduce over 8x more blocks, finished in-launch (LayerNorm parameter gradients: 768 partial rows x 2C or 3C);
+    columns >= split go to out2 when given."""
     key = (part.device.type, part.device.index)
     if key not in _SCRATCH:
-        _SCRATCH[key] = torch.empty(8 * 2048, dtype=torch.float32, device=part.device)
-    assert C <= 2048
+        _SCRATCH[key] = torch.empty(8 * 4096, dtype=torch.float32, device=part.device)
+    assert C <= 4096
     _call("scl_colreduce_seg_f32", _p(part), _p(out), nparts, C, pstride or C, 1 if accumulate else 0, _p(_SCRATCH[key]),
-          _p(_counters(part.device)), _stream())
+          _p(_counters(part.device)), _p(out2), split, _stream())
 
 
 def colsum_reduce(x, part, out, M, N, ld=None):

@@ -52,6 +52,14 @@ def test_layernorm_fwd_bwd(dev, C, M, xdt, act):
     assert rel(dx_f, xr.grad + dres) < 5e-5
     assert rel(dx_b, xr.grad + dres) < 8e-3
     assert rel(dgam, gr.grad) < 5e-5 and rel(dbet, br.grad) < 5e-5
+    # third partial row: column sums of the residual gradient (bias gradient of the linear feeding the residual), split output
+    part3 = torch.empty(nparts, 3 * C, device=dev)
+    dx_f3 = torch.empty(M, C, device=dev)
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f3, None, part3, M, C, act=act, sum_dres=True)
+    assert torch.equal(dx_f3, dx_f)
+    lnout = torch.full((2 * C,), float("nan"), device=dev); bias_out = torch.full((C,), float("nan"), device=dev)
+    ops.colreduce_seg(part3, lnout, nparts, 3 * C, out2=bias_out, split=2 * C)
+    assert rel(lnout, both) < 1e-5 and rel(bias_out, dres.sum(0)) < 2e-5
     # bf16 dy variant
     dyb = dy.to(torch.bfloat16)
     ops.layernorm_bwd(dyb, x, mean, rstd, gamma, beta, None, dx_f, None, part, M, C, act=act)
