@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 // NCH = chunks of 512 channels a wave covers (1: C <= 512, 2: C <= 1024, 4: C <= 2048): sized exactly, the accumulators take
 // 32*NCH + ... registers instead of 227 for every C, i.e. 4-7 waves per SIMD instead of 2 on this latency-bound kernel.
 template <bool XF32, bool DYF32, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+__global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
