@@ -49,7 +49,7 @@ struct GemmK {
     void* C; void* C2; const void* R; const float* bias;
     long long c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2;  // elements
     unsigned c_rpb, c_magic, c_shift;
-    int ldc, M, N, K, nb2, splitk, flags, vec_ok;
+    int ldc, M, N, K, nb2, splitk, flags, vec_ok, group_m;
     float alpha, drop_p;
     unsigned drop_seed;
 };
@@ -168,11 +168,10 @@ template <> struct StageSel<true> { typedef StageT type; };
 // workgroup id -> output tile.  (1) XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD gets a
 // contiguous run of tile ids; (2) grouped order inside the run: 8 tile-rows are walked for one tile-column before moving to
 // the next column, so the ~64 tiles resident on an XCD at a time touch 8 A row-panels and 8 B column-panels (~4 MiB = its L2).
-__device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * tiles_n;
     const int group = tile / per_group;
     const int first_m = group * GROUP_M;
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
 
     const int tiles_n = (d.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn);
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
 
     int z = blockIdx.z;
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (d.N + BN - 1) / BN;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn);
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
     int z = blockIdx.z;
     const int ksplit = z % d.splitk; z /= d.splitk;
@@ -904,6 +903,8 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
     k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
+    static const int group_m_env = [] { const char* e = getenv("SCL_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();
+    k.group_m = group_m_env;
     // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias
     auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p & (bytes - 1)) == 0; };
     const bool strides4 = !(d.ldc & 3) && !(d.c_bs1 & 3) && !(d.c_bs2 & 3) && !(d.c_rbstride & 3) && !(d.c_split_stride & 3) && !(d.bias_bs2 & 3);
