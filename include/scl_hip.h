@@ -124,7 +124,10 @@ int scl_layernorm_bwd_nparts(int M);
  * (one scl_colreduce_f32 over 2*C columns finishes both).  Autograd backward of the above (main.py:79). */
 int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
-                      float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, void* stream);
+                      float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, int out_rpb,
+                      int64_t out_rbstride, int64_t out_off, void* stream);
+/* out_rpb > 0: bf16 output row r goes to element (r / out_rpb) * out_rbstride + (r % out_rpb) * lddx + out_off (per-utterance
+ * zero padding kept by the caller) */
 /* sum_dres != 0: `part` rows are [dgamma | dbeta | colsum(dres)] (3*C floats per slab instead of 2*C) — the residual gradient
  * entering a pre-LN block's LayerNorm backward is the output gradient of the preceding fc2 / out_proj, so its column sum is
  * that layer's bias gradient (fairseq TransformerSentenceEncoderLayer, reached from model/xlsr.py:41) */
@@ -155,8 +158,11 @@ int scl_pad_rows_bf16(const void* src, int src_f32, void* dst, const void* pre, 
                       int rows_out, int pad_before, void* stream);
 /* conv-stack dgrad tail: dz[b][r][c] = sum_j dcol[b][(r-j)/s][j*C+c] (Conv1d backward-data, layers 1..6) */
 int scl_col2im_bf16(const void* dcol, void* dz, int B, int Tin, int Tout, int C, int k, int s, void* stream);
-/* Conv1d weight [co][ci][j] f32 <-> GEMM operand [co][j*Ci+ci] (bf16 forward copy / f32 gradient back) */
-int scl_conv_weight_pack(const float* w, void* wk, int Co, int Ci, int k, void* stream);
+/* Conv1d weight [co][ci][j] f32 <-> GEMM operand [co][j*Ci+ci] (bf16 forward copy / f32 gradient back).  wd (optional): the
+ * backward-data operand of the phase-split transposed convolution, [k tap blocks][co][ci] bf16, blocks ordered by phase
+ * p = j mod stride and, inside a phase, by descending tap — dz[stride*u + p] = [dy[u-q_max] .. dy[u]] x wd(phase p) is then one
+ * GEMM per phase with overlapping A rows, and no [M, k*C] column buffer / col2im pass exists (Conv1d backward, layers 1..6) */
+int scl_conv_weight_pack(const float* w, void* wk, void* wd, int Co, int Ci, int k, int stride, void* stream);
 int scl_conv_weight_unpack_grad(const float* dwk, float* dw, int Co, int Ci, int k, void* stream);
 /* torch.nn.utils.weight_norm(dim=2) of encoder.pos_conv.0 + GEMM layouts (forward and flipped dgrad) */
 int scl_posconv_weight_pack(const float* v, const float* g, float* norm, void* wf, void* wd, int E, int Cg, int K, void* stream);

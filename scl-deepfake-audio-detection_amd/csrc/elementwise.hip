@@ -93,14 +93,26 @@ __global__ void col2im_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restric
     }
 }
 
-// conv weight [co][ci][j] f32  ->  GEMM layout [co][j*Ci + ci] bf16
-__global__ void conv_w_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wk, int Co, int Ci, int k) {
+// conv weight [co][ci][j] f32  ->  GEMM layout [co][j*Ci + ci] bf16, and (optional) the transposed-convolution layout used by the
+// phase-split dgrad: wd[blk(j)][co][ci], tap blocks ordered phase by phase (p = j mod stride), inside a phase by DESCENDING tap
+// (the A rows of that GEMM are [dy[u-q_max] ... dy[u]], so block q' holds tap p + stride*(nq-1-q')).
+__global__ void conv_w_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wk, bf16_t* __restrict__ wd, int Co, int Ci, int k,
+                                   int stride) {
     const int64_t n = (int64_t)Co * Ci * k;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i % Ci);
         const int j = (int)((i / Ci) % k);
         const int co = (int)(i / ((int64_t)Ci * k));
-        wk[i] = f2bf(w[((int64_t)co * Ci + ci) * k + j]);
+        const bf16_t v = f2bf(w[((int64_t)co * Ci + ci) * k + j]);
+        wk[i] = v;
+        if (wd) {
+            const int p = j % stride, q = j / stride;
+            int blk = 0;
+            for (int pp = 0; pp < p; ++pp) blk += (k - pp + stride - 1) / stride;     // taps in the earlier phases
+            const int nq = (k - p + stride - 1) / stride;
+            blk += nq - 1 - q;
+            wd[((int64_t)blk * Co + co) * Ci + ci] = v;
+        }
     }
 }
 // gradient back: dwk [co][j*Ci+ci] f32 -> dw [co][ci][j] f32
@@ -289,9 +301,10 @@ extern "C" int scl_col2im_bf16(const void* dcol, void* dz, int B, int Tin, int T
     return scl_check_launch("scl_col2im_bf16");
 }
 
-extern "C" int scl_conv_weight_pack(const float* w, void* wk, int Co, int Ci, int k, void* stream) {
-    SCL_REQUIRE(w && wk && Co > 0 && Ci > 0 && k > 0, "conv_weight_pack: bad args");
-    hipLaunchKernelGGL(conv_w_pack_kernel, dim3(grid_for((int64_t)Co * Ci * k)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wk, Co, Ci, k);
+extern "C" int scl_conv_weight_pack(const float* w, void* wk, void* wd, int Co, int Ci, int k, int stride, void* stream) {
+    SCL_REQUIRE(w && wk && Co > 0 && Ci > 0 && k > 0 && stride >= 1, "conv_weight_pack: bad args");
+    hipLaunchKernelGGL(conv_w_pack_kernel, dim3(grid_for((int64_t)Co * Ci * k)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wk,
+                       (bf16_t*)wd, Co, Ci, k, stride);
     return scl_check_launch("scl_conv_weight_pack");
 }
 extern "C" int scl_conv_weight_unpack_grad(const float* dwk, float* dw, int Co, int Ci, int k, void* stream) {

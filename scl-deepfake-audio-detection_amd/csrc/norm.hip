@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
                                                      bf16_t* __restrict__ dx_bf, float* __restrict__ part, int M, int C, int64_t ldx,
-                                                     int64_t lddy, int64_t lddx, int rows_per_block, int act, int sum_dres) {
+                                                     int64_t lddy, int64_t lddx, int rows_per_block, int act, int sum_dres,
+                                                     int out_rpb, int64_t out_rbstride, int64_t out_off) {
     // sum_dres: also emit the column sums of `dres` (third partial row).  In a pre-LN transformer block the residual gradient
     // that enters this LayerNorm's backward IS the gradient of the preceding linear's output (fc2 / out_proj), so its column
     // sum is that linear's bias gradient — read here anyway, summed for free instead of by a separate pass over [M, C].
@@ -169,7 +170,13 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                     for (int i = 0; i < 8; ++i) { o[i] += r[i]; ar[ch][i] += r[i]; }
                 }
                 if (dx_f32) store8_f32(dx_f32, (int64_t)row * lddx + c, o);
-                if (dx_bf) store8_bf16(dx_bf, (int64_t)row * lddx + c, o);
+                if (dx_bf) {
+                    // optional per-utterance padding of the bf16 output (zero rows around each utterance's frames, pre-zeroed
+                    // by the caller): the phase-split conv dgrad reads [dy[u-1], dy[u]] as ONE overlapping GEMM row
+                    const int64_t orow = out_rpb > 0 ? (int64_t)(row / out_rpb) * out_rbstride + (int64_t)(row % out_rpb) * lddx + out_off
+                                                     : (int64_t)row * lddx;
+                    store8_bf16(dx_bf, orow + c, o);
+                }
             }
         }
     }
@@ -361,7 +368,9 @@ extern "C" int scl_layernorm_bwd_nparts(int M) {
 extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, const float* dres,
                                  float* dx_f32, void* dx_bf16, float* part, int M, int C,
-                                 int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, void* stream) {
+                                 int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, int out_rpb, int64_t out_rbstride,
+                                 int64_t out_off, void* stream) {
+    SCL_REQUIRE(out_rpb == 0 || (dx_bf16 && out_rpb > 0 && (out_rbstride & 7) == 0 && (out_off & 7) == 0), "layernorm_bwd: padded output needs dx_bf16");
     SCL_REQUIRE(!sum_dres || dres, "layernorm_bwd: sum_dres needs dres");
     SCL_REQUIRE(dy && x && mean && rstd && gamma && part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SCL_REQUIRE(act == 0 || beta, "layernorm_bwd: gelu variant needs beta");
@@ -373,7 +382,8 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nblk), block(256);
 #define LN_BWD(XF, DF, NC) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF, NC>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
-                                              dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act, sum_dres)
+                                              dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act, sum_dres, \
+                                              out_rpb, out_rbstride, out_off)
 #define LN_BWD_C(XF, DF) do { if (C <= 512) LN_BWD(XF, DF, 1); else if (C <= 1024) LN_BWD(XF, DF, 2); else LN_BWD(XF, DF, 4); } while (0)
     if (x_f32 && dy_f32) LN_BWD_C(true, true);
     else if (x_f32) LN_BWD_C(true, false);

@@ -97,6 +97,8 @@ class Encoder:
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
         # derived bf16 weights that are not plain casts
         self.wk = [None] + [bf(C, cfg.conv_kernels[i] * C) for i in range(1, len(cfg.conv_kernels))]
+        # backward-data operands of the phase-split transposed convolution ([k tap blocks][C][C], see scl_conv_weight_pack)
+        self.wd = [None] + [bf(cfg.conv_kernels[i] * C, C) for i in range(1, len(cfg.conv_kernels))]
         self.pos_wf, self.pos_wd, self.pos_norm = bf(G, Cg, K * Cg), bf(G, Cg, K * Cg), f32(K)
         self.ws_small = f32(max(K, 16))
         self.on_grads_ready = None   # callback(lo_offset): every gradient at flat offset >= lo_offset is final (DP overlap)
@@ -116,7 +118,8 @@ class Encoder:
             return
         C, E, K, G = cfg.conv_dim, cfg.embed, cfg.pos_k, cfg.pos_groups
         for i in range(1, len(cfg.conv_kernels)):
-            ops.conv_weight_pack(P.f32(self.n("feature_extractor.conv_layers.%d.0.weight" % i)), self.wk[i], C, C, cfg.conv_kernels[i])
+            ops.conv_weight_pack(P.f32(self.n("feature_extractor.conv_layers.%d.0.weight" % i)), self.wk[i], C, C, cfg.conv_kernels[i],
+                                 wd=self.wd[i], stride=cfg.conv_strides[i])
         ops.posconv_weight_pack(P.f32(self.n("encoder.pos_conv.0.weight_v")), P.f32(self.n("encoder.pos_conv.0.weight_g")),
                                 self.pos_norm, self.pos_wf, self.pos_wd, E, E // G, K)
         self._derived_version = P.version
@@ -178,16 +181,24 @@ class Encoder:
         d["dS"] = None if d["fused_attn"] else bf(B * H * T * Tp + 1024)
         d["dcpad"] = bf(B * (T + K) * E + slack)
         d["dz"] = [bf(B * t * C + slack) for t in Ts]
-        d["dy"] = bf(B * Ts[1] * C + slack) if len(Ts) > 1 else None
-        kmax = max(cfg.conv_kernels[1:]) if len(cfg.conv_kernels) > 1 else 1
-        d["dcol"] = bf(B * Ts[1] * kmax * C + slack) if len(Ts) > 1 else None
+        # conv-stack backward: LayerNorm-backward output of layer i with per-utterance zero rows (Q in front, Qe behind) so that
+        # the transposed convolution reads [dy[u-1], dy[u]] as one overlapping GEMM row; zeroed once, only frame rows are rewritten
+        d["dyp"], d["dyp_geom"] = [None], [None]
+        for i in range(1, len(Ts)):
+            k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
+            Q = (k - 1) // s
+            Qe = max(0, max((Tin - 1 - p) // s for p in range(s)) - (Tout - 1))
+            Rp = Q + Tout + Qe
+            d["dyp"].append(torch.zeros(B * Rp * C + slack, dtype=torch.bfloat16, device=dev))
+            d["dyp_geom"].append((Q, Rp))
         nln = max(ops.layernorm_bwd_nparts(B * t) for t in Ts)
         d["ln_part"] = f32(nln * 3 * max(C, E))
-        ncs = max(ops.colsum_nparts(B * max(Ts[1:] + [T + K])), 1)
+        ncs = max(ops.colsum_nparts(B * (max(Ts[1:] + [T + K]) + 4)), 1) + 1      # conv bias sums run over the zero-padded dyp rows
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
         d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
         d["conv0_stats"] = f32(B * Ts[0] * 2)   # per-frame (mean, rstd) of layer 0's LayerNorm
         d["slab"] = None  # split-K slabs, sized on first use
+        kmax = max(cfg.conv_kernels[1:]) if len(cfg.conv_kernels) > 1 else 1
         d["dwk"] = f32(C * kmax * C)
         d["dwf"] = f32(E * (E // cfg.pos_groups) * K)
         self._bufs[key] = d
@@ -381,15 +392,27 @@ class Encoder:
         for i in reversed(range(1, len(Ts))):
             k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
             Mi = B * Tout
+            Q, Rp = d["dyp_geom"][i]
+            dyp = d["dyp"][i]
             ops.layernorm_bwd(d["dz"][i], d["y"][i], d["cmean"][i], d["crstd"][i], self.b(fe % i + "2.1.weight"),
-                              self.b(fe % i + "2.1.bias"), None, None, d["dy"], d["ln_part"], Mi, C, act=1)
+                              self.b(fe % i + "2.1.bias"), None, None, dyp, d["ln_part"], Mi, C, act=1,
+                              out_rpb=Tout, out_rbstride=Rp * C, out_off=Q * C)
             self._ln_grads(d, ops.layernorm_bwd_nparts(Mi), C, fe % i + "2.1.weight", fe % i + "2.1.bias")
-            self._bias_grad(d, d["dy"], Mi, C, fe % i + "0.bias")
+            self._bias_grad(d, dyp, B * Rp, C, fe % i + "0.bias")            # the padding rows are zero
             dwk = d["dwk"][: C * k * C].view(C, k * C)
-            self._wgrad(d, Op(d["dy"], C), Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), dwk, C, k * C, Mi)
+            self._wgrad(d, Op(dyp, C, rpb=Tout, rbstride=Rp * C, offset=Q * C), Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), dwk,
+                        C, k * C, Mi)
             ops.conv_weight_unpack_grad(dwk, P.g(self.n(fe % i + "0.weight")), C, C, k)
-            ops.gemm(Op(d["dy"], C), Op(self.wk[i], k * C), d["dcol"], Mi, k * C, C, b_t=True)
-            ops.col2im(d["dcol"], d["dz"][i - 1], B, Tin, Tout, C, k, s)
+            # backward-data, one GEMM per output phase p: dz[s*u + p] = sum_q dy[u - q] W[p + s*q]  (K = nq*C, overlapping A rows)
+            blk = 0
+            for p in range(s):
+                nq = len(range(p, k, s))
+                Up = (Tin - 1 - p) // s
+                if nq == 0:
+                    raise NotImplementedError("conv layer with kernel < stride")
+                ops.gemm(Op(dyp, C, rpb=Up + 1, rbstride=Rp * C, offset=(Q - (nq - 1)) * C), Op(self.wd[i], C, offset=blk * C * C),
+                         d["dz"][i - 1], B * (Up + 1), C, nq * C, b_t=True, ldc=s * C, c_rpb=Up + 1, c_rbstride=Tin * C, c_offset=p * C)
+                blk += nq
         ops.conv0_bwd(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"),
                       self.b(fe % 0 + "2.1.bias"), d["dz"][0], d["conv0_ws"], P.g(self.n(fe % 0 + "0.weight")),
                       P.g(self.n(fe % 0 + "0.bias")), P.g(self.n(fe % 0 + "2.1.weight")), P.g(self.n(fe % 0 + "2.1.bias")),

@@ -68,7 +68,7 @@ def _protos():
         "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
         "scl_layernorm_bwd_nparts": ([_i32], _i32),
         "scl_layernorm_bwd": ([_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64,
-                               _i64, _i32, _i32, _vp], _i32),
+                               _i64, _i32, _i32, _i32, _i64, _i64, _vp], _i32),
         "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
         "scl_colsum_nparts": ([_i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
@@ -79,7 +79,7 @@ def _protos():
         "scl_add_f32": ([_vp, _vp, _vp, _vp, _i64, _vp], _i32),
         "scl_pad_rows_bf16": ([_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_col2im_bf16": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
-        "scl_conv_weight_pack": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_conv_weight_pack": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_conv_weight_unpack_grad": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_posconv_weight_pack": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_posconv_weight_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),

@@ -168,10 +168,12 @@ def layernorm_bwd_nparts(M):
     return L.load().scl_layernorm_bwd_nparts(M)
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0, sum_dres=False):
-    """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums; [nparts, 3*C] with sum_dres (| colsum(dres))."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0, sum_dres=False, out_rpb=0,
+                  out_rbstride=0, out_off=0):
+    """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums; [nparts, 3*C] with sum_dres (| colsum(dres)).
+    out_rpb > 0: the bf16 output is written with per-utterance row padding (see include/scl_hip.h)."""
     _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, 1 if sum_dres else 0, _stream())
+          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, 1 if sum_dres else 0, out_rpb, out_rbstride, out_off, _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):
@@ -232,8 +234,8 @@ def col2im(dcol, dz, B, Tin, Tout, C, k, s):
     _call("scl_col2im_bf16", _p(dcol), _p(dz), B, Tin, Tout, C, k, s, _stream())
 
 
-def conv_weight_pack(w, wk, Co, Ci, k):
-    _call("scl_conv_weight_pack", _p(w), _p(wk), Co, Ci, k, _stream())
+def conv_weight_pack(w, wk, Co, Ci, k, wd=None, stride=1):
+    _call("scl_conv_weight_pack", _p(w), _p(wk), _p(wd), Co, Ci, k, stride, _stream())
 
 
 def conv_weight_unpack_grad(dwk, dw, Co, Ci, k):
