@@ -128,7 +128,8 @@ int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, cons
                       int64_t out_rbstride, int64_t out_off, void* stream);
 /* out_rpb > 0: bf16 output row r goes to element (r / out_rpb) * out_rbstride + (r % out_rpb) * lddx + out_off (per-utterance
  * zero padding kept by the caller) */
-/* sum_dres != 0: `part` rows are [dgamma | dbeta | colsum(dres)] (3*C floats per slab instead of 2*C) — the residual gradient
+/* sum_dres == 1: `part` rows are [dgamma | dbeta | colsum(dres)] (3*C floats per slab instead of 2*C; sum_dres == 2: third row =
+ * colsum of the OUTPUT dx, the bias gradient of the Conv1d in front of a conv-stack LayerNorm) — the residual gradient
  * entering a pre-LN block's LayerNorm backward is the output gradient of the preceding fc2 / out_proj, so its column sum is
  * that layer's bias gradient (fairseq TransformerSentenceEncoderLayer, reached from model/xlsr.py:41) */
 int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, void* stream);

@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { o[i] += r[i]; ar[ch][i] += r[i]; }
                 }
+                if (sum_dres == 2) {      // column sums of the OUTPUT: dx of a conv layer's LayerNorm is d(conv output) => conv bias gradient
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ar[ch][i] += o[i];
+                }
                 if (dx_f32) store8_f32(dx_f32, (int64_t)row * lddx + c, o);
                 if (dx_bf) {
                     // optional per-utterance padding of the bf16 output (zero rows around each utterance's frames, pre-zeroed
@@ -371,7 +375,7 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
                                  int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, int out_rpb, int64_t out_rbstride,
                                  int64_t out_off, void* stream) {
     SCL_REQUIRE(out_rpb == 0 || (dx_bf16 && out_rpb > 0 && (out_rbstride & 7) == 0 && (out_off & 7) == 0), "layernorm_bwd: padded output needs dx_bf16");
-    SCL_REQUIRE(!sum_dres || dres, "layernorm_bwd: sum_dres needs dres");
+    SCL_REQUIRE(sum_dres == 0 || (sum_dres == 1 && dres) || (sum_dres == 2 && !dres), "layernorm_bwd: sum_dres 1 needs dres, 2 excludes it");
     SCL_REQUIRE(dy && x && mean && rstd && gamma && part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SCL_REQUIRE(act == 0 || beta, "layernorm_bwd: gelu variant needs beta");
     SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0,

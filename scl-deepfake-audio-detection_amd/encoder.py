@@ -396,9 +396,9 @@ class Encoder:
             dyp = d["dyp"][i]
             ops.layernorm_bwd(d["dz"][i], d["y"][i], d["cmean"][i], d["crstd"][i], self.b(fe % i + "2.1.weight"),
                               self.b(fe % i + "2.1.bias"), None, None, dyp, d["ln_part"], Mi, C, act=1,
-                              out_rpb=Tout, out_rbstride=Rp * C, out_off=Q * C)
-            self._ln_grads(d, ops.layernorm_bwd_nparts(Mi), C, fe % i + "2.1.weight", fe % i + "2.1.bias")
-            self._bias_grad(d, dyp, B * Rp, C, fe % i + "0.bias")            # the padding rows are zero
+                              out_rpb=Tout, out_rbstride=Rp * C, out_off=Q * C, sum_dres=2)
+            # third partial row = colsum of this LayerNorm backward's output = the Conv1d bias gradient
+            self._ln_grads(d, ops.layernorm_bwd_nparts(Mi), C, fe % i + "2.1.weight", fe % i + "2.1.bias", resid_bias=fe % i + "0.bias")
             dwk = d["dwk"][: C * k * C].view(C, k * C)
             self._wgrad(d, Op(dyp, C, rpb=Tout, rbstride=Rp * C, offset=Q * C), Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), dwk,
                         C, k * C, Mi)

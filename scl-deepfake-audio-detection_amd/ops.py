@@ -173,7 +173,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M
     """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums; [nparts, 3*C] with sum_dres (| colsum(dres)).
     out_rpb > 0: the bf16 output is written with per-utterance row padding (see include/scl_hip.h)."""
     _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, 1 if sum_dres else 0, out_rpb, out_rbstride, out_off, _stream())
+          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, int(sum_dres), out_rpb, out_rbstride, out_off, _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):

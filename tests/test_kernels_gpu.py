@@ -60,6 +60,16 @@ def test_layernorm_fwd_bwd(dev, C, M, xdt, act):
     lnout = torch.full((2 * C,), float("nan"), device=dev); bias_out = torch.full((C,), float("nan"), device=dev)
     ops.colreduce_seg(part3, lnout, nparts, 3 * C, out2=bias_out, split=2 * C)
     assert rel(lnout, both) < 1e-5 and rel(bias_out, dres.sum(0)) < 2e-5
+    # sum mode 2: column sums of the OUTPUT (conv bias gradient), padded bf16 output rows (3 rows per "utterance" of rpb frames)
+    rpb = 5
+    if M % rpb == 0:
+        padded = torch.zeros((M // rpb) * (rpb + 3), C, dtype=torch.bfloat16, device=dev)
+        ops.layernorm_bwd(dy, x, mean, rstd, gamma, beta, None, None, padded, part3, M, C, act=act, sum_dres=2,
+                          out_rpb=rpb, out_rbstride=(rpb + 3) * C, out_off=2 * C)
+        ops.colreduce_seg(part3, lnout, nparts, 3 * C, out2=bias_out, split=2 * C)
+        pv = padded.view(M // rpb, rpb + 3, C)
+        assert rel(pv[:, 2:2 + rpb].reshape(M, C), xr.grad) < 8e-3 and pv[:, :2].abs().max() == 0 and pv[:, 2 + rpb:].abs().max() == 0
+        assert rel(bias_out, xr.grad.sum(0)) < 2e-4
     # bf16 dy variant
     dyb = dy.to(torch.bfloat16)
     ops.layernorm_bwd(dyb, x, mean, rstd, gamma, beta, None, dx_f, None, part, M, C, act=act)
