@@ -281,17 +281,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    // software pipeline over the query steps: the 32-query tile of step u+1 (Q, dO, O rows and LSE) is fetched into registers
+    // while step u is multiplied — one exposed global round trip per workgroup instead of one per step
+    const int sr = threadIdx.x >> 3, sc = threadIdx.x & 7;
+    uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), cv = make_uint4(0, 0, 0, 0);
+    float lq_next = 0.f;
+    auto fetch_tile = [&](int u) {
+        const int q = 32 * u + sr;
+        qv = make_uint4(0, 0, 0, 0); ov = make_uint4(0, 0, 0, 0); cv = make_uint4(0, 0, 0, 0); lq_next = 0.f;
+        if (q < T) {
+            qv = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
+            ov = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+            cv = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+            if (sc == 0) lq_next = lse[((int64_t)b * H + h) * T + q];
+        }
+    };
+    fetch_tile(0);
     for (int u = 0; u < NT2; ++u) {
         __syncthreads();   // previous step's readers are done with the q-tiles / dQ partials (and K/V staging on u == 0)
-        {   // ---- stage 32 queries: Q, dO (both images), LSE, delta
-            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-            const int q = 32 * u + r;
-            uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), cv = make_uint4(0, 0, 0, 0);
-            if (q < T) {
-                qv = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * c);
-                ov = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * c);
-                cv = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * c);
-            }
+        {   // ---- stage the fetched 32 queries: Q, dO (both images), LSE, delta
+            const int r = sr, c = sc;
             *reinterpret_cast<uint4*>(Qk + att_k_off(r, c)) = qv;
             *reinterpret_cast<uint4*>(Qt + att_t_off(r, 8 * c)) = qv;
             *reinterpret_cast<uint4*>(Ok + att_k_off(r, c)) = ov;
@@ -306,8 +315,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
             dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
             if (c == 0) {
                 delS[r] = dot;
-                lseS[r] = q < T ? lse[((int64_t)b * H + h) * T + q] : 0.f;
+                lseS[r] = lq_next;
             }
+            if (u + 1 < NT2) fetch_tile(u + 1);      // in flight during this step's MFMAs
         }
         __syncthreads();
         if (nkt > 0) {
