@@ -146,6 +146,24 @@ def test_adamw_under_the_backward_equals_adamw_after_it(dev, model_kind):
         assert (finals[0][0] - finals[1][0]).abs().max().item() < 5e-3 * 1e-3 + 2.1e-3
 
 
+def test_backward_is_bitwise_reproducible(dev):
+    """Every reduction on the path has a fixed order (split-K slabs, ticket-finished column sums, 4-wave combines, SupCon Gram
+    chunks): the same step from the same state gives the same bits, outputs and all 300+ gradient tensors."""
+    cfg = W.W2VConfig.tiny()
+    m = build(dev, W.init_state(cfg, seed=81), OH.init_head(cfg.embed, seed=82))
+    m.eval()
+    x = (0.1 * torch.randn(5, 9000, generator=torch.Generator().manual_seed(6))).to(dev)
+    y = torch.tensor([1, 1, 0, 0, 0], device=dev)
+    runs = []
+    for _ in range(3):
+        out, feats, emb = m(x)
+        sum(m.loss(out, feats, emb, y, CONF).values()).backward()
+        torch.cuda.synchronize()
+        runs.append((out.clone(), feats.clone(), m.P.grad.clone()))
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+
+
 def test_forward_matches_oracle_on_fresh_input_and_eval_scores(dev):
     cfg = W.W2VConfig.tiny()
     ssl = W.init_state(cfg, seed=21)
