@@ -174,7 +174,7 @@ def main():
                      "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
                      "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
                      "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
-                     "gemm_share_of_step_time": gemm_ms * 1e-3 / dt},
+                     "gemm_share_of_step_time": gemm_ms * 1e-3 / (dt / args.steps)},   # events bracket the last timed step only
     }
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)
