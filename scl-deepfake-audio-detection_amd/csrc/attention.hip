@@ -214,12 +214,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 
 // -----------------------------------------------------------------------------------------------------
-// Backward, one workgroup per (utterance, head), 4 waves, T <= 224.  Wave w OWNS keys 64w..64w+63 and keeps
-// dK^T and dV^T of those keys in 128 accumulator registers while the workgroup sweeps the queries 32 at a time:
+// Backward, one workgroup per (utterance, head), T <= 224.  A wave OWNS a block of keys and keeps dK^T and dV^T of those keys
+// in accumulator registers while the workgroup sweeps the queries 32 at a time:
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T         (lane owns one key column, registers hold 4 queries)
 //   P = exp(scale*S - LSE[q]),  dS = P * (dP - delta[q]),  delta[q] = <dO[q], O[q]>   (computed here, in the tile loader)
 //   dV^T += dO^T P,  dK^T += Q^T dS                (P / dS accumulators ARE the B operands; dO^T / Q^T by transposed LDS reads)
-//   dQ    = dS K                                   (dS crosses LDS once per wave; the 4 waves' partials are summed in fixed order)
+//   dQ    = dS K                                   (dS crosses LDS once)
 // Scores, probabilities and their gradients never touch HBM.  dQ/dK carry the softmax scale.
 // -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8 att_frag_tr_nat(const char* tile, int base, int dt, int lane) {   // k = base + 8g + 0..7
@@ -237,9 +237,23 @@ __device__ __forceinline__ bf16x8 att_pack8(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bf16x8, pk);
 }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
-                                                          const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+// -----------------------------------------------------------------------------------------------------
+// The launched form: 8 waves, so that TWO waves share each SIMD (a first 4-wave form — 64 keys per wave, 388 registers, one wave
+// per SIMD, per-wave f32 dQ partials summed through LDS — exposed every LDS / global latency: 8 % MFMA busy, 90 us; this: 55 us):
+//   * wave w OWNS keys 32w..32w+31: dK^T / dV^T of those keys in 64 accumulators (was 128), P / dS of 32 queries x 32 keys in 32;
+//   * dS of all waves goes to ONE LDS image of eight [32 q][32 keys] sub-images (sub-image = owning wave = one 32-deep k step);
+//   * dQ is produced without partial sums: wave w computes the [16 q x 16 d] output tile (q-tile w&1, d-tile w>>1) over ALL keys
+//     (<= 8 MFMAs) and stores it, so the 32 KiB of per-wave f32 partials and the 4-wave combine pass are gone;
+//   * Q is staged by threads 0-255, dO / O / delta by threads 256-511, both prefetched one step ahead.
+// LDS: K (row image), K (tr image), V (row image) + 16 KiB query tiles + 16 KiB dS = 116 KiB for T = 199.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [32 q][32 keys], 64-B rows, 16-B chunk ^= (q>>2)&3
+    return q * 64 + ((((key32 >> 3) ^ (q >> 2)) & 3) << 4) + ((key32 & 7) << 1);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -251,12 +265,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
     char* Qt = Qk + 4096;
     char* Ok = Qt + 4096;
     char* Ot = Ok + 4096;
-    char* dSs = Ot + 4096;                 // [4 waves][32 q][128 B]
-    float* dQp = reinterpret_cast<float*>(dSs + 4 * 4096);   // [4 waves][32 q][64 d]
-    float* lseS = dQp + 4 * 32 * 64;       // [32]
+    char* dSs = Ot + 4096;                 // [8 waves][32 q][64 B]
+    float* lseS = reinterpret_cast<float*>(dSs + 8 * 2048);   // [32]
     float* delS = lseS + 32;               // [32]
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
-    for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+    for (int idx = threadIdx.x; idx < rows * 8; idx += 512) {
         const int key = idx >> 3, c = idx & 7;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (key < T) {
@@ -268,44 +281,45 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
         *reinterpret_cast<uint4*>(Vk + att_k_off(key, c)) = vv;
     }
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
     const int lc = lane & 15, g = lane >> 4;
-    int nkt = NT - 4 * wave; nkt = nkt < 0 ? 0 : (nkt > 4 ? 4 : nkt);     // key tiles this wave owns
-    const int nks = (rows - 64 * wave) >= 64 ? 2 : ((rows - 64 * wave) >= 32 ? 1 : 0);   // 32-key steps inside the K image
-    char* dSw = dSs + wave * 4096;
-    float* dQw = dQp + wave * 32 * 64;
+    int nkt = NT - 2 * wave; nkt = nkt < 0 ? 0 : (nkt > 2 ? 2 : nkt);     // 16-key tiles this wave owns
+    char* dSw = dSs + wave * 2048;
 
-    f32x4 dVt[4][4], dKt[4][4];
+    f32x4 dVt[4][2], dKt[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < 2; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // software pipeline over the query steps: the 32-query tile of step u+1 (Q, dO, O rows and LSE) is fetched into registers
-    // while step u is multiplied — one exposed global round trip per workgroup instead of one per step
-    const int sr = threadIdx.x >> 3, sc = threadIdx.x & 7;
-    uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), cv = make_uint4(0, 0, 0, 0);
+    // staging roles: threads 0..255 carry Q, threads 256..511 carry dO + O (for delta) + LSE; one step ahead in registers
+    const int half = threadIdx.x >> 8, st = threadIdx.x & 255;
+    const int sr = st >> 3, sc = st & 7;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
     float lq_next = 0.f;
     auto fetch_tile = [&](int u) {
         const int q = 32 * u + sr;
-        qv = make_uint4(0, 0, 0, 0); ov = make_uint4(0, 0, 0, 0); cv = make_uint4(0, 0, 0, 0); lq_next = 0.f;
+        v0 = make_uint4(0, 0, 0, 0); v1 = make_uint4(0, 0, 0, 0); lq_next = 0.f;
         if (q < T) {
-            qv = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
-            ov = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
-            cv = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
-            if (sc == 0) lq_next = lse[((int64_t)b * H + h) * T + q];
+            if (half == 0) {
+                v0 = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
+            } else {
+                v0 = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+                v1 = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+                if (sc == 0) lq_next = lse[((int64_t)b * H + h) * T + q];
+            }
         }
     };
     fetch_tile(0);
     for (int u = 0; u < NT2; ++u) {
-        __syncthreads();   // previous step's readers are done with the q-tiles / dQ partials (and K/V staging on u == 0)
-        {   // ---- stage the fetched 32 queries: Q, dO (both images), LSE, delta
-            const int r = sr, c = sc;
-            *reinterpret_cast<uint4*>(Qk + att_k_off(r, c)) = qv;
-            *reinterpret_cast<uint4*>(Qt + att_t_off(r, 8 * c)) = qv;
-            *reinterpret_cast<uint4*>(Ok + att_k_off(r, c)) = ov;
-            *reinterpret_cast<uint4*>(Ot + att_t_off(r, 8 * c)) = ov;
-            const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w}, cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        __syncthreads();   // A: previous step's readers are done with the query tiles and the dS image (and K/V staging on u == 0)
+        if (half == 0) {
+            *reinterpret_cast<uint4*>(Qk + att_k_off(sr, sc)) = v0;
+            *reinterpret_cast<uint4*>(Qt + att_t_off(sr, 8 * sc)) = v0;
+        } else {
+            *reinterpret_cast<uint4*>(Ok + att_k_off(sr, sc)) = v0;
+            *reinterpret_cast<uint4*>(Ot + att_t_off(sr, 8 * sc)) = v0;
+            const unsigned ow[4] = {v0.x, v0.y, v0.z, v0.w}, cw[4] = {v1.x, v1.y, v1.z, v1.w};
             float dot = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -313,129 +327,99 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
                 dot += __uint_as_float(ow[k] & 0xFFFF0000u) * __uint_as_float(cw[k] & 0xFFFF0000u);
             }
             dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-            if (c == 0) {
-                delS[r] = dot;
-                lseS[r] = lq_next;
-            }
-            if (u + 1 < NT2) fetch_tile(u + 1);      // in flight during this step's MFMAs
+            if (sc == 0) { delS[sr] = dot; lseS[sr] = lq_next; }
         }
-        __syncthreads();
-        if (nkt > 0) {
-            bf16x8 qa[2][2], oa[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) { qa[a][ks] = att_frag_rows(Qk, a, ks, lane); oa[a][ks] = att_frag_rows(Ok, a, ks, lane); }
-            float lq[2][4], dq_[2][4];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r]; dq_[a][r] = delS[16 * a + 4 * g + r]; }
-            f32x4 P[2][4], dS[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) { P[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dS[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (j < nkt) {
-                    const int kb = 4 * wave + j;
-                    const bf16x8 k0 = att_frag_rows(Kk, kb, 0, lane), k1 = att_frag_rows(Kk, kb, 1, lane);
-                    const bf16x8 v0 = att_frag_rows(Vk, kb, 0, lane), v1 = att_frag_rows(Vk, kb, 1, lane);
-                    const int key = 16 * kb + lc;
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][0], k0, sv, 0, 0, 0);
-                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][1], k1, sv, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][0], v0, dp, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][1], v1, dp, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int qq = 32 * u + 16 * a + 4 * g + r;
-                            const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
-                            P[a][j][r] = p;
-                            dS[a][j][r] = p * (dp[r] - dq_[a][r]);
-                        }
-                    }
-                }
-            }
-            // ---- dV^T += dO^T P ; dK^T += Q^T dS   (k = 32 queries of this step)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 ot = att_frag_tr(Ot, 0, 16, dt, lane);
-                const bf16x8 qt = att_frag_tr(Qt, 0, 16, dt, lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < nkt) {
-                        dVt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, att_pack8(P[0][j], P[1][j]), dVt[dt][j], 0, 0, 0);
-                        dKt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, att_pack8(dS[0][j], dS[1][j]), dKt[dt][j], 0, 0, 0);
-                    }
-                }
-            }
-            // ---- dS -> LDS (row-read image [32 q][64 keys]) for the dQ product
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ql = 16 * a + 4 * g + r, kl = 16 * j + lc;
-                        *reinterpret_cast<bf16_t*>(dSw + att_k_off(ql, kl >> 3) + ((kl & 7) << 1)) = f2bf(dS[a][j][r]);
-                    }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's dS writes are in LDS before it reads them back
-        __builtin_amdgcn_wave_barrier();
+        if (u + 1 < NT2) fetch_tile(u + 1);      // in flight during this step's MFMAs
+        __syncthreads();   // B
         {
-            f32x4 dq[2][4];
+            f32x4 P[2][2], dS[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[a][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) { P[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dS[a][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (nkt > 0) {
+                bf16x8 qa[2][2], oa[2][2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (ks < nks) {
-                        const bf16x8 d0 = att_frag_rows(dSw, 0, ks, lane), d1 = att_frag_rows(dSw, 1, ks, lane);
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            const bf16x8 kf = att_frag_tr_nat(Kt, 64 * wave + 32 * ks, dt, lane);
-                            dq[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, kf, dq[0][dt], 0, 0, 0);
-                            dq[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, kf, dq[1][dt], 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) { qa[a][ks] = att_frag_rows(Qk, a, ks, lane); oa[a][ks] = att_frag_rows(Ok, a, ks, lane); }
+                float lq[2][4], dq_[2][4];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r]; dq_[a][r] = delS[16 * a + 4 * g + r]; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j < nkt) {
+                        const int kb = 2 * wave + j;
+                        const bf16x8 k0 = att_frag_rows(Kk, kb, 0, lane), k1 = att_frag_rows(Kk, kb, 1, lane);
+                        const bf16x8 vv0 = att_frag_rows(Vk, kb, 0, lane), vv1 = att_frag_rows(Vk, kb, 1, lane);
+                        const int key = 16 * kb + lc;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][0], k0, sv, 0, 0, 0);
+                            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][1], k1, sv, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][0], vv0, dp, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[a][1], vv1, dp, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int qq = 32 * u + 16 * a + 4 * g + r;
+                                const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
+                                P[a][j][r] = p;
+                                dS[a][j][r] = p * (dp[r] - dq_[a][r]);
+                            }
+                        }
+                    }
+                }
+                // ---- dV^T += dO^T P ; dK^T += Q^T dS   (k = the 32 queries of this step)
+                bf16x8 pP[2], pS[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { pP[j] = att_pack8(P[0][j], P[1][j]); pS[j] = att_pack8(dS[0][j], dS[1][j]); }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 ot = att_frag_tr(Ot, 0, 16, dt, lane);
+                    const bf16x8 qt = att_frag_tr(Qt, 0, 16, dt, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (j < nkt) {
+                            dVt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pP[j], dVt[dt][j], 0, 0, 0);
+                            dKt[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pS[j], dKt[dt][j], 0, 0, 0);
                         }
                     }
                 }
             }
-            // partial dQ[q = 16a + 4g + r][d = 16dt + lc] of this wave's keys
+            // ---- dS -> this wave's sub-image [32 q][32 keys] (zeros for keys it does not own inside the K image)
+            if (2 * wave < 2 * NT2) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dQw[(16 * a + 4 * g + r) * 64 + 16 * dt + lc] = dq[a][dt][r];
-        }
-        __syncthreads();
-        {   // ---- sum the 4 waves' partials (fixed order), scale, store dQ
-            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-            const int q = 32 * u + r;
-            if (q < T) {
-                float acc[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-                for (int w = 0; w < 4; ++w) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(dQp + (w * 32 + r) * 64 + 8 * c);
-                    const float4 x1 = *reinterpret_cast<const float4*>(dQp + (w * 32 + r) * 64 + 8 * c + 4);
-                    acc[0] += x0.x; acc[1] += x0.y; acc[2] += x0.z; acc[3] += x0.w; acc[4] += x1.x; acc[5] += x1.y; acc[6] += x1.z; acc[7] += x1.w;
-                }
-                uint4 o;
-                o.x = pack_bf2(acc[0] * scale, acc[1] * scale); o.y = pack_bf2(acc[2] * scale, acc[3] * scale);
-                o.z = pack_bf2(acc[4] * scale, acc[5] * scale); o.w = pack_bf2(acc[6] * scale, acc[7] * scale);
-                *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * T + q) * 3 * E + h * ATT_D + 8 * c) = o;
+                        for (int r = 0; r < 4; ++r)
+                            *reinterpret_cast<bf16_t*>(dSw + att_s_off(16 * a + 4 * g + r, 16 * j + lc)) = f2bf(dS[a][j][r]);
             }
+        }
+        __syncthreads();   // C: every wave's dS is in LDS
+        {   // ---- dQ tile [16 q (tile qa_) x 16 d (tile dt)] over all keys; lane ends up with 4 consecutive d of one query
+            const int qa_ = wave & 1, dt = wave >> 1;
+            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < NT2; ++ks) {
+                const int row = 16 * qa_ + lc;
+                const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(dSs + ks * 2048 + row * 64 + (((g ^ (row >> 2)) & 3) << 4));
+                const bf16x8 kf = att_frag_tr_nat(Kt, 32 * ks, dt, lane);
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq, 0, 0, 0);      // D[d = 4g + r][q = lc]
+            }
+            const int q = 32 * u + 16 * qa_ + lc;
+            if (q < T)
+                *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * T + q) * 3 * E + h * ATT_D + 16 * dt + 4 * g) =
+                    make_uint2(pack_bf2(dq[0] * scale, dq[1] * scale), pack_bf2(dq[2] * scale, dq[3] * scale));
         }
     }
-    // ---- dK, dV of this wave's keys: lane owns key 16(4w+j)+lc, d = 16dt + 4g + 0..3
+    // ---- dK, dV of this wave's keys: lane owns key 16(2w+j)+lc, d = 16dt + 4g + 0..3
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int key = 16 * (4 * wave + j) + lc;
+    for (int j = 0; j < 2; ++j) {
+        const int key = 16 * (2 * wave + j) + lc;
         if (j < nkt && key < T) {
             bf16_t* dst = dqkv + ((int64_t)b * T + key) * 3 * E + h * ATT_D + 4 * g;
 #pragma unroll
@@ -465,13 +449,13 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0, "attn_bwd: bad args");
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 224, "attn_bwd: fused path needs head dim 64 and T <= 224 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
-    const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 4 * 4096 + 4 * 32 * 64 * 4 + 64 * 4;
+    const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 8 * 2048 + 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+    hipLaunchKernelGGL(attn_bwd8_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, H, scale);
     return scl_check_launch("scl_attn_bwd");
 }
