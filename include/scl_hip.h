@@ -165,7 +165,8 @@ int scl_col2im_bf16(const void* dcol, void* dz, int B, int Tin, int Tout, int C,
  * GEMM per phase with overlapping A rows, and no [M, k*C] column buffer / col2im pass exists (Conv1d backward, layers 1..6) */
 int scl_conv_weight_pack(const float* w, void* wk, void* wd, int Co, int Ci, int k, int stride, void* stream);
 int scl_conv_weight_unpack_grad(const float* dwk, float* dw, int Co, int Ci, int k, void* stream);
-/* torch.nn.utils.weight_norm(dim=2) of encoder.pos_conv.0 + GEMM layouts (forward and flipped dgrad) */
+/* torch.nn.utils.weight_norm(dim=2) of encoder.pos_conv.0 + GEMM layouts (forward and flipped dgrad).  K must divide 256.
+ * sdot_ws: K + E*K floats (per-tap sums, then per-output-channel partials). */
 int scl_posconv_weight_pack(const float* v, const float* g, float* norm, void* wf, void* wd, int E, int Cg, int K, void* stream);
 int scl_posconv_weight_bwd(const float* dwf, const float* v, const float* g, const float* norm, float* sdot_ws,
                            float* dv, float* dg, int E, int Cg, int K, void* stream);

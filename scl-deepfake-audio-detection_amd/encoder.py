@@ -100,7 +100,7 @@ class Encoder:
         # backward-data operands of the phase-split transposed convolution ([k tap blocks][C][C], see scl_conv_weight_pack)
         self.wd = [None] + [bf(cfg.conv_kernels[i] * C, C) for i in range(1, len(cfg.conv_kernels))]
         self.pos_wf, self.pos_wd, self.pos_norm = bf(G, Cg, K * Cg), bf(G, Cg, K * Cg), f32(K)
-        self.ws_small = f32(max(K, 16))
+        self.ws_small = f32(K + E * K)      # weight-norm backward: per-tap sums + per-output-channel partials
         self.on_grads_ready = None   # callback(lo_offset): every gradient at flat offset >= lo_offset is final (DP overlap)
 
     # ---- weights ---------------------------------------------------------------------------------

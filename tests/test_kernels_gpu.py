@@ -167,8 +167,8 @@ def test_pad_rows_col2im_weight_packs(dev):
     assert torch.equal(dw, dwk.view(Co, k, Ci).permute(0, 2, 1))
 
 
-def test_posconv_weight_norm_pack_and_bwd(dev):
-    E, G, K = 32, 4, 8
+@pytest.mark.parametrize("E,G,K", [(32, 4, 8), (64, 4, 16), (1024, 16, 128)])
+def test_posconv_weight_norm_pack_and_bwd(dev, E, G, K):
     Cg = E // G
     v = torch.randn(E, Cg, K, generator=g(1)).to(dev)
     gg = (1 + 0.3 * torch.randn(1, 1, K, generator=g(2))).to(dev)
@@ -184,7 +184,7 @@ def test_posconv_weight_norm_pack_and_bwd(dev):
     dwf = torch.randn(G, Cg, K * Cg, generator=g(3)).to(dev)
     dw_torch = dwf.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(E, Cg, K)
     w.backward(dw_torch)
-    dv = torch.empty_like(v); dg = torch.empty(K, device=dev); ws = torch.empty(K, device=dev)
+    dv = torch.empty_like(v); dg = torch.empty(K, device=dev); ws = torch.empty(K + E * K, device=dev)
     ops.posconv_weight_bwd(dwf, v, gg, norm, ws, dv, dg, E, Cg, K)
     assert rel(dv, vr.grad) < 1e-4 and rel(dg, gr.grad.view(-1)) < 1e-4
 
