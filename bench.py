@@ -169,7 +169,7 @@ def main():
                    "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
         "final_loss": loss_val,
         "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
-        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{dma,big,}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{dma,}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
                      "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,

@@ -74,7 +74,8 @@ typedef struct SclOperand {
 #define SCL_GEMM_HAS_C2   0x00000040  /* also store the pre-activation value */
 #define SCL_GEMM_DROPOUT  0x00000080  /* multiply by keep-mask(seed,row,col)/(1-p) after act / grad-mul */
 #define SCL_GEMM_NO_DMA   0x00100000  /* force the register-staged kernel (testing / A-B comparison) */
-#define SCL_GEMM_NO_BIG   0x00200000  /* do not pick the 256x128 / 3-stage variant */
+#define SCL_GEMM_NO_BIG   0x00200000  /* never the 256x128 / 3-stage variant */
+#define SCL_GEMM_FORCE_BIG 0x04000000 /* pick the 256x128 / 3-stage variant (A-B comparison; not chosen automatically) */
 #define SCL_GEMM_NO_P8    0x00400000  /* do not pick the 256x256 ping-pong variant */
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */

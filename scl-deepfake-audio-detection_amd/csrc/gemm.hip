@@ -919,9 +919,11 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
         const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
         const bool dma = a_whole && b_whole && !(d.flags & SCL_GEMM_NO_DMA);
-        // 256x128 tiles when the problem fills the chip with them (one 8-wave block per CU)
+        // 256x128 tiles, one 8-wave block per CU, 3-stage ring: opt-in (SCL_GEMM_FORCE_BIG).  A/B in one process on MI355X: equal
+        // to the 128x128 kernel on the conv-stack shapes (+-2 %), 2.5 % slower end to end at batch 64 where it used to be picked
+        // for the encoder linears as well; bit-identical results either way.
         const long long big_tiles = (long long)((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN) * zdim;
-        const bool big = dma && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 512 && d.N >= 128 && d.K >= 192 && big_tiles >= 1000;
+        const bool big = dma && (d.flags & SCL_GEMM_FORCE_BIG) && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 256 && d.K >= 192 && big_tiles >= 1;
         // 256x256 ping-pong tiles: opt-in (SCL_GEMM_FORCE_P8).  Measured on MI355X (tools/gemm_square.py, tools/gemm_p8_ab.py):
         // 1093 / 1308 TFLOP/s at 4096^3 / 8192^3 (128x128 kernel: 811 / 1041), but on the encoder's M = 6368, K = 1024 shapes
         // 400 tiles = 1.56 rounds of 256 CUs and a 16-step K loop leave it behind the 128x128 kernel (fc1 fwd 576 vs 694).

@@ -43,6 +43,7 @@ GEMM_A_T, GEMM_B_T, GEMM_C_F32, GEMM_C2_F32, GEMM_R_F32 = 1, 2, 4, 8, 16
 GEMM_HAS_BIAS, GEMM_HAS_C2, GEMM_DROPOUT = 0x20, 0x40, 0x80
 GEMM_NO_DMA = 0x00100000
 GEMM_NO_BIG = 0x00200000
+GEMM_FORCE_BIG = 0x04000000
 GEMM_NO_P8 = 0x00400000
 GEMM_FORCE_P8 = 0x00800000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16

@@ -87,7 +87,7 @@ class Op:
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False):
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
@@ -121,6 +121,8 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
         flags |= L.GEMM_NO_DMA
     if no_big:
         flags |= L.GEMM_NO_BIG
+    if force_big:
+        flags |= L.GEMM_FORCE_BIG
     if no_p8:
         flags |= L.GEMM_NO_P8
     if force_p8:

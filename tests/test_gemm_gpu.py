@@ -83,16 +83,16 @@ def test_lds_dma_staging_equals_register_staging(dev, a_t, b_t, M, N, K):
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(5128, 1280, 264), (6368, 1024, 1024), (2600, 2560, 192)])
 def test_big_tile_ring_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K):
-    """Problems that fill the chip take the 256x128 / 3-stage LDS-DMA ring kernel; every output element sums K in the
-    same order as in the 128x128 kernels, so the results must be bit-identical."""
+    """The opt-in 256x128 / 3-stage LDS-DMA ring kernel: every output element sums K in the same order as in the 128x128
+    kernels, so the results must be bit-identical."""
     A = _rand((M, K), dev, 31, 0.3); B = _rand((N, K), dev, 32, 0.3)
     opA = ops.Op(A.t().contiguous(), M) if a_t else ops.Op(A, K)
     opB = ops.Op(B.t().contiguous(), N) if b_t else ops.Op(B, K)
     bias = torch.randn(N, device=dev)
     outs = []
-    for no_big in (False, True):
+    for force_big in (True, False):
         C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
-        ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=1, no_big=no_big)
+        ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=1, force_big=force_big)
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     _close(outs[0], torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 8e-3, "big a_t=%s b_t=%s" % (a_t, b_t))

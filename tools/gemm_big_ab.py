@@ -30,10 +30,10 @@ for i in range(1, 5):
     for name, fn in cases.items():
         fl = 2.0 * Mi * C * k * C
         res = {}
-        for var, kw in (("t128", dict(no_big=True)), ("big", dict())):
+        for var, kw in (("t128", dict(no_big=True)), ("big", dict(force_big=True))):
             fn(kw); torch.cuda.synchronize()
         for _ in range(5):
-            for var, kw in (("t128", dict(no_big=True)), ("big", dict())):
+            for var, kw in (("t128", dict(no_big=True)), ("big", dict(force_big=True))):
                 res.setdefault(var, []).append(run(lambda: fn(kw)))
         med = {v: sorted(x)[len(x) // 2] for v, x in res.items()}
         print("conv%d %-5s M=%6d | t128 %7.1f us %5.0f TF | big %7.1f us %5.0f TF | big/t128 speed x%.2f" % (

@@ -23,7 +23,7 @@ for S in (4096, 8192):
         A, Bm = bf(S, S), bf(S, S)
         C = torch.zeros(S, S, dtype=torch.bfloat16, device=dev)
         res = []
-        for var, kw in (("t128", dict(no_p8=True, no_big=True)), ("big", dict(no_p8=True)), ("p8", dict(force_p8=True))):
+        for var, kw in (("t128", dict(no_p8=True, no_big=True)), ("big", dict(no_p8=True, force_big=True)), ("p8", dict(force_p8=True))):
             fn = lambda kw=kw: ops.gemm(Op(A, S), Op(Bm, S), C, S, S, S, a_t=at, b_t=bt, **kw)
             fn(); torch.cuda.synchronize()
             t = sorted(run(fn) for _ in range(3))[1]
