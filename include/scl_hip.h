@@ -204,6 +204,21 @@ int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float
                   int stride, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* AASIST graph attention: pairwise attention score, fused (model/wav2vec2_aasist.py:107-135,   */
+/* 259-291: att_proj(x_i * x_j) -> tanh -> dot with att_weight{,11,22,12})                      */
+/* ------------------------------------------------------------------------------------------ */
+/* s[b][i][j] = sum_o tanh(sum_d W[o][d] x[b][i][d] x[b][j][d] + bias[o]) * a[t(i,j)][o];  t = 0 (i, j < n1), 1 (i, j >= n1),
+ * 2 (mixed); the homogeneous layer passes n1 = N and only a[0] is used.  All f32.  x [B,N,D], W [Do,D], a [3,Do], s [B,N,N];
+ * D in {32, 64}, Do <= 64, N <= 128.  Temperature and softmax stay with the caller. */
+int scl_gat_score_nblocks(int N);
+int scl_gat_score_fwd(const float* x, const float* W, const float* bias, const float* a, float* s, int B, int N, int D, int Do, int n1,
+                      void* stream);
+/* backward: dP f32 [B, N*N, D] scratch; part f32 [B * scl_gat_score_nblocks(N)][Do*D + 4*Do] per-block partial sums
+ * (dW | dbias | da[0] | da[1] | da[2]) for the caller to sum over the first dimension; dx f32 [B, N, D] */
+int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const float* a, const float* ds, float* dP, float* part, float* dx,
+                      int B, int N, int D, int Do, int n1, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
 /* ------------------------------------------------------------------------------------------ */
 int scl_supcon_nchunks(int64_t K);

@@ -8,9 +8,20 @@ load: model/wav2vec2_aasist.py:62-155 (GraphAttentionLayer), :158-332 (HtrgGraph
 :377-433 (Residual_block), :436-604 (Model).  Reference quirks kept on purpose: Residual_block applies conv1 to its INPUT
 (the bn1+SELU result is discarded, :414-420); the temporal/spectral attention pools share one 1x1-conv score map.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+# On the GPU the pairwise attention scores (att_proj over every node pair, tanh, dot with att_weight*) come from the fused HIP
+# kernels of csrc/gat.hip (fp32, same numbers to ~1e-6) instead of [B,N,N,D] tensors and library GEMMs; SCL_AASIST_FUSED_GAT=0 or
+# CPU tensors keep the plain torch formulation below (which is what tests/test_aasist_cpu.py pins to the reference).
+FUSED_GAT = os.environ.get("SCL_AASIST_FUSED_GAT", "1") != "0"
+
+
+def _fused_ok(x, lin):
+    return FUSED_GAT and x.is_cuda and x.dtype == torch.float32 and lin.in_features in (32, 64) and lin.out_features <= 64 and x.shape[1] <= 128
 
 UPSTREAM_AASIST = {"filts": [128, [1, 32], [32, 32], [32, 64], [64, 64]], "gat_dims": [64, 32],
                    "pool_ratios": [0.5, 0.5, 0.5, 0.5], "temperatures": [2.0, 2.0, 100.0, 100.0], "nclasses": 2}
@@ -40,8 +51,12 @@ class GraphAttentionLayer(nn.Module):
 
     def forward(self, x):
         x = self.input_drop(x)
-        att = torch.tanh(self.att_proj(_pairwise(x))) @ self.att_weight          # [B, N, N, 1]
-        att = F.softmax(att / self.temp, dim=-2).squeeze(-1)
+        if _fused_ok(x, self.att_proj):
+            from .gat import gat_score
+            att = F.softmax(gat_score(x, self.att_proj.weight, self.att_proj.bias, self.att_weight.t()) / self.temp, dim=-1)
+        else:
+            att = torch.tanh(self.att_proj(_pairwise(x))) @ self.att_weight          # [B, N, N, 1]
+            att = F.softmax(att / self.temp, dim=-2).squeeze(-1)
         y = self.proj_with_att(att @ x) + self.proj_without_att(x)
         y = self.bn(y.reshape(-1, y.shape[-1])).view_as(y)
         return F.selu(y)
@@ -73,13 +88,18 @@ class HtrgGraphAttentionLayer(nn.Module):
             master = x.mean(dim=1, keepdim=True)
         x = self.input_drop(x)
         # heterogeneous attention map: one weight vector per (type, type) block
-        h = torch.tanh(self.att_proj(_pairwise(x)))                                # [B, N, N, D']
-        board = torch.zeros_like(h[..., :1])
-        board[:, :n1, :n1] = h[:, :n1, :n1] @ self.att_weight11
-        board[:, n1:, n1:] = h[:, n1:, n1:] @ self.att_weight22
-        board[:, :n1, n1:] = h[:, :n1, n1:] @ self.att_weight12
-        board[:, n1:, :n1] = h[:, n1:, :n1] @ self.att_weight12
-        att = F.softmax(board / self.temp, dim=-2).squeeze(-1)
+        if _fused_ok(x, self.att_proj):
+            from .gat import gat_score
+            a = torch.cat([self.att_weight11, self.att_weight22, self.att_weight12], dim=1).t()      # [3, D']
+            att = F.softmax(gat_score(x, self.att_proj.weight, self.att_proj.bias, a, n1) / self.temp, dim=-1)
+        else:
+            h = torch.tanh(self.att_proj(_pairwise(x)))                                # [B, N, N, D']
+            board = torch.zeros_like(h[..., :1])
+            board[:, :n1, :n1] = h[:, :n1, :n1] @ self.att_weight11
+            board[:, n1:, n1:] = h[:, n1:, n1:] @ self.att_weight22
+            board[:, :n1, n1:] = h[:, :n1, n1:] @ self.att_weight12
+            board[:, n1:, :n1] = h[:, n1:, :n1] @ self.att_weight12
+            att = F.softmax(board / self.temp, dim=-2).squeeze(-1)
         # master node: attention of every node towards the master
         am = torch.tanh(self.att_projM(x * master)) @ self.att_weightM             # [B, N, 1]
         am = F.softmax(am / self.temp, dim=-2)

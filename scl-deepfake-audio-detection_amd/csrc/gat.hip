@@ -1,0 +1,246 @@
+// gat.hip — the pairwise attention score of the AASIST graph-attention layers, forward and backward, fused.
+//
+//   s[b][i][j] = sum_o tanh( sum_d W[o][d] * x[b][i][d] * x[b][j][d] + bias[o] ) * a_t(i,j)[o]
+//
+// is what GraphAttentionLayer._derive_att_map / HtrgGraphAttentionLayer._derive_att_map compute before the temperature and
+// the softmax (model/wav2vec2_aasist.py:107-135, 259-291): `att_proj` applied to the element-wise product of every node
+// pair, tanh, and a dot with `att_weight` — for the heterogeneous layer one of three vectors chosen by the types of the
+// two nodes (a11 both < n1, a22 both >= n1, a12 mixed).  The reference materialises [B, N, N, D] and [B, N, N, D'] tensors
+// and runs fp32 library GEMMs with M = B*N*N rows on them (15 TFLOP/s, ~6 ms of the 16 ms the torch-composed back-end
+// costs per step); here a thread owns one node pair, W / x live in LDS, and nothing of size N*N*D ever reaches HBM in the
+// forward.  All arithmetic is fp32 (the back-end's parity bar is the fp32 one).
+//
+// Backward (given ds): recompute h per pair, then
+//   d a_t[o]  = sum_{pairs of type t} ds * h_o                       (wave reductions -> per-block partials)
+//   d pre_o   = ds * a_t[o] * (1 - h_o^2);  d bias[o] = sum d pre_o
+//   d W[o][d] = sum_pairs d pre_o * x_i[d] x_j[d]                    (d pre tile in LDS, 16 outputs per thread)
+//   d p[d]    = sum_o d pre_o W[o][d]  -> dP[b][i][j][d] in HBM (the only N*N*D tensor), gathered by a second kernel into
+//   d x_i[d]  = sum_j (dP[i][j][d] + dP[j][i][d]) * x_j[d]           (deterministic: no atomics anywhere)
+#include "common.h"
+
+namespace {
+
+constexpr int GAT_MAXN = 128;     // nodes per graph
+constexpr int GAT_PAIRS = 256;    // pairs (= threads) per block
+
+template <int D>
+struct GatSmem {
+    // W [Do][D] | bias [Do] | a [3][Do] | x [N][D+1]
+    __device__ static float* w(float* s) { return s; }
+    __device__ static float* bias(float* s, int Do) { return s + Do * D; }
+    __device__ static float* a(float* s, int Do) { return s + Do * D + Do; }
+    __device__ static float* x(float* s, int Do) { return s + Do * D + 4 * Do; }
+    __host__ __device__ static size_t floats(int Do, int N) { return (size_t)Do * D + 4 * Do + (size_t)N * (D + 1); }
+};
+
+template <int D>
+__device__ __forceinline__ void gat_stage(float* sm, const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                          const float* __restrict__ a, int b, int N, int Do) {
+    float* w = GatSmem<D>::w(sm);
+    for (int i = threadIdx.x; i < Do * D; i += blockDim.x) w[i] = W[i];
+    float* bs = GatSmem<D>::bias(sm, Do);
+    float* as = GatSmem<D>::a(sm, Do);
+    for (int i = threadIdx.x; i < Do; i += blockDim.x) bs[i] = bias[i];
+    for (int i = threadIdx.x; i < 3 * Do; i += blockDim.x) as[i] = a[i];
+    float* xs = GatSmem<D>::x(sm, Do);
+    const float* xb = x + (int64_t)b * N * D;
+    for (int i = threadIdx.x; i < N * D; i += blockDim.x) xs[(i / D) * (D + 1) + (i % D)] = xb[i];
+}
+
+__device__ __forceinline__ int gat_type(int i, int j, int n1) { return (i < n1) == (j < n1) ? (i < n1 ? 0 : 1) : 2; }
+
+__device__ __forceinline__ float gat_tanh(float v) {
+    // tanh(v) = 1 - 2 / (exp(2v) + 1): |err| < 2 ulp of fp32 over the whole range, saturates cleanly
+    const float e = __expf(2.0f * v);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+template <int D>
+__global__ __launch_bounds__(GAT_PAIRS) void gat_score_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, const float* __restrict__ a,
+                                                                  float* __restrict__ s, int N, int Do, int n1) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y;
+    gat_stage<D>(sm, x, W, bias, a, b, N, Do);
+    __syncthreads();
+    const int q = blockIdx.x * GAT_PAIRS + threadIdx.x;
+    if (q >= N * N) return;
+    const int i = q / N, j = q - i * N;
+    const float* w = GatSmem<D>::w(sm);
+    const float* bs = GatSmem<D>::bias(sm, Do);
+    const float* at = GatSmem<D>::a(sm, Do) + gat_type(i, j, n1) * Do;
+    const float* xi = GatSmem<D>::x(sm, Do) + i * (D + 1);
+    const float* xj = GatSmem<D>::x(sm, Do) + j * (D + 1);
+    float p[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) p[d] = xi[d] * xj[d];
+    float acc = 0.f;
+    for (int o = 0; o < Do; ++o) {
+        float pre = bs[o];
+        const float4* wr = reinterpret_cast<const float4*>(w + o * D);
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4) {
+            const float4 ww = wr[d4];
+            pre += ww.x * p[4 * d4] + ww.y * p[4 * d4 + 1] + ww.z * p[4 * d4 + 2] + ww.w * p[4 * d4 + 3];
+        }
+        acc += gat_tanh(pre) * at[o];
+    }
+    s[(int64_t)b * N * N + q] = acc;
+}
+
+// part[blk] = [ dW (Do*D) | dbias (Do) | da (3*Do) ] ; dP[b][q][d]
+template <int D>
+__global__ __launch_bounds__(GAT_PAIRS) void gat_score_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, const float* __restrict__ a,
+                                                                  const float* __restrict__ ds, float* __restrict__ dP,
+                                                                  float* __restrict__ part, int N, int Do, int n1) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y;
+    gat_stage<D>(sm, x, W, bias, a, b, N, Do);
+    float* dpre_l = sm + GatSmem<D>::floats(Do, N);            // [Do][GAT_PAIRS]
+    float* red = dpre_l + (size_t)Do * GAT_PAIRS;               // [4 waves][Do][4]  (dbias, da0, da1, da2)
+    unsigned char* pi = reinterpret_cast<unsigned char*>(red + 4 * Do * 4);   // [GAT_PAIRS] i, then [GAT_PAIRS] j
+    unsigned char* pj = pi + GAT_PAIRS;
+    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x * GAT_PAIRS + tid;
+    const bool valid = q < N * N;
+    const int i = valid ? q / N : 0, j = valid ? q - i * N : 0;
+    pi[tid] = (unsigned char)i; pj[tid] = (unsigned char)j;
+    const int ty = gat_type(i, j, n1);
+    const float* w = GatSmem<D>::w(sm);
+    const float* bs = GatSmem<D>::bias(sm, Do);
+    const float* at = GatSmem<D>::a(sm, Do) + ty * Do;
+    const float* xs = GatSmem<D>::x(sm, Do);
+    const float* xi = xs + i * (D + 1);
+    const float* xj = xs + j * (D + 1);
+    const float g = valid ? ds[(int64_t)b * N * N + q] : 0.f;
+    float p[D], dp[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { p[d] = xi[d] * xj[d]; dp[d] = 0.f; }
+    for (int o = 0; o < Do; ++o) {
+        float pre = bs[o];
+        const float4* wr = reinterpret_cast<const float4*>(w + o * D);
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4) {
+            const float4 ww = wr[d4];
+            pre += ww.x * p[4 * d4] + ww.y * p[4 * d4 + 1] + ww.z * p[4 * d4 + 2] + ww.w * p[4 * d4 + 3];
+        }
+        const float h = gat_tanh(pre);
+        const float dpre = g * at[o] * (1.0f - h * h);
+        dpre_l[o * GAT_PAIRS + tid] = dpre;
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4) {
+            const float4 ww = wr[d4];
+            dp[4 * d4] += dpre * ww.x; dp[4 * d4 + 1] += dpre * ww.y; dp[4 * d4 + 2] += dpre * ww.z; dp[4 * d4 + 3] += dpre * ww.w;
+        }
+        // per-wave sums of d bias and of ds*h by pair type (fixed order: deterministic)
+        const float gh = g * h;
+        const float r0 = wave_sum(dpre);
+        const float r1 = wave_sum(ty == 0 ? gh : 0.f), r2 = wave_sum(ty == 1 ? gh : 0.f), r3 = wave_sum(ty == 2 ? gh : 0.f);
+        if (lane == 0) {
+            float* r = red + (wave * Do + o) * 4;
+            r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+        }
+    }
+    if (valid) {
+        float* out = dP + ((int64_t)b * N * N + q) * D;
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4)
+            *reinterpret_cast<float4*>(out + 4 * d4) = make_float4(dp[4 * d4], dp[4 * d4 + 1], dp[4 * d4 + 2], dp[4 * d4 + 3]);
+    }
+    __syncthreads();
+    float* pb = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)Do * D + 4 * Do);
+    // ---- dW[o][d] = sum_pairs dpre[o][pair] * x_i[d] x_j[d]: thread -> (o = tid / 4 (+64 per pass), 16*(tid % 4) .. +D/4 ...)
+    {
+        constexpr int DG = D / 4;                 // d values per thread
+        const int dq = tid & 3;
+        for (int o = tid >> 2; o < Do; o += GAT_PAIRS / 4) {
+            float accw[DG];
+#pragma unroll
+            for (int t = 0; t < DG; ++t) accw[t] = 0.f;
+            const float* dr = dpre_l + o * GAT_PAIRS;
+            for (int pr = 0; pr < GAT_PAIRS; ++pr) {
+                const float dv = dr[pr];
+                const float* a_ = xs + pi[pr] * (D + 1) + dq * DG;
+                const float* b_ = xs + pj[pr] * (D + 1) + dq * DG;
+#pragma unroll
+                for (int t = 0; t < DG; ++t) accw[t] += dv * a_[t] * b_[t];
+            }
+#pragma unroll
+            for (int t = 0; t < DG; ++t) pb[o * D + dq * DG + t] = accw[t];
+        }
+    }
+    // ---- dbias, da: combine the 4 waves
+    for (int t = tid; t < Do * 4; t += GAT_PAIRS) {
+        const int o = t >> 2, c = t & 3;
+        const float v = red[(0 * Do + o) * 4 + c] + red[(1 * Do + o) * 4 + c] + red[(2 * Do + o) * 4 + c] + red[(3 * Do + o) * 4 + c];
+        pb[(size_t)Do * D + (c == 0 ? o : Do + (c - 1) * Do + o)] = v;
+    }
+}
+
+// dx[b][i][d] = sum_j (dP[b][i][j][d] + dP[b][j][i][d]) * x[b][j][d];  one block per (b, i), threads = 4 j-lanes x D
+template <int D>
+__global__ void gat_dx_kernel(const float* __restrict__ dP, const float* __restrict__ x, float* __restrict__ dx, int N) {
+    __shared__ float red[4][D];
+    const int b = blockIdx.y, i = blockIdx.x;
+    const int d = threadIdx.x % D, jl = threadIdx.x / D;
+    const float* xb = x + (int64_t)b * N * D;
+    const float* pb = dP + (int64_t)b * N * N * D;
+    float s = 0.f;
+    for (int j = jl; j < N; j += 4)
+        s += (pb[((int64_t)i * N + j) * D + d] + pb[((int64_t)j * N + i) * D + d]) * xb[(int64_t)j * D + d];
+    red[jl][d] = s;
+    __syncthreads();
+    if (jl == 0) dx[((int64_t)b * N + i) * D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+}
+
+}  // namespace
+
+extern "C" int scl_gat_score_nblocks(int N) { return (N * N + GAT_PAIRS - 1) / GAT_PAIRS; }
+
+extern "C" int scl_gat_score_fwd(const float* x, const float* W, const float* bias, const float* a, float* s, int B, int N, int D, int Do,
+                                 int n1, void* stream) {
+    SCL_REQUIRE(x && W && bias && a && s && B > 0, "gat_score_fwd: null pointer");
+    SCL_REQUIRE((D == 64 || D == 32) && Do >= 1 && Do <= 64 && N >= 1 && N <= GAT_MAXN && n1 >= 0 && n1 <= N,
+                "gat_score_fwd: need D in {32, 64}, Do <= 64, N <= 128 (D=%d Do=%d N=%d)", D, Do, N);
+    dim3 grid(scl_gat_score_nblocks(N), B), block(GAT_PAIRS);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 64) {
+        const size_t lds = GatSmem<64>::floats(Do, N) * sizeof(float);
+        hipLaunchKernelGGL((gat_score_fwd_kernel<64>), grid, block, lds, st, x, W, bias, a, s, N, Do, n1);
+    } else {
+        const size_t lds = GatSmem<32>::floats(Do, N) * sizeof(float);
+        hipLaunchKernelGGL((gat_score_fwd_kernel<32>), grid, block, lds, st, x, W, bias, a, s, N, Do, n1);
+    }
+    return scl_check_launch("scl_gat_score_fwd");
+}
+
+// dP: f32 [B, N*N, D] scratch; part: f32 [B * nblocks(N)][Do*D + 4*Do] partial sums (dW | dbias | da11 | da22 | da12), to be
+// summed over their first dimension by the caller (scl_colreduce_*); dx: f32 [B, N, D]
+extern "C" int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const float* a, const float* ds, float* dP, float* part,
+                                 float* dx, int B, int N, int D, int Do, int n1, void* stream) {
+    SCL_REQUIRE(x && W && bias && a && ds && dP && part && dx && B > 0, "gat_score_bwd: null pointer");
+    SCL_REQUIRE((D == 64 || D == 32) && Do >= 1 && Do <= 64 && N >= 1 && N <= GAT_MAXN && n1 >= 0 && n1 <= N,
+                "gat_score_bwd: need D in {32, 64}, Do <= 64, N <= 128 (D=%d Do=%d N=%d)", D, Do, N);
+    dim3 grid(scl_gat_score_nblocks(N), B), block(GAT_PAIRS);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gat_score_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)gat_score_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (D == 64) {
+        const size_t lds = (GatSmem<64>::floats(Do, N) + (size_t)Do * GAT_PAIRS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
+        SCL_REQUIRE(lds <= 160 * 1024, "gat_score_bwd: LDS tile too large");
+        hipLaunchKernelGGL((gat_score_bwd_kernel<64>), grid, block, lds, st, x, W, bias, a, ds, dP, part, N, Do, n1);
+        hipLaunchKernelGGL((gat_dx_kernel<64>), dim3(N, B), dim3(256), 0, st, dP, x, dx, N);
+    } else {
+        const size_t lds = (GatSmem<32>::floats(Do, N) + (size_t)Do * GAT_PAIRS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
+        SCL_REQUIRE(lds <= 160 * 1024, "gat_score_bwd: LDS tile too large");
+        hipLaunchKernelGGL((gat_score_bwd_kernel<32>), grid, block, lds, st, x, W, bias, a, ds, dP, part, N, Do, n1);
+        hipLaunchKernelGGL((gat_dx_kernel<32>), dim3(N, B), dim3(128), 0, st, dP, x, dx, N);
+    }
+    return scl_check_launch("scl_gat_score_bwd");
+}

@@ -97,6 +97,10 @@ def _protos():
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_conv0_bwd_nparts": ([_i32, _i32, _i32, _i32], _i32),
         "scl_conv0_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        # gat.hip
+        "scl_gat_score_nblocks": ([_i32], _i32),
+        "scl_gat_score_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_gat_score_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         # loss.hip
         "scl_supcon_nchunks": ([_i64], _i32),
         "scl_supcon_fwd": ([_vp, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),

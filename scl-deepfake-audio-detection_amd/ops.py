@@ -361,3 +361,15 @@ def i16_gain_overlay(speech_i16, n, noise_i16, nn, factor, out_f32=None, out_i16
 def multiview_crop(src, off, lens, V, firstlen, start, out_len, repeat_pad, out, ldo):
     _call("scl_multiview_crop_f32", _p(src), _p(off), _p(lens), V, firstlen, start, out_len, 1 if repeat_pad else 0,
                                             _p(out), ldo, _stream())
+
+
+def gat_score_nblocks(N):
+    return L.load().scl_gat_score_nblocks(N)
+
+
+def gat_score_fwd(x, W, bias, a, s, B, N, D, Do, n1):
+    _call("scl_gat_score_fwd", _p(x), _p(W), _p(bias), _p(a), _p(s), B, N, D, Do, n1, _stream())
+
+
+def gat_score_bwd(x, W, bias, a, ds, dP, part, dx, B, N, D, Do, n1):
+    _call("scl_gat_score_bwd", _p(x), _p(W), _p(bias), _p(a), _p(ds), _p(dP), _p(part), _p(dx), B, N, D, Do, n1, _stream())
