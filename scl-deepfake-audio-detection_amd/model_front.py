@@ -113,9 +113,9 @@ class FrontHeadModel(nn.Module):
         self.out_dim = self.cfg.embed
         self.grad_sync = None
         # Optional (SCL_HEAD_GRAPH=1): replay the back-end's training forward / backward as two captured hipGraphs per feature
-        # shape.  Off by default: measured gain is small (AASIST 54.4 -> 53.2 ms/step: the back-end is bound by its many small
-        # fp32 library kernels, not by launch overhead) and capturing MIOpen convolutions is not robust on ROCm 7.2 — the ResNet
-        # back-end's capture segfaults inside hipStreamEndCapture, which no Python-level fallback can catch.
+        # shape: AASIST 48.7 -> 44.3 ms/step at batch 32 (the back-end is ~890 small launches).  Off by default: capturing MIOpen
+        # convolutions is not robust on ROCm 7.2 — the ResNet back-end's capture segfaults inside hipStreamEndCapture, which no
+        # Python-level fallback can catch.
         self.use_graphs = os.environ.get("SCL_HEAD_GRAPH", "0") == "1"
         self.__dict__["_graphed"] = {}
 
