@@ -22,6 +22,7 @@ namespace {
 
 constexpr int GAT_MAXN = 128;     // nodes per graph
 constexpr int GAT_PAIRS = 256;    // pairs (= threads) per block
+constexpr int GAT_DPS = 68;       // row stride (floats) of the backward's d-pre tile [pair][o]: 16-byte aligned, 4-way banked
 
 template <int D>
 struct GatSmem {
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(GAT_PAIRS) void gat_score_bwd_kernel(const float* _
     extern __shared__ float sm[];
     const int b = blockIdx.y;
     gat_stage<D>(sm, x, W, bias, a, b, N, Do);
-    float* dpre_l = sm + GatSmem<D>::floats(Do, N);            // [Do][GAT_PAIRS]
-    float* red = dpre_l + (size_t)Do * GAT_PAIRS;               // [4 waves][Do][4]  (dbias, da0, da1, da2)
+    float* dpre_l = sm + ((GatSmem<D>::floats(Do, N) + 3) & ~(size_t)3);   // [GAT_PAIRS][GAT_DPS]
+    float* red = dpre_l + (size_t)GAT_PAIRS * GAT_DPS;          // [4 waves][Do][4]  (-, da0, da1, da2)
     unsigned char* pi = reinterpret_cast<unsigned char*>(red + 4 * Do * 4);   // [GAT_PAIRS] i, then [GAT_PAIRS] j
     unsigned char* pj = pi + GAT_PAIRS;
     __syncthreads();
@@ -128,19 +129,20 @@ __global__ __launch_bounds__(GAT_PAIRS) void gat_score_bwd_kernel(const float* _
         }
         const float h = gat_tanh(pre);
         const float dpre = g * at[o] * (1.0f - h * h);
-        dpre_l[o * GAT_PAIRS + tid] = dpre;
+        dpre_l[tid * GAT_DPS + o] = dpre;
 #pragma unroll
         for (int d4 = 0; d4 < D / 4; ++d4) {
             const float4 ww = wr[d4];
             dp[4 * d4] += dpre * ww.x; dp[4 * d4 + 1] += dpre * ww.y; dp[4 * d4 + 2] += dpre * ww.z; dp[4 * d4 + 3] += dpre * ww.w;
         }
-        // per-wave sums of d bias and of ds*h by pair type (fixed order: deterministic)
+        // per-wave sums of ds*h by pair type (fixed order: deterministic); the homogeneous layer has one type
         const float gh = g * h;
-        const float r0 = wave_sum(dpre);
-        const float r1 = wave_sum(ty == 0 ? gh : 0.f), r2 = wave_sum(ty == 1 ? gh : 0.f), r3 = wave_sum(ty == 2 ? gh : 0.f);
+        const float r1 = wave_sum(ty == 0 ? gh : 0.f);
+        float r2 = 0.f, r3 = 0.f;
+        if (n1 < N) { r2 = wave_sum(ty == 1 ? gh : 0.f); r3 = wave_sum(ty == 2 ? gh : 0.f); }
         if (lane == 0) {
             float* r = red + (wave * Do + o) * 4;
-            r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+            r[1] = r1; r[2] = r2; r[3] = r3;
         }
     }
     if (valid) {
@@ -151,31 +153,38 @@ __global__ __launch_bounds__(GAT_PAIRS) void gat_score_bwd_kernel(const float* _
     }
     __syncthreads();
     float* pb = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)Do * D + 4 * Do);
-    // ---- dW[o][d] = sum_pairs dpre[o][pair] * x_i[d] x_j[d]: thread -> (o = tid / 4 (+64 per pass), 16*(tid % 4) .. +D/4 ...)
+    // ---- dW[o][d] = sum_pairs dpre[pair][o] * x_i[d] x_j[d]: thread -> (d = tid % D, 16 consecutive o); the whole wave shares the
+    //      d-pre addresses (LDS broadcast), x reads are conflict-free across d; dbias[o] = sum_pairs dpre[pair][o] from the same pass
     {
-        constexpr int DG = D / 4;                 // d values per thread
-        const int dq = tid & 3;
-        for (int o = tid >> 2; o < Do; o += GAT_PAIRS / 4) {
-            float accw[DG];
+        const int d = tid % D, og = tid / D;
+        for (int o0 = og * 16; o0 < Do; o0 += (GAT_PAIRS / D) * 16) {
+            float accw[16];
 #pragma unroll
-            for (int t = 0; t < DG; ++t) accw[t] = 0.f;
-            const float* dr = dpre_l + o * GAT_PAIRS;
+            for (int t = 0; t < 16; ++t) accw[t] = 0.f;
             for (int pr = 0; pr < GAT_PAIRS; ++pr) {
-                const float dv = dr[pr];
-                const float* a_ = xs + pi[pr] * (D + 1) + dq * DG;
-                const float* b_ = xs + pj[pr] * (D + 1) + dq * DG;
+                const float pv = xs[pi[pr] * (D + 1) + d] * xs[pj[pr] * (D + 1) + d];
+                const float4* dr = reinterpret_cast<const float4*>(dpre_l + pr * GAT_DPS + o0);
 #pragma unroll
-                for (int t = 0; t < DG; ++t) accw[t] += dv * a_[t] * b_[t];
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const float4 dv = dr[t4];
+                    accw[4 * t4] += dv.x * pv; accw[4 * t4 + 1] += dv.y * pv; accw[4 * t4 + 2] += dv.z * pv; accw[4 * t4 + 3] += dv.w * pv;
+                }
             }
 #pragma unroll
-            for (int t = 0; t < DG; ++t) pb[o * D + dq * DG + t] = accw[t];
+            for (int t = 0; t < 16; ++t)
+                if (o0 + t < Do) pb[(o0 + t) * D + d] = accw[t];
         }
     }
-    // ---- dbias, da: combine the 4 waves
-    for (int t = tid; t < Do * 4; t += GAT_PAIRS) {
-        const int o = t >> 2, c = t & 3;
+    // ---- dbias[o] (row sums of the d-pre tile) and da: combine the 4 waves
+    for (int o = tid; o < Do; o += GAT_PAIRS) {
+        float sb = 0.f;
+        for (int pr = 0; pr < GAT_PAIRS; ++pr) sb += dpre_l[pr * GAT_DPS + o];
+        pb[(size_t)Do * D + o] = sb;
+    }
+    for (int t = tid; t < Do * 3; t += GAT_PAIRS) {
+        const int o = t / 3, c = 1 + t % 3;
         const float v = red[(0 * Do + o) * 4 + c] + red[(1 * Do + o) * 4 + c] + red[(2 * Do + o) * 4 + c] + red[(3 * Do + o) * 4 + c];
-        pb[(size_t)Do * D + (c == 0 ? o : Do + (c - 1) * Do + o)] = v;
+        pb[(size_t)Do * D + Do + (c - 1) * Do + o] = v;
     }
 }
 
@@ -232,12 +241,12 @@ extern "C" int scl_gat_score_bwd(const float* x, const float* W, const float* bi
         attr_set = true;
     }
     if (D == 64) {
-        const size_t lds = (GatSmem<64>::floats(Do, N) + (size_t)Do * GAT_PAIRS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
+        const size_t lds = (((GatSmem<64>::floats(Do, N) + 3) & ~(size_t)3) + (size_t)GAT_PAIRS * GAT_DPS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
         SCL_REQUIRE(lds <= 160 * 1024, "gat_score_bwd: LDS tile too large");
         hipLaunchKernelGGL((gat_score_bwd_kernel<64>), grid, block, lds, st, x, W, bias, a, ds, dP, part, N, Do, n1);
         hipLaunchKernelGGL((gat_dx_kernel<64>), dim3(N, B), dim3(256), 0, st, dP, x, dx, N);
     } else {
-        const size_t lds = (GatSmem<32>::floats(Do, N) + (size_t)Do * GAT_PAIRS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
+        const size_t lds = (((GatSmem<32>::floats(Do, N) + 3) & ~(size_t)3) + (size_t)GAT_PAIRS * GAT_DPS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
         SCL_REQUIRE(lds <= 160 * 1024, "gat_score_bwd: LDS tile too large");
         hipLaunchKernelGGL((gat_score_bwd_kernel<32>), grid, block, lds, st, x, W, bias, a, ds, dP, part, N, Do, n1);
         hipLaunchKernelGGL((gat_dx_kernel<32>), dim3(N, B), dim3(128), 0, st, dP, x, dx, N);
