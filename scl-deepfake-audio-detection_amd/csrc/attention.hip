@@ -123,7 +123,7 @@ __device__ __forceinline__ bf16x8 att_frag_tr(const char* tile, int rowa, int ro
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
                                                        int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     char* Kt = asmem;                 // [rows][128 B] row-read image
     char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
-    for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+    for (int idx = threadIdx.x; idx < rows * 8; idx += blockDim.x) {
         const int key = idx >> 3, c = idx & 7;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (key < T) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lc = lane & 15, g = lane >> 4;
     const float sl2 = scale * 1.4426950408889634f;
-    for (int qb = wave; qb < NT; qb += 4) {
+    for (int qb = wave; qb < NT; qb += (int)(blockDim.x >> 6)) {      // 8 waves: two blocks per CU = 4 waves per SIMD
         const int q = qb * 16 + lc;
         bf16x8 qf[2];
 #pragma unroll
@@ -440,7 +440,7 @@ extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 256, "attn_fwd: fused path needs head dim 64 and T <= 256 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
     const size_t lds = (size_t)2 * rows * 128;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale);
     return scl_check_launch("scl_attn_fwd");
 }
 
