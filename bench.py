@@ -74,8 +74,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  SCL_BENCH_BACKEND=gloo + SCL_BENCH_ONE_DEVICE=1 rehearse the N > 1 code path on a one-GPU box
+        dist.init_process_group(os.environ.get("SCL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    if os.environ.get("SCL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
