@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (configs[1]: 32; configs[2]: 64)")
     ap.add_argument("--samples", type=int, default=64000)
     ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo applied on the GPU inside the step (0 = off)")
-    ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist"], default="wav2vec2_linear_nll",
-                    help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist is an extra workload")
+    ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist", "wav2vec2_resnet_nll"], default="wav2vec2_linear_nll",
+                    help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet are extra workloads")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -87,6 +87,8 @@ def main():
     from scl_amd.lib import KID_GEMM
     if args.model == "wav2vec2_aasist":
         from scl_amd.model_aasist import Model
+    elif args.model == "wav2vec2_resnet_nll":
+        from scl_amd.model_resnet import Model
     else:
         from scl_amd.model_linear import Model
     from scl_amd.optim import FusedAdamW
