@@ -78,6 +78,8 @@ typedef struct SclOperand {
 #define SCL_GEMM_FORCE_BIG 0x04000000 /* pick the 256x128 / 3-stage variant (A-B comparison; not chosen automatically) */
 #define SCL_GEMM_NO_P8    0x00400000  /* do not pick the 256x256 ping-pong variant */
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
+#define SCL_GEMM_NO_W8    0x01000000  /* never the wide-tile (<=208/256 x 256, runtime row pitch) ping-pong kernel of gemm_w8.hip */
+#define SCL_GEMM_FORCE_W8 0x02000000  /* pick it whenever it can address the operands (testing / A-B comparison) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
 #define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */
 #define SCL_GEMM_RACT_SHIFT  16

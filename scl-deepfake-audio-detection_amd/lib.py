@@ -46,6 +46,8 @@ GEMM_NO_BIG = 0x00200000
 GEMM_FORCE_BIG = 0x04000000
 GEMM_NO_P8 = 0x00400000
 GEMM_FORCE_P8 = 0x00800000
+GEMM_NO_W8 = 0x01000000
+GEMM_FORCE_W8 = 0x02000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 KID_GEMM = 0

@@ -92,7 +92,7 @@ def test_big_tile_ring_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K):
     outs = []
     for force_big in (True, False):
         C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
-        ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=1, force_big=force_big)
+        ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=1, force_big=force_big, no_w8=True)
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     _close(outs[0], torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 8e-3, "big a_t=%s b_t=%s" % (a_t, b_t))
@@ -108,7 +108,7 @@ def test_pingpong_256_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K,
     opA = ops.Op(A.t().contiguous(), M) if a_t else ops.Op(A, K)
     opB = ops.Op(B.t().contiguous(), N) if b_t else ops.Op(B, K)
     outs = []
-    for kw in (dict(no_p8=True, no_big=True), dict(force_p8=True), dict(force_p8=True), dict(force_p8=True)):
+    for kw in (dict(no_p8=True, no_big=True, no_w8=True), dict(force_p8=True), dict(force_p8=True), dict(force_p8=True)):
         if splitk > 1:
             C = torch.full((splitk, M, N), float("nan"), dtype=torch.float32, device=dev)
             ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N, **kw)
@@ -264,3 +264,73 @@ def test_gemm_speed_report(dev, capsys):
         ms = e0.elapsed_time(e1) / 20
         with capsys.disabled():
             print("\n[gemm %s %dx%dx%d] %.3f ms  %.1f TFLOP/s" % (name, M, N, K, ms, 2 * M * N * K / ms / 1e9))
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(12736, 1024, 1024, 1), (5128, 1288, 256, 1), (2189, 3072, 1024, 1), (1024, 4096, 12736, 4),
+                                          (520, 776, 4096, 3), (199, 256, 64, 1), (1000, 200, 512, 1)])
+def test_wide_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
+    """The wide-tile ping-pong kernel (gemm_w8.hip: runtime row pitch, 7+6 / 8+8 row blocks per wave row, scalar-offset K
+    advance): same K order per output element as the 128x128 kernels => bit-identical, on ragged M / N edges, row pitches that
+    are not multiples of 16, split-K slabs with an uneven last slab, repeated to give a mis-ordered LDS read a chance to show.
+    Memory behind the operands is NaN: a fetch past a row limit that is not range-checked to zero would poison the output."""
+    A = _rand((M, K), dev, 51, 0.3); B = _rand((N, K), dev, 52, 0.3)
+    def nanpad(mat):
+        buf = torch.full((mat.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=dev)
+        buf[:mat.numel()] = mat.reshape(-1)
+        return buf
+    opA = ops.Op(nanpad(A.t().contiguous()), M) if a_t else ops.Op(nanpad(A), K)
+    opB = ops.Op(nanpad(B.t().contiguous()), N) if b_t else ops.Op(nanpad(B), K)
+    outs = []
+    for kw in (dict(no_p8=True, no_big=True, no_w8=True), dict(force_w8=True), dict(force_w8=True), dict(force_w8=True)):
+        if splitk > 1:
+            C = torch.full((splitk, M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N, **kw)
+        else:
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, act=2, **kw)
+        outs.append(C)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    ref = A.float() @ B.float().t()
+    got = outs[1].sum(0) if splitk > 1 else outs[1]
+    _close(got, ref if splitk > 1 else torch.relu(ref), 8e-3, "w8 a_t=%s b_t=%s" % (a_t, b_t))
+
+
+def test_wide_tile_kernel_conv_and_grouped_addressing(dev):
+    """Operands the wide kernel must address exactly as the 128x128 kernels do: utterance-batched overlapping rows (conv layer as a
+    GEMM: rpb / rbstride / ld < K), a strided utterance-batched output (c_rpb / c_rbstride / ldc, the phase-split transposed
+    convolution), and the 2-level contiguous index of the grouped positional conv (cin = 64) with batch strides, bias, GELU, second
+    output and residual."""
+    Bz, Tin, C, k, s = 6, 1601, 512, 3, 2
+    Tout = (Tin - k) // s + 1
+    z = _rand((Bz * Tin * C + 65536,), dev, 61, 0.3); wk = _rand((C, k * C), dev, 62, 0.05)
+    bias = torch.randn(C, device=dev)
+    outs = []
+    for kw in (dict(no_w8=True, no_p8=True, no_big=True), dict(force_w8=True)):
+        y = torch.full((Bz * Tout, C), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(ops.Op(z, s * C, rpb=Tout, rbstride=Tin * C), ops.Op(wk, k * C), y, Bz * Tout, C, k * C, bias=bias, **kw)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    # strided, utterance-batched output with a transposed weight operand
+    dy = _rand((Bz * (Tout + 2) * C + 65536,), dev, 63, 0.3); wd = _rand((2 * C, C), dev, 64, 0.05)
+    outs = []
+    for kw in (dict(no_w8=True, no_p8=True, no_big=True), dict(force_w8=True)):
+        dz = torch.zeros(Bz * Tin * C + 65536, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(dy, C, rpb=Tout, rbstride=(Tout + 2) * C), ops.Op(wd, C), dz, Bz * Tout, C, 2 * C, b_t=True, ldc=s * C,
+                 c_rpb=Tout, c_rbstride=Tin * C, c_offset=C, **kw)
+        outs.append(dz)
+    assert torch.equal(outs[0], outs[1])
+    # grouped positional conv: 16 groups, N = 64 per group, k index = (tap, channel-in-group)
+    Bz, T, E, K, G = 8, 199, 1024, 128, 16
+    Cg = E // G
+    xpad = _rand((Bz * (T + K) * E + 65536,), dev, 65, 0.3); wf = _rand((G, Cg, K * Cg), dev, 66, 0.02)
+    x0 = torch.randn(Bz * T, E, device=dev); pbias = torch.randn(E, device=dev)
+    outs = []
+    for kw in (dict(no_w8=True, no_p8=True, no_big=True), dict(force_w8=True)):
+        xo = torch.full((Bz * T, E), float("nan"), dtype=torch.float32, device=dev)
+        pre = torch.full((Bz * T, E), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(xpad, E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), ops.Op(wf, K * Cg, bs2=Cg * K * Cg), xo, Bz * T, Cg,
+                 K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=pbias, bias_bs2=Cg, act=1, c2=pre, R=x0, rmode=1, **kw)
+        outs.append((xo, pre))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
