@@ -7,15 +7,20 @@
 A step = one optimizer step of `wav2vec2_linear_nll` at XLS-R-300M shape on a synthetic batch that is
 already resident in HBM: [RawBoost on the GPU if the config says so ->] forward -> NLL + SupCon losses
 -> backward -> gradient all-reduce (N > 1) -> fused AdamW.  Default workload = BASELINE.json
-configs[1]: batch 32 x 64000-sample clips per GPU, bf16 GEMM operands, RawBoost off.
+configs[2], the north_star's target configuration and the largest single-GPU config: wav2vec2_linear_nll + SupCon
+(conf-3 loss), batch 64 x 64000-sample clips per GPU, RawBoost algo 5 (LnL + ISD) on the GPU INSIDE the timed step,
+bf16 GEMM operands.  configs[1] (batch 32, RawBoost off) = `--batch 32 --rawboost 0`.
 Weak scaling: every rank runs the same per-GPU batch; value = all ranks' utterances / max-over-ranks time.
 
 The JSON line also carries
-  roofline     — the dominant kernel family (scl_gemm_kernel, bf16 MFMA): algorithmic FLOPs per launch
+  roofline     — the dominant kernel family (scl_gemm_*, bf16 MFMA): algorithmic FLOPs per launch
                  / average launch duration, both measured live with HIP events on the launch stream
                  over the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s);
-  cpu_baseline — the oracle's CPU train step (torch fp32, all host cores) on a bounded sample of the
-                 same workload (rank 0, N = 1 only).
+  roofline_aug — the RawBoost chain (FIR + normalise + ISD scatter kernels): SURVEY.md 8(d)'s 8 B/sample
+                 = 512 kB per clip / the chain's kernel time (HIP events), against the 8 TB/s HBM peak, and its
+                 fp32 FLOP/s against the 157.3 TFLOP/s vector peak (the direct-form FIR is VALU-bound);
+  cpu_baseline — the oracle's CPU path (RawBoost per clip as the reference does it + torch fp32 train step,
+                 all host cores) on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -38,9 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (configs[1]: 32; configs[2]: 64)")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (configs[2]: 64; configs[1]: 32)")
     ap.add_argument("--samples", type=int, default=64000)
-    ap.add_argument("--rawboost", type=int, default=0, help="RawBoost algo applied on the GPU inside the step (0 = off)")
+    ap.add_argument("--rawboost", type=int, default=5, help="RawBoost algo applied on the GPU inside the step (configs[2]: 5; 0 = off)")
     ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist", "wav2vec2_resnet_nll"], default="wav2vec2_linear_nll",
                     help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet are extra workloads")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
@@ -50,9 +55,12 @@ def parse():
 
 
 def cpu_baseline(args):
-    """Oracle train step (the CPU restatement pinned to the reference) on a bounded sample:
-    `cpu_batch` utterances of the same length, one warm-up-free timed step."""
+    """Oracle CPU path (the restatement pinned to the reference) on a bounded sample: `cpu_batch` utterances of the same
+    length — RawBoost per clip with the reference's own call sequence (one clip after the other, as a DataLoader worker
+    does), then one warm-up-free train step."""
+    import numpy as np
     from oracle import head as OH
+    from oracle import rawboost as RB
     from oracle import wav2vec2 as W
     cfg = W.W2VConfig.tiny() if args.tiny else W.W2VConfig()
     ssl, head = W.init_state(cfg, seed=0), OH.init_head(cfg.embed, seed=1)
@@ -60,10 +68,17 @@ def cpu_baseline(args):
     x = 0.1 * torch.randn(B, args.samples, generator=torch.Generator().manual_seed(1234))
     y = torch.tensor(([1] * ((5 * B + 10) // 11) + [0] * B)[:B])
     t0 = time.time()
+    t_aug = 0.0
+    if args.rawboost:
+        np.random.seed(1234)
+        xa = np.stack([RB.process_rawboost_feature(x[i].numpy(), 16000, RB.RawBoostArgs(), args.rawboost) for i in range(B)])
+        x = torch.from_numpy(xa.astype(np.float32))
+        t_aug = time.time() - t0
     OH.train_step(ssl, head, cfg, x, y)
     dt = time.time() - t0
     return {"value": B / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 train step (fwd+loss+bwd+AdamW, fp32 torch CPU oracle) on %d x %d-sample clips, %.1f s" % (B, args.samples, dt)}
+            "sample": "%d x %d-sample clips: oracle RawBoost algo %d per clip on 1 core (%.2f s) + 1 train step (fwd+loss+bwd+AdamW, fp32 "
+                      "torch CPU oracle, %d threads), %.1f s in all" % (B, args.samples, args.rawboost, t_aug, torch.get_num_threads(), dt)}
 
 
 def main():
@@ -84,7 +99,7 @@ def main():
 
     from scl_amd import augment, ops
     from scl_amd.encoder import W2VConfig
-    from scl_amd.lib import KID_GEMM
+    from scl_amd.lib import KID_AUG, KID_GEMM
     if args.model == "wav2vec2_aasist":
         from scl_amd.model_aasist import Model
     elif args.model == "wav2vec2_resnet_nll":
@@ -140,12 +155,16 @@ def main():
     for i in range(args.steps):
         if i == args.steps - 1:
             ops.prof_enable(KID_GEMM, True)
+            ops.prof_enable(KID_AUG, True)
         last = step()
     fence()
     dt = time.perf_counter() - t0
     ops.prof_enable(KID_GEMM, False)
+    ops.prof_enable(KID_AUG, False)
     n_launch, gemm_ms, gemm_flops = ops.prof_read(KID_GEMM)
+    aug_launch, aug_ms, _ = ops.prof_read(KID_AUG)
     loss_val = float(last.item())
+    assert loss_val == loss_val and 0.0 < loss_val < 2.0, "final loss %r outside the band of a seeded-random-init step" % loss_val
     if world > 1:
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -156,12 +175,12 @@ def main():
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # HBM traffic per GEMM launch cannot be read live (PMC needs rocprofv3): take it from the committed counter pass of this
-    # same command (profiles/r1_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), else null
+    # same command (profiles/r2_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), else null
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")) as f:
             pmc = json.load(f)
-        if B == 32 and L == 64000 and not args.tiny and not args.rawboost and args.model == "wav2vec2_linear_nll":
+        if B == pmc.get("batch", 32) and L == 64000 and not args.tiny and args.model == "wav2vec2_linear_nll":
             traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
     except (OSError, KeyError, ValueError):
         traffic = None
@@ -174,13 +193,25 @@ def main():
                    "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
         "final_loss": loss_val,
         "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
-        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{dma,}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{w8,w8s,dma}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
                      "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
                      "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
                      "gemm_share_of_step_time": gemm_ms * 1e-3 / (dt / args.steps)},   # events bracket the last timed step only
     }
+    if args.rawboost and aug_ms > 0:
+        # 8 B/sample (fp32 in + out) per fused chain = 512 kB per 64000-sample clip; arithmetic = 2 * sum(taps) per
+        # sample of the five LnL branches (+ a few FLOP/sample for the powers and the ISD / normalise passes)
+        aug_bytes = 8.0 * B * L
+        aug_flops = 2.0 * augment.last_tap_total() * L
+        gbs = aug_bytes / (aug_ms * 1e-3) / 1e9
+        res["roofline_aug"] = {"bound": "hbm", "kernel": "RawBoost algo %d chain: fir_kernel (LnL, 5 power branches fused) + clip_affine + "
+                               "isd_scatter + clip_stats + clip_affine" % args.rawboost, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                               "frac": gbs / 8000.0, "traffic": None, "launches": aug_launch, "chain_ms": aug_ms,
+                               "clips_per_s_kernel_only": B / (aug_ms * 1e-3),
+                               "achieved_fp32_tflops": aug_flops / (aug_ms * 1e-3) / 1e12, "fp32_vector_peak_tflops": 157.3,
+                               "note": "direct-form FIR, ~2.7 kFLOP/sample: VALU-bound, HBM traffic is the minimal 8 B/sample"}
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(res))

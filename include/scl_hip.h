@@ -39,6 +39,7 @@ const char* scl_last_error(void);
  * the kernel family `kid` (SCL_KID_*) is bracketed by two hipEvents on the launch stream.
  * scl_prof_read synchronises those events and returns launch count and summed milliseconds. */
 #define SCL_KID_GEMM 0
+#define SCL_KID_AUG  1   /* the RawBoost chain: scl_fir_multi_f32, scl_clip_stats_f32, scl_isd_scatter_f32, scl_clip_affine_f32 */
 #define SCL_KID_MAX  8
 int scl_prof_enable(int kid, int on);
 int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops);
@@ -80,6 +81,7 @@ typedef struct SclOperand {
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
 #define SCL_GEMM_NO_W8    0x01000000  /* never the wide-tile (<=208/256 x 256, runtime row pitch) ping-pong kernel of gemm_w8.hip */
 #define SCL_GEMM_FORCE_W8 0x02000000  /* pick it whenever it can address the operands (testing / A-B comparison) */
+#define SCL_GEMM_STAMPS   0x20000000  /* diagnostic: the wide kernels record per-block time stamps (scl_debug_gemm_stamps) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
 #define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */
 #define SCL_GEMM_RACT_SHIFT  16
@@ -109,6 +111,14 @@ typedef struct SclGemmDesc {
  * (model/xlsr.py:41), nn.Linear in model/wav2vec2_linear_nll.py:107,49-67 and their autograd
  * backward (main.py:79).                                                                       */
 int scl_gemm_bf16(const SclGemmDesc* desc, void* stream);
+
+/* 0 when scl_gemm_bf16 would run this descriptor on the 128x128 tiles, 1 / 2 for the wide (<= 208 / 256 rows x 256 columns) tiles of
+ * gemm_w8.hip — lets the caller size split-K for the tile that will actually be used (pointers are not dereferenced). */
+int scl_gemm_uses_wide_tiles(const SclGemmDesc* desc);
+
+/* diagnostic: copy the per-block stamps of the last SCL_GEMM_STAMPS launch: 8 x u64 per block = {realtime (100 MHz), shader
+ * clock} at kernel entry, after the prologue, after the K loop, after the epilogue (blocks 0 .. nblocks-1, nblocks <= 4096). */
+int scl_debug_gemm_stamps(unsigned long long* out, int nblocks);
 
 /* out[i] = sum_s slabs[s*stride + i]  (deterministic split-K combine). */
 int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream);

@@ -146,8 +146,18 @@ def _fast_ssi(a, n, L, fs):
 
 
 # ---- device stages -----------------------------------------------------------------------------
+_LAST_TAP_TOTAL = 0
+
+
+def last_tap_total():
+    """Sum of FIR tap counts over all clips and branches of the most recent LnL / SSI stage (bench.py: achieved FLOP/s)."""
+    return _LAST_TAP_TOTAL
+
+
 def _taps_to_device(taps_per_clip, dev, centred=True):
     """taps_per_clip: list (clips) of lists (filters) of float64 arrays."""
+    global _LAST_TAP_TOTAL
+    _LAST_TAP_TOTAL = sum(len(b) for taps in taps_per_clip for b in taps)
     flat, off, ln, hh = [], [], [], []
     pos = 0
     for taps in taps_per_clip:

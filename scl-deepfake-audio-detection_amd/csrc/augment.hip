@@ -250,6 +250,7 @@ extern "C" int scl_fir_multi_f32(const float* x, int64_t ldx, int Lin, const flo
     SCL_REQUIRE(x && taps && tap_off && tap_len && tap_h && y, "fir: null pointer");
     SCL_REQUIRE(nclip >= 1 && nclip <= 65535 && nf >= 1 && Lin >= 1 && Lout >= 1, "fir: bad dims");
     dim3 grid(scl_fir_nblocks(Lout), nclip), block(256);
+    SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
     hipLaunchKernelGGL(fir_kernel, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
     return scl_check_launch("scl_fir_multi_f32");
 }
@@ -257,6 +258,7 @@ extern "C" int scl_fir_multi_f32(const float* x, int64_t ldx, int Lin, const flo
 extern "C" int scl_clip_stats_f32(const float* x, int64_t ldx, int L, int nclip, float* part, void* stream) {
     SCL_REQUIRE(x && part && L >= 1 && nclip >= 1 && nclip <= 65535, "clip_stats: bad args");
     dim3 grid(scl_fir_nblocks(L), nclip), block(256);
+    SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
     hipLaunchKernelGGL(clip_stats_kernel, grid, block, 0, (hipStream_t)stream, x, ldx, L, part);
     return scl_check_launch("scl_clip_stats_f32");
 }
@@ -266,6 +268,7 @@ extern "C" int scl_isd_scatter_f32(float* y, int64_t ldy, const int* pos, const 
     SCL_REQUIRE(y && pos && fr && clip_off && nclip >= 1 && nclip <= 65535, "isd_scatter: bad args");
     if (max_per_clip <= 0) return SCL_OK;
     dim3 grid(blocks_for(max_per_clip), nclip), block(256);
+    SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
     hipLaunchKernelGGL(isd_scatter_kernel, grid, block, 0, (hipStream_t)stream, y, ldy, pos, fr, clip_off, g_sd);
     return scl_check_launch("scl_isd_scatter_f32");
 }
@@ -276,6 +279,7 @@ extern "C" int scl_clip_affine_f32(int mode, const float* x, int64_t ldx, const 
     SCL_REQUIRE(mode != AFF_SSI_MIX || (z && partz && snr_db), "clip_affine: SSI mode needs z, partz, snr_db");
     const int nblk = scl_fir_nblocks(L);
     dim3 grid(nblk, nclip), block(256);
+    SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
     hipLaunchKernelGGL(clip_affine_kernel, grid, block, 0, (hipStream_t)stream, mode, x, ldx, z, ldz, partx, partz, nblk, snr_db, out, ldo, L);
     return scl_check_launch("scl_clip_affine_f32");
 }

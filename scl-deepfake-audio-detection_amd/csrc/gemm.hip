@@ -684,7 +684,25 @@ bool fill_operand(const SclOperand& o, const char* name, long long rows, long lo
     return true;
 }
 
+// wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the problem fills at
+// least half a round of them and the operands advance linearly along K
+bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, W8Plan* plan) {
+    static const int w8_env = [] { const char* e = getenv("SCL_GEMM_W8"); return e ? atoi(e) : 1; }();
+    if (d.flags & (SCL_GEMM_NO_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG | SCL_GEMM_NO_DMA)) return false;
+    const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
+    const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
+    if (!a_whole || !b_whole || !scl_gemm_w8_plan(k, at, bt, d, zdim, 256, plan)) return false;
+    return (d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan->tiles * zdim >= 128);
+}
+
 }  // namespace
+
+extern "C" int scl_gemm_uses_wide_tiles(const SclGemmDesc* dp) {
+    if (!dp || dp->M <= 0 || dp->N <= 0 || dp->K <= 0 || dp->nb1 < 1 || dp->nb2 < 1 || dp->splitk < 1) return 0;
+    GemmK k; W8Plan plan;
+    const bool at = dp->flags & SCL_GEMM_A_T, bt = dp->flags & SCL_GEMM_B_T;
+    return gemm_pick_w8(k, at, bt, *dp, (long long)dp->nb1 * dp->nb2 * dp->splitk, &plan) ? 1 + plan.variant : 0;
+}
 
 extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     SCL_REQUIRE(dp, "gemm: null desc");
@@ -712,7 +730,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
     k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
     static const int group_m_env = [] { const char* e = getenv("SCL_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();
-    k.group_m = group_m_env; k.tile_m = 0;
+    k.group_m = group_m_env; k.tile_m = 0; k.debug = 0;
     // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias
     auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p & (bytes - 1)) == 0; };
     const bool strides4 = !(d.ldc & 3) && !(d.c_bs1 & 3) && !(d.c_bs2 & 3) && !(d.c_rbstride & 3) && !(d.c_split_stride & 3) && !(d.bias_bs2 & 3);
@@ -739,10 +757,8 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool p8 = dma && (d.flags & SCL_GEMM_FORCE_P8) && !(d.flags & SCL_GEMM_NO_P8);
         // wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the
         // problem fills at least half a round of them and the operands advance linearly along K
-        static const int w8_env = [] { const char* e = getenv("SCL_GEMM_W8"); return e ? atoi(e) : 1; }();
         W8Plan plan;
-        const bool w8_can = dma && !(d.flags & (SCL_GEMM_NO_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG)) && scl_gemm_w8_plan(k, at, bt, d, zdim, 256, &plan);
-        const bool w8 = w8_can && ((d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan.tiles * zdim >= 128));
+        const bool w8 = dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
         if (w8) {
             scl_gemm_w8_launch(k, at, bt, plan, zdim, s);
         } else if (p8) {
@@ -786,6 +802,11 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         }
     }
     return scl_check_launch("scl_gemm_bf16");
+}
+
+extern "C" int scl_debug_gemm_stamps(unsigned long long* out, int nblocks) {
+    SCL_REQUIRE(out && nblocks > 0 && nblocks <= 4096, "gemm stamps: bad args");
+    return scl_gemm_read_stamps(out, nblocks);
 }
 
 extern "C" int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream) {

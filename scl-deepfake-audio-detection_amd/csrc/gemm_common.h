@@ -21,7 +21,7 @@ struct GemmK {
     void* C; void* C2; const void* R; const float* bias;
     long long c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2;  // elements
     unsigned c_rpb, c_magic, c_shift;
-    int ldc, M, N, K, nb2, splitk, flags, vec_ok, group_m, tile_m;
+    int ldc, M, N, K, nb2, splitk, flags, vec_ok, group_m, tile_m, debug;
     float alpha, drop_p;
     unsigned drop_seed;
 };
@@ -220,6 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[4][4]
 // gemm_w8.hip (host side)
 struct W8Plan { int variant, tiles_m, tile_m; long long tiles, cost; };
 bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan);
+int scl_gemm_read_stamps(unsigned long long* out, int nblocks);
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s);
 
 }  // namespace sclg

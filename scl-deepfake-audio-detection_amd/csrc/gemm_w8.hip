@@ -14,24 +14,40 @@
 //   * Staging is global -> LDS directly (buffer_load_dwordx4 ... lds), swizzles applied to the per-lane source address as in
 //     gemm.hip.  The per-lane byte offset is computed ONCE per tile; the K advance is the instruction's scalar offset (one
 //     s_add per K step; soffset is not part of the range check, so out-of-range lanes stay out of range).
-//   * LDS: 2 buffers x {A image 32 KiB, B image 32 KiB} = 128 KiB.  Hazards (raw s_barrier, counted vmcnt), per K tile t:
-//       p0: read B(blocks 0,1) A(blocks 0-3) | DMA A(t+1) -> other buffer        | MFMA A0-3 x B0-1
-//       p1: read B(blocks 2,3)               |                                    | MFMA A0-3 x B2-3
-//       p2: read A(blocks 4..)               |                                    | MFMA A4.. x B2-3
-//       p3:                                  | DMA B(t+2) -> this buffer; vmcnt(4): all of tile t+1 landed | MFMA A4.. x B0-1
-//     RAW: tile t+1 is waited for (vmcnt) before the first barrier of p3 and first read in the next phase; WAR: a region is
-//     re-staged >= 2 phases after its last ds_read, which covers the wave row that runs half a phase behind.
+//   * LDS (all 160 KiB): A images in a ring of 3, B images in a ring of 2, 32 KiB each; two DMA pieces per wave and phase (the
+//     round-1 ping-pong kernel issued 4 in p0 and 4 in p3: its load segments, not its MFMA bursts, set the phase time), eight
+//     pieces (8 KiB per wave) stay in flight across the wait.  Per K tile t (raw s_barrier, counted vmcnt):
+//       p0: read B(blocks 0,1) A(blocks 0-3) | DMA A(t+2) pieces 0,1 -> A ring    | MFMA A0-3 x B0-1
+//       p1: read B(blocks 2,3)               | DMA A(t+2) pieces 2,3              | MFMA A0-3 x B2-3
+//       p2: read A(blocks 4..)               | DMA B(t+2) pieces 0,1 -> this B    | MFMA A4.. x B2-3
+//       p3:                                  | DMA B(t+2) pieces 2,3; vmcnt(8): all of tile t+1 landed | MFMA A4.. x B0-1
+//     RAW: tile t+1 is waited for (vmcnt) before the first barrier of p3 and first read in the next phase.  WAR: every phase
+//     retires its LDS reads (lgkmcnt(0)) BEFORE its first barrier, so a region may be re-staged one phase after its last read
+//     even by the wave row that runs half a phase ahead (B image: read p0/p1, staged p2/p3; A image t-1: read until p2 of the
+//     previous tile, staged p0/p1).
+//   * The epilogue goes through LDS (w8_epilogue_pass): whole 128-B lines per store instead of 16 x 32-byte fragments.
 //   * Accumulation order per output element is k ascending, as in the 128x128 kernels: results are bit-identical to theirs.
 #include "gemm_common.h"
 
 using namespace sclg;
 
+// in-kernel stamps of the wide kernels (diagnostic: flag SCL_GEMM_STAMPS; wave 0 of every block writes {realtime, shader clock}
+// at kernel entry, after the prologue wait, after the K loop and after the epilogue)
+__device__ unsigned long long scl_gemm_stamps[4096 * 8];
+
 namespace {
+
+__device__ __forceinline__ void w8_stamp(const GemmK& d, int slot, int lane, int wave) {
+    if ((d.flags & SCL_GEMM_STAMPS) && wave == 0 && lane == 0 && blockIdx.x < 4096 && blockIdx.z == 0) {
+        scl_gemm_stamps[blockIdx.x * 8 + 2 * slot] = __builtin_amdgcn_s_memrealtime();
+        scl_gemm_stamps[blockIdx.x * 8 + 2 * slot + 1] = __builtin_amdgcn_s_memtime();
+    }
+}
 
 constexpr int W8_BN = 256;
 constexpr int W8_OPB = 2 * TILE_BYTES;      // one operand image of one K step: 256 rows x 64 k (or 2 sub-tiles of [64 k][128])
-constexpr int W8_BUF = 2 * W8_OPB;
-constexpr int W8_LDS = 2 * W8_BUF;          // 131072 B
+constexpr int W8_NA = 3, W8_NB = 2;         // A images form a ring of 3 (two K steps in flight), B images a ring of 2
+constexpr int W8_LDS = (W8_NA + W8_NB) * W8_OPB;   // 163840 B = all of the CU's LDS
 
 // K-contiguous operand, 256 rows: this wave stages the 1-KiB pieces wave*4 + i (8 rows x 64 k each)
 struct W8K {
@@ -47,9 +63,10 @@ struct W8K {
             voff[i] = r < rowlimit ? row_off(o, (unsigned)r) + (unsigned)(kc << 4) : OOB;
         }
     }
-    __device__ __forceinline__ void issue(char* img, int wave, unsigned soff, bool live) const {
+    template <int I0>
+    __device__ __forceinline__ void issue2(char* img, int wave, unsigned soff, bool live) const {   // pieces I0, I0 + 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = I0; i < I0 + 2; ++i) {
             const unsigned off = live ? voff[i] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
         }
@@ -72,9 +89,10 @@ struct W8T {
             voff[i] = col < collimit ? (unsigned)kr * o.ld_bytes + col_off(o, (unsigned)col) : OOB;
         }
     }
-    __device__ __forceinline__ void issue(char* img, int wave, unsigned soff, bool live) const {
+    template <int I0>
+    __device__ __forceinline__ void issue2(char* img, int wave, unsigned soff, bool live) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = I0; i < I0 + 2; ++i) {
             const unsigned off = live ? voff[i] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
         }
@@ -90,10 +108,122 @@ __device__ __forceinline__ bf16x8 w8_frag(const char* img, int gb, int ks, int l
     return frag_k(img, gb, ks, lane);
 }
 
+// ---- epilogue through LDS: whole 128-B lines per store ----------------------------------------------------------------
+// The MFMA leaves a lane with 4 consecutive columns of 16 different rows, so a direct store touches 16 cache lines with 32
+// (bf16: 16) bytes each; with one 8-wave block per CU nothing overlaps the epilogue and those stores (plus the residual loads of
+// the same shape) took 16-27 us of a 45-55 us block (stamps, profiles/r2_gemm_stamps.txt).  Here each wave parks up to 64 rows x
+// 64 columns of f32 accumulators in a private 16-KiB LDS block ([row][256 B], 16-byte chunks XOR-swizzled with row & 15: the
+// ds_write_b128 of a 16-lane group and the two ds_read_b128 per lane are bank-conflict free) and reads them back row-contiguous:
+// a lane owns 8 consecutive columns of one row, 8 lanes own a row's 64 columns, so bias / residual loads and the C / C2 stores of
+// one wave-instruction cover 8 rows x 128 (bf16) or 256 (f32) contiguous bytes.  Arithmetic per element is the old epilogue's,
+// in the same order: results are bit-identical.
+__device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4][4], int nmt, char* wlds, int mbase, int nbase,
+                                                 int mlimit, long long cbase, const float* bias, int lane) {
+    const int flags = d.flags;
+    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
+    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
+    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
+    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
+    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+    const int g = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (mt < nmt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(wlds + (mt * 16 + lc) * 256 + (((nt * 4 + g) ^ lc) << 4)) = acc[mt][nt];
+        }
+    }
+    const int c = lane & 7, rsub = lane >> 3;
+    const int col = nbase + 8 * c;
+    const bool colv = d.vec_ok && col + 8 <= d.N;
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has_bias && colv) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
+    const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
+    for (int i = 0; i < 2 * nmt; ++i) {
+        const int r = 8 * i + rsub;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c) ^ (r & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c + 1) ^ (r & 15)) << 4));
+        const int row = mbase + r;
+        if (row >= mlimit) continue;
+        const unsigned q = udiv_magic((unsigned)row, d.c_magic, d.c_shift);
+        const long long off = cbase + (long long)q * d.c_rbstride + (long long)((unsigned)row - q * d.c_rpb) * d.ldc + col;
+        float v[8] = {d.alpha * lo[0], d.alpha * lo[1], d.alpha * lo[2], d.alpha * lo[3], d.alpha * hi[0], d.alpha * hi[1], d.alpha * hi[2], d.alpha * hi[3]};
+        if (colv) {
+            if (has_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += bb[j];
+            }
+            if (has_c2) {
+                if (c2_f32) {
+                    float* p = reinterpret_cast<float*>(d.C2) + off;
+                    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    bf16_t* p = reinterpret_cast<bf16_t*>(d.C2) + off;
+                    if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = act_f(act, v[j]);
+            }
+            float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (rmode) {
+                if (r_f32) {
+                    const float* p = reinterpret_cast<const float*>(d.R) + off;
+                    const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + 4);
+                    rr[0] = t0.x; rr[1] = t0.y; rr[2] = t0.z; rr[3] = t0.w; rr[4] = t1.x; rr[5] = t1.y; rr[6] = t1.z; rr[7] = t1.w;
+                } else {
+                    const bf16_t* p = reinterpret_cast<const bf16_t*>(d.R) + off;
+                    uint2 t0, t1;
+                    if ((off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
+                    else { t0 = *reinterpret_cast<const uint2*>(p); t1 = *reinterpret_cast<const uint2*>(p + 4); }
+                    rr[0] = __uint_as_float(t0.x << 16); rr[1] = __uint_as_float(t0.x & 0xFFFF0000u);
+                    rr[2] = __uint_as_float(t0.y << 16); rr[3] = __uint_as_float(t0.y & 0xFFFF0000u);
+                    rr[4] = __uint_as_float(t1.x << 16); rr[5] = __uint_as_float(t1.x & 0xFFFF0000u);
+                    rr[6] = __uint_as_float(t1.y << 16); rr[7] = __uint_as_float(t1.y & 0xFFFF0000u);
+                }
+            }
+            if (rmode == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= act_grad_f(ract, rr[j]);
+            }
+            if (drop) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(d.drop_seed, (uint64_t)(off + j), d.drop_p);
+            }
+            if (rmode == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+            if (c_f32) {
+                float* p = reinterpret_cast<float*>(d.C) + off;
+                *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                bf16_t* p = reinterpret_cast<bf16_t*>(d.C) + off;
+                if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
+            }
+        } else {
+            // column-edge tile / unaligned C: element-wise path
+#pragma unroll
+            for (int j = 0; j < 8; ++j) epi_scalar(ea, v[j], off + j, col + j, bias);
+        }
+    }
+}
+
+// one phase: [the caller's LDS reads / DMA issues]  wait reads -> barrier -> MFMA burst -> barrier.  The LDS reads are retired
+// BEFORE the first barrier: a region may then be re-staged one phase after its last read (the B image at p2).
 #define W8_MFMA_PHASE(MH, NH, FBSEL, NI)                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
@@ -120,11 +250,15 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
     const int nbk = wc * 4;
+    char* const bimg = smem + W8_NA * W8_OPB;
+    // A image of tile kt / kt + 1 / kt + 2 (= kt - 1, free since p2 of the previous tile)
+    char *a_cur = smem, *a_nxt = smem + W8_OPB, *a_fill = smem + 2 * W8_OPB;
+    // on entry soffA / soffB are the scalar offsets of tile 1 (the prologue staged tiles 0 and 1)
     for (int kt = 0; kt < nk; ++kt) {
-        char* buf = smem + (kt & 1) * W8_BUF;
-        char* obuf = smem + ((kt & 1) ^ 1) * W8_BUF;
-        const char* tA = buf;
-        const char* tB = buf + W8_OPB;
+        const char* tA = a_cur;
+        char* tB = bimg + (kt & 1) * W8_OPB;
+        const bool live2 = kt + 2 < nk;
+        soffA += stepA; soffB += stepB;          // tile kt + 2
         // ---- p0
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -137,8 +271,7 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i][ks] = w8_frag<AT>(tA, ab + i, ks, lane);
         }
-        soffA += stepA;
-        la.issue(obuf, wave, soffA, kt + 1 < nk);
+        la.template issue2<0>(a_fill, wave, soffA, live2);
         W8_MFMA_PHASE(0, 0, fb0, 4)
         // ---- p1
 #pragma unroll
@@ -146,24 +279,36 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb1[j][ks] = w8_frag<BT>(tB, nbk + 2 + j, ks, lane);
         }
+        la.template issue2<2>(a_fill, wave, soffA, live2);
         W8_MFMA_PHASE(0, 1, fb1, 4)
-        // ---- p2
+        // ---- p2   (every wave retired its B reads of this tile before the first barrier of its p1)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < NH; ++i) fa[i][ks] = w8_frag<AT>(tA, ab + 4 + i, ks, lane);
         }
+        lb.template issue2<0>(tB, wave, soffB, live2);
         W8_MFMA_PHASE(1, 1, fb1, NH)
         // ---- p3
-        soffB += stepB;
-        lb.issue(buf + W8_OPB, wave, soffB, kt + 2 < nk);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but B(kt+2): tile kt+1 has landed (this wave's pieces)
+        lb.template issue2<2>(tB, wave, soffB, live2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but tile kt+2's 8 pieces: tile kt+1 has landed (this wave's pieces)
         W8_MFMA_PHASE(1, 0, fb0, NH)
+        char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
     }
-    if ((wave >> 2) == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may still target this block's LDS when it retires
-    gemm_epilogue_blk<4>(d, acc[0], m0 + ab * 16, n0 + wc * 64, mlimit, 4, z1, z2, ksplit, lane);
-    if (NH > 0) gemm_epilogue_blk<4>(d, acc[1], m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, NH, z1, z2, ksplit, lane);
+    if ((wave >> 2) == 0) __builtin_amdgcn_s_barrier();      // balance the stagger: every wave is past its last LDS read
+    // the tail iterations issued out-of-range pieces (zeros) into the rings: none may land in another wave's epilogue block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    w8_stamp(d, 2, lane, wave);
+    {
+        const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
+        const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
+        char* wlds = smem + wave * 16384;
+        w8_epilogue_pass(d, acc[0], 4, wlds, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        if (NH > 0) w8_epilogue_pass(d, acc[1], NH, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w8_stamp(d, 3, lane, wave);
 }
 
 template <bool AT, bool BT, int RB0, int RB1>
@@ -172,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
+    w8_stamp(d, 0, lane, wave);
     const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn, d.group_m);
@@ -194,12 +340,14 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
     unsigned soffA = (unsigned)kt0 * stepA, soffB = (unsigned)kt0 * stepB;
 
-    // prologue: all of tile 0, B of tile 1
-    la.issue(smem, wave, soffA, nk > 0);
-    lb.issue(smem + W8_OPB, wave, soffB, nk > 0);
-    soffB += stepB;
-    lb.issue(smem + W8_BUF + W8_OPB, wave, soffB, nk > 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // prologue: tiles 0 and 1 (16 pieces per wave)
+    la.template issue2<0>(smem, wave, soffA, nk > 0); la.template issue2<2>(smem, wave, soffA, nk > 0);
+    lb.template issue2<0>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0); lb.template issue2<2>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0);
+    soffA += stepA; soffB += stepB;
+    la.template issue2<0>(smem + W8_OPB, wave, soffA, nk > 1); la.template issue2<2>(smem + W8_OPB, wave, soffA, nk > 1);
+    lb.template issue2<0>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1); lb.template issue2<2>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    w8_stamp(d, 1, lane, wave);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // wave row 1 runs half a phase behind wave row 0
 
@@ -212,17 +360,156 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     }
 }
 
+// ---- single-barrier variant ("w8s") ---------------------------------------------------------------------------------------
+// Ablation of the ping-pong loop above on MI355X (tools/abl.sh, profiles/r2_gemm_ablation.txt): with DMA, LDS reads and MFMAs
+// all removed the 16 K steps of a block still took 11 us — 16 s_barrier per wave and K step cost ~0.7 us of a 1.44-us step, and
+// the MFMA bursts do not overlap them.  This variant keeps the tile, the LDS images, the rings and the epilogue but has ONE
+// barrier per K step: each wave double-buffers its fragments in registers per 32-deep sub-step, so the MFMAs of one sub-step
+// run while the LDS reads of the next are in flight — also across the barrier, where the second sub-step of tile t multiplies
+// while the first fragments of tile t+1 are read.  Per K step t:
+//     wait(set 0) | read set 1 <- tile t, k 32..63 | MFMA set 0 | DMA A(t+2) -> A ring | wait(set 1) | vmcnt(4): tile t+1 landed
+//     BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
+//     DMA B(t+2) -> B image of tile t | read set 0 <- tile t+1, k 0..31 | MFMA set 1
+// A pieces have two K steps to land, B pieces one.  Same K order per output element: bit-identical to the other kernels.
+template <bool AT, bool BT, int RBW>
+__device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typename W8Sel<AT>::type& la, const typename W8Sel<BT>::type& lb,
+                                         int nk, unsigned soffA, unsigned soffB, int ab, int m0, int n0, int mlimit,
+                                         int z1, int z2, int ksplit, int lane, int wave, int wc) {
+    const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
+    f32x4 acc[RBW][4];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa0[RBW], fa1[RBW], fb0[4], fb1[4];
+    const int nbk = wc * 4;
+    char* const bimg = smem + W8_NA * W8_OPB;
+    char *a_cur = smem, *a_nxt = smem + W8_OPB, *a_fill = smem + 2 * W8_OPB;
+#define W8S_READ(FA, FB, TA, TB, KS)                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = w8_frag<BT>(TB, nbk + j, KS, lane); \
+    _Pragma("unroll") for (int i = 0; i < RBW; ++i) FA[i] = w8_frag<AT>(TA, ab + i, KS, lane);
+#define W8S_MFMA(FA, FB)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
+    // tile 0 is visible (the caller's barrier); tiles 0 and 1 were staged, soffA / soffB point at tile 1
+    W8S_READ(fa0, fb0, a_cur, bimg, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        char* tB = bimg + (kt & 1) * W8_OPB;
+        const bool live2 = kt + 2 < nk;
+        soffA += stepA; soffB += stepB;          // tile kt + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W8S_READ(fa1, fb1, a_cur, tB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W8S_MFMA(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        la.template issue2<0>(a_fill, wave, soffA, live2); la.template issue2<2>(a_fill, wave, soffA, live2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // all but A(kt+2): tile kt+1 has landed (this wave's pieces)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        lb.template issue2<0>(tB, wave, soffB, live2); lb.template issue2<2>(tB, wave, soffB, live2);
+        if (kt + 1 < nk) { W8S_READ(fa0, fb0, a_nxt, bimg + ((kt & 1) ^ 1) * W8_OPB, 0) }
+        __builtin_amdgcn_sched_barrier(0);
+        W8S_MFMA(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
+    }
+#undef W8S_READ
+#undef W8S_MFMA
+    // the tail iterations issued out-of-range pieces (zeros) into the rings: none may land in another wave's epilogue block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    w8_stamp(d, 2, lane, wave);
+    {
+        const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
+        const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
+        char* wlds = smem + wave * 16384;
+        f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
+        w8_epilogue_pass(d, alo, 4, wlds, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        if (RBW > 4) {
+            f32x4 hi[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            w8_epilogue_pass(d, hi, RBW - 4, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w8_stamp(d, 3, lane, wave);
+}
+
+template <bool AT, bool BT, int RB0, int RB1>
+__global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int wr = wave >> 2, wc = wave & 3;
+    w8_stamp(d, 0, lane, wave);
+    const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn, d.group_m);
+    const int m0 = tm * d.tile_m, n0 = tn * W8_BN;
+    const int mlimit = min(d.M, m0 + d.tile_m);
+    int z = blockIdx.z;
+    const int ksplit = z % d.splitk; z /= d.splitk;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int nk_total = d.K / BK;
+    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int kt0 = ksplit * nk_per;
+    const int nk = max(0, min(nk_per, nk_total - kt0));
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    typename W8Sel<AT>::type la;
+    typename W8Sel<BT>::type lb;
+    la.init(d.A, Ab, m0, mlimit, lane, wave);
+    lb.init(d.B, Bb, n0, d.N, lane, wave);
+    const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
+    unsigned soffA = (unsigned)kt0 * stepA, soffB = (unsigned)kt0 * stepB;
+    la.template issue2<0>(smem, wave, soffA, nk > 0); la.template issue2<2>(smem, wave, soffA, nk > 0);
+    lb.template issue2<0>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0); lb.template issue2<2>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0);
+    soffA += stepA; soffB += stepB;
+    la.template issue2<0>(smem + W8_OPB, wave, soffA, nk > 1); la.template issue2<2>(smem + W8_OPB, wave, soffA, nk > 1);
+    lb.template issue2<0>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1); lb.template issue2<2>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    w8_stamp(d, 1, lane, wave);
+    __builtin_amdgcn_s_barrier();
+    if (RB0 == RB1) {
+        w8s_body<AT, BT, RB0>(d, smem, la, lb, nk, soffA, soffB, wr * RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+    } else if (wr == 0) {
+        w8s_body<AT, BT, RB0>(d, smem, la, lb, nk, soffA, soffB, 0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+    } else {
+        w8s_body<AT, BT, RB1>(d, smem, la, lb, nk, soffA, soffB, RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+    }
+}
+
 template <int RB0, int RB1>
-void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s) {
+void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, int mode) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8_kernel<true, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         attr_set = true;
     }
     const dim3 block(512);
+    if (mode == 1) {
+        if (!at && !bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else if (!at && bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else if (at && !bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else hipLaunchKernelGGL((scl_gemm_w8s_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+        return;
+    }
     if (!at && !bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
     else if (!at && bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
     else if (at && !bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
@@ -243,10 +530,12 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
     const long long tiles_n = (d.N + W8_BN - 1) / W8_BN;
     long long best = -1;
     for (int v = 0; v < 2; ++v) {
-        const int bm = v == 0 ? 208 : 256, blocks = v == 0 ? 13 : 16;
+        // the K loop of either tile is bound by the per-CU L2 -> LDS feed (stamps + ablation, profiles/r2_gemm_*): a round costs
+        // ~ (tile rows + 256 columns) x K bytes per CU, not the MFMA count
+        const int bm = v == 0 ? 208 : 256;
         const long long ntm = (d.M + bm - 1) / bm;
         const long long rounds = (ntm * tiles_n * zdim + ncu - 1) / ncu;
-        const long long cost = rounds * blocks;
+        const long long cost = rounds * (bm + W8_BN);
         if (best < 0 || cost < best) {
             best = cost;
             plan->variant = v; plan->tiles_m = (int)ntm; plan->tile_m = (int)((d.M + ntm - 1) / ntm);
@@ -256,11 +545,21 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
     return true;
 }
 
+int scl_gemm_read_stamps(unsigned long long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(scl_gemm_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+}
+
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s) {
     k.tile_m = plan.tile_m;
+    { const char* e = getenv("SCL_W8_DEBUG"); k.debug = e ? atoi(e) : 0; }
     const dim3 grid((unsigned)plan.tiles, 1, (unsigned)zdim);
-    if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, grid, s);
-    else w8_launch_rb<8, 8>(k, at, bt, grid, s);
+    // 1: single barrier per K step, 0: two-barrier ping-pong.  A/B on MI355X (profiles/r2_gemm_ab.txt): equal within 3 % on the forward
+    // and dgrad shapes (single barrier ahead), the ping-pong 2-9 % ahead when both operands are transposed (wgrads: twice the LDS
+    // read instructions per fragment)
+    const char* me = getenv("SCL_W8_MODE");
+    const int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
+    if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, grid, s, mode);
+    else w8_launch_rb<8, 8>(k, at, bt, grid, s, mode);
     return 0;
 }
 

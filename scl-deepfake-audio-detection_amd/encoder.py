@@ -207,8 +207,15 @@ class Encoder:
     # ---- helpers ---------------------------------------------------------------------------------
     def _wgrad(self, d, A, B_, out, Mo, No, Kr, **kw):
         """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small."""
+        ksteps = (Kr + 63) // 64
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128) * kw.get("nb2", 1)
-        sk = _splitk(tiles, (Kr + 63) // 64)
+        sk = _splitk(tiles, ksteps)
+        # wide tiles (gemm_w8.hip: 256 x 256 output tiles, one 8-wave block per CU): size the split for one round of the 256 CUs
+        t256 = ((Mo + 255) // 256) * ((No + 255) // 256) * kw.get("nb2", 1)
+        if t256 >= 32:
+            skw = max(1, min(8, (256 + t256 // 2) // t256, ksteps // 8))
+            if ops.gemm_wide_kind(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, splitk=skw, c_split_stride=out.numel() if skw > 1 else 0, **kw):
+                sk = skw
         if sk == 1:
             ops.gemm(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, **kw)
             return

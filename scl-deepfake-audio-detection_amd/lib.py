@@ -51,6 +51,7 @@ GEMM_FORCE_W8 = 0x02000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 KID_GEMM = 0
+KID_AUG = 1
 
 _vp, _i32, _i64, _f32, _f64, _u32 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
                                      ctypes.c_double, ctypes.c_uint32)
@@ -67,6 +68,8 @@ def _protos():
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
+        "scl_debug_gemm_stamps": ([_vp, _i32], _i32),
+        "scl_gemm_uses_wide_tiles": ([P(SclGemmDesc)], _i32),
         # norm.hip
         "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
         "scl_layernorm_bwd_nparts": ([_i32], _i32),

@@ -89,6 +89,24 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
          c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
+    d = _gemm_desc(A, B, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=act, c2=c2, R=R, rmode=rmode, ract=ract, alpha=alpha, nb1=nb1,
+                   nb2=nb2, splitk=splitk, ldc=ldc, c_rpb=c_rpb, c_rbstride=c_rbstride, c_bs1=c_bs1, c_bs2=c_bs2, c_offset=c_offset,
+                   bias_bs2=bias_bs2, bias_offset=bias_offset, drop_p=drop_p, drop_seed=drop_seed, c_split_stride=c_split_stride,
+                   no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8)
+    _call("scl_gemm_bf16", ctypes.byref(d), _stream(), keep=d)
+    return d
+
+
+def gemm_wide_kind(A, B, C, M, N, K, **kw):
+    """0 if scl_gemm_bf16 would use the 128x128 tiles for this call, 1 / 2 for the wide tiles (gemm_w8.hip); same arguments as gemm()."""
+    d = _gemm_desc(A, B, C, M, N, K, **kw)
+    return L.load().scl_gemm_uses_wide_tiles(ctypes.byref(d))
+
+
+def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
+               alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
+               c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False,
+               force_p8=False, force_big=False, no_w8=False, force_w8=False):
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
     flags = 0
@@ -136,7 +154,6 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
     d.c_rpb, d.ldc = c_rpb, (N if ldc is None else ldc)
     d.M, d.N, d.K, d.nb1, d.nb2, d.splitk = M, N, K, nb1, nb2, splitk
     d.flags, d.alpha, d.drop_p, d.drop_seed = flags, alpha, drop_p, drop_seed
-    _call("scl_gemm_bf16", ctypes.byref(d), _stream(), keep=d)
     return d
 
 

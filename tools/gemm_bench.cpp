@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
     cases.push_back({"square 4096", 4096, 4096, 4096, false, false, 1, 0});
     cases.push_back({"square 8192", 8192, 8192, 8192, false, false, 1, 0});
 
+    if (only) { std::vector<Case> f; for (auto& c : cases) if (c.name.find(only) != std::string::npos) f.push_back(c); cases = f; }
     size_t maxA = 0, maxB = 0, maxC = 0;
     for (auto& c : cases) {
         maxA = std::max(maxA, (size_t)c.M * c.K); maxB = std::max(maxB, (size_t)c.N * c.K);
@@ -110,6 +111,28 @@ int main(int argc, char** argv) {
             printf(" %s %7.1f us %6.0f TF |", vars[v].name, med[v], fl / med[v] / 1e6);
         }
         printf(" w8/t128 x%.2f  bitwise p8:%d w8:%d\n", med[0] / med[2], (int)same[1], (int)same[2]);
+        if (getenv("STAMPS")) {   // one stamped launch of the wide kernel: where a block's time goes
+            SclGemmDesc d = desc(1, SCL_GEMM_FORCE_W8 | SCL_GEMM_STAMPS);
+            scl_gemm_bf16(&d, st); CK(hipStreamSynchronize(st));
+            const long long tn_ = (c.N + 255) / 256, z_ = c.splitk;
+            const long long n208 = (c.M + 207) / 208, n256 = (c.M + 255) / 256;
+            const long long c208 = ((n208 * tn_ * z_ + 255) / 256) * 13, c256 = ((n256 * tn_ * z_ + 255) / 256) * 16;
+            const int nb = (int)std::min(4096ll, (c208 <= c256 ? n208 : n256) * tn_);
+            std::vector<unsigned long long> sp(8 * (size_t)nb);
+            if (scl_debug_gemm_stamps(sp.data(), nb) == 0) {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (int b = 0; b < nb; ++b) { t0 = std::min(t0, sp[8 * b]); t1 = std::max(t1, sp[8 * b + 6]); }
+                std::vector<double> st0, pro, loop, epi, clk;
+                for (int b = 0; b < nb; ++b) {
+                    st0.push_back((sp[8 * b] - t0) * 0.01); pro.push_back((sp[8 * b + 2] - sp[8 * b]) * 0.01);
+                    loop.push_back((sp[8 * b + 4] - sp[8 * b + 2]) * 0.01); epi.push_back((sp[8 * b + 6] - sp[8 * b + 4]) * 0.01);
+                    clk.push_back((double)(sp[8 * b + 5] - sp[8 * b + 3]) / std::max(1.0, (double)(sp[8 * b + 4] - sp[8 * b + 2])) * 0.1);
+                }
+                auto q = [](std::vector<double>& v, double f) { std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+                printf("    stamps(%d blocks): span %.1f us | start med %.1f max %.1f | prologue med %.1f max %.1f | loop med %.1f max %.1f | epilogue med %.1f max %.1f | loop clock %.2f GHz\n",
+                       nb, (t1 - t0) * 0.01, q(st0, .5), q(st0, 1), q(pro, .5), q(pro, 1), q(loop, .5), q(loop, 1), q(epi, .5), q(epi, 1), q(clk, .5));
+            }
+        }
         fflush(stdout);
     }
     return 0;
