@@ -366,7 +366,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
 // the MFMA bursts do not overlap them.  This variant keeps the tile, the LDS images, the rings and the epilogue but has ONE
 // barrier per K step: each wave double-buffers its fragments in registers per 32-deep sub-step, so the MFMAs of one sub-step
 // run while the LDS reads of the next are in flight — also across the barrier, where the second sub-step of tile t multiplies
-// while the first fragments of tile t+1 are read.  Per K step t:
+// while the first fragments of tile t+1 are read.  Ablation of THIS loop (16 K steps, 208 x 256 tile, profiles/r2_gemm_ablation.txt):
+// all 22.9 us, MFMA only 17.6, LDS reads only 8.8, DMA only 11.1 (84 GB/s per CU), nothing 4.6 — the loop is MFMA-paced at the
+// 1.8-2.0 GHz the chip holds under this load; running wave row 1 half a step out of phase (read | MFMA swapped) measured +-2 %.
+// Per K step t:
 //     wait(set 0) | read set 1 <- tile t, k 32..63 | MFMA set 0 | DMA A(t+2) -> A ring | wait(set 1) | vmcnt(4): tile t+1 landed
 //     BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
 //     DMA B(t+2) -> B image of tile t | read set 0 <- tile t+1, k 0..31 | MFMA set 1
@@ -551,7 +554,7 @@ int scl_gemm_read_stamps(unsigned long long* out, int nblocks) {
 
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s) {
     k.tile_m = plan.tile_m;
-    { const char* e = getenv("SCL_W8_DEBUG"); k.debug = e ? atoi(e) : 0; }
+    k.debug = 0;
     const dim3 grid((unsigned)plan.tiles, 1, (unsigned)zdim);
     // 1: single barrier per K step, 0: two-barrier ping-pong.  A/B on MI355X (profiles/r2_gemm_ab.txt): equal within 3 % on the forward
     // and dgrad shapes (single barrier ahead), the ping-pong 2-9 % ahead when both operands are transposed (wgrads: twice the LDS
