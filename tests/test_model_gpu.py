@@ -70,7 +70,7 @@ def test_train_step_matches_reference_golden(dev):
     losses = m.loss(out, feats, emb, y, CONF)
     for k in ("L_CE", "L_CF1", "L_CF2"):
         ref = float(g["loss:" + k])
-        assert abs(losses[k].item() - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, losses[k].item(), ref)
+        assert abs(losses[k].item() - ref) <= 1e-2 * max(abs(ref), 1e-3), (k, losses[k].item(), ref)   # north_star: 1e-2 rel at bf16
     train_loss = 0.0
     for v in losses.values():
         train_loss = train_loss + v
@@ -291,3 +291,91 @@ def test_full_size_xlsr_forward_matches_oracle(dev):
     print("full-size rel-L2: out %.2e feats %.2e emb %.2e ; max-rel feats %.2e" % (rl2(out, ro), rl2(feats, rf), rl2(emb, re), relerr(feats, rf)))
     assert rl2(out, ro) < 1e-2 and rl2(feats, rf) < 1e-2 and rl2(emb, re) < 1e-2
     assert (out.argmax(1).cpu() == ro.argmax(1)).all()
+
+
+def _full_size_model(dev, seed_ssl=61, seed_head=62):
+    from scl_amd.encoder import W2VConfig
+    ocfg = W.W2VConfig()
+    ssl, head = W.init_state(ocfg, seed=seed_ssl), OH.init_head(ocfg.embed, seed=seed_head)
+    m = Model(ARGS, dev, w2v_cfg=W2VConfig())
+    sd = {"ssl_model.model." + k: v for k, v in ssl.items()}
+    sd.update(head)
+    _, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m.eval()          # dropout off: the oracle's masks cannot be shared
+    return m, ssl, head, ocfg
+
+
+# one tensor per GEMM layout class of the backward (conv wgrad with overlapping rows, grouped pos-conv weight-norm pair, q/k/v/out, fc1/fc2,
+# LayerNorm parameters, the head's LL) in a shallow, a middle and the deepest layer
+FULL_SIZE_GRADS = [
+    "ssl_model.model.feature_extractor.conv_layers.0.0.weight", "ssl_model.model.feature_extractor.conv_layers.1.0.weight",
+    "ssl_model.model.feature_extractor.conv_layers.6.0.weight", "ssl_model.model.feature_extractor.conv_layers.3.2.1.weight",
+    "ssl_model.model.post_extract_proj.weight", "ssl_model.model.encoder.pos_conv.0.weight_v", "ssl_model.model.encoder.pos_conv.0.weight_g",
+    "ssl_model.model.encoder.layers.0.self_attn.q_proj.weight", "ssl_model.model.encoder.layers.0.self_attn.k_proj.weight",
+    "ssl_model.model.encoder.layers.0.self_attn.v_proj.weight", "ssl_model.model.encoder.layers.0.self_attn.out_proj.weight",
+    "ssl_model.model.encoder.layers.0.fc1.weight", "ssl_model.model.encoder.layers.0.fc2.weight", "ssl_model.model.encoder.layers.0.fc1.bias",
+    "ssl_model.model.encoder.layers.11.fc1.weight", "ssl_model.model.encoder.layers.11.self_attn.q_proj.bias",
+    "ssl_model.model.encoder.layers.23.self_attn.out_proj.weight", "ssl_model.model.encoder.layers.23.fc2.weight",
+    "ssl_model.model.encoder.layers.23.final_layer_norm.weight", "ssl_model.model.encoder.layer_norm.bias", "LL.weight", "LL.bias",
+    "backend.m_frame_level.0.weight", "backend.m_utt_level.weight",
+]
+
+
+def test_full_size_train_step_matches_oracle_at_baseline_shape(dev):
+    """BASELINE shape: XLS-R-300M encoder (24 x 1024 x 16 heads x 4096), 4 x 64000-sample clips (T = 199), dropout off — forward
+    outputs, the three loss terms (north_star bar: 1e-2 relative at bf16) and 24 gradient tensors covering every GEMM layout
+    class of the backward, against oracle.head.train_step (torch fp32 autograd on the CPU, pinned to the reference's Model /
+    loss by tests/golden/train_step.npz).  Model.loss here is the reference's (wav2vec2_linear_nll.py:158-192)."""
+    m, ssl, head, ocfg = _full_size_model(dev)
+    x = 0.1 * torch.randn(4, 64000, generator=torch.Generator().manual_seed(1234))
+    y = torch.tensor([1, 1, 0, 0])
+    out, feats, emb = m(x.to(dev))
+    losses = m.loss(out, feats, emb, y.to(dev), CONF)
+    total = sum(losses.values())
+    for p in m.parameters():
+        p.grad = None
+    total.backward()
+    torch.cuda.synchronize()
+    ref_losses, ref_grads, (ro, rf, re), _ = OH.train_step(ssl, head, ocfg, x, y)
+    print("4 x 64000 rel-L2: out %.2e feats %.2e emb %.2e" % (rl2(out, ro), rl2(feats, rf), rl2(emb, re)))
+    assert rl2(out, ro) < 1e-2 and rl2(feats, rf) < 1e-2 and rl2(emb, re) < 1e-2
+    for k, v in ref_losses.items():
+        print("loss %s: %.6f vs oracle %.6f (rel %.2e)" % (k, losses[k].item(), v, abs(losses[k].item() - v) / max(abs(v), 1e-6)))
+        assert abs(losses[k].item() - v) <= 1e-2 * max(abs(v), 1e-3), (k, losses[k].item(), v)
+    bad = []
+    for name in FULL_SIZE_GRADS:
+        got, ref = m.P.g(name).float().cpu().flatten(), ref_grads[name].flatten()
+        e, c = rl2(got, ref), cosine(got, ref)
+        print("grad %-70s rel-L2 %.2e cos %.6f" % (name, e, c))
+        # the frame-level head linears back-propagate the broadcast mean-pool gradient (identical rows x LeakyReLU masks) through bf16
+        # operands: their rounding is systematic over the T rows instead of averaging out (measured 8e-2 / 0.9969)
+        lim_e, lim_c = (1.2e-1, 0.995) if name.startswith("backend.m_frame_level") else (6e-2, 0.998)
+        if not (e < lim_e and c > lim_c):
+            bad.append((name, e, c))
+    assert not bad, bad
+
+
+def test_batch_64_auto_selected_tiles_agree_with_the_validated_small_batch(dev):
+    """bench.py's shape (batch 64 x 64000: M = 12736 rows, where the wide-tile GEMM kernels and their split-K plans are picked
+    automatically) cannot be run through the CPU oracle in test time.  Every utterance's forward is independent of the others, and
+    the row tiles only re-partition M, so the first 4 rows of a batch-64 step must reproduce the batch-4 step that the test above
+    checks against the oracle: outputs to bf16 round-off, and the per-utterance losses entering a batch of the same labels."""
+    m, _, _, _ = _full_size_model(dev)
+    g = torch.Generator().manual_seed(1234)
+    x4 = 0.1 * torch.randn(4, 64000, generator=g)
+    x64 = torch.cat([x4, 0.1 * torch.randn(60, 64000, generator=g)]).to(dev)
+    with torch.no_grad():
+        o4, f4, e4 = [t.clone() for t in m(x4.to(dev))]
+        o64, f64, e64 = m(x64)
+    print("batch 64 vs batch 4 rel-L2: out %.2e feats %.2e emb %.2e" % (rl2(o64[:4], o4.cpu()), rl2(f64[:4], f4.cpu()), rl2(e64[:4], e4.cpu())))
+    assert rl2(o64[:4], o4.cpu()) < 2e-3 and rl2(f64[:4], f4.cpu()) < 2e-3 and rl2(e64[:4], e4.cpu()) < 2e-3
+    # one full train step at this size: finite losses in the band of a random-init model, finite gradients everywhere
+    m.train()
+    y = torch.tensor(([1] * 29 + [0] * 64)[:64], device=dev)
+    out, feats, emb = m(x64)
+    losses = m.loss(out, feats, emb, y, CONF)
+    total = sum(losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    assert 0.0 < total.item() < 1.0 and torch.isfinite(m.P.grad[: m.P.n_train]).all()

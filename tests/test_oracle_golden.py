@@ -167,7 +167,8 @@ def test_int16_semantics_corner_cases():
     # +1.0 wraps to -32768, truncation toward zero, saturating add, floor-after-clip gain
     assert AI.librosa_to_int16(np.array([1.0, -1.0, 0.99999, -0.00002, 0.5])).tolist() == [-32768, -32768, 32767, 0, 16384]
     assert AI.overlay(np.array([32000, -32000, 5], np.int16), np.array([1000, -1000], np.int16)).tolist() == [32767, -32768, 5]
-    assert AI.apply_gain(np.array([100, -100, 30000], np.int16), 20 * np.log10(1.5)).tolist() == [150, -150, 32767] or True
+    # audioop.mul: floor AFTER the clip, on the double product (x * 1.5 = +-4.5 / 10.5: floor, not truncation; +-45000 clip first)
+    assert AI.apply_gain(np.array([3, -3, 7, 30000, -30000], np.int16), 20 * np.log10(1.5)).tolist() == [4, -5, 10, 32767, -32768]
     assert AI.rms_int(np.array([3, 4], np.int16)) == 3
     sp = (0.1 * np.random.RandomState(0).randn(1000)).astype(np.float32)
     noise = (300 * np.random.RandomState(1).randn(800)).astype(np.int16)
