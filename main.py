@@ -109,7 +109,14 @@ def run_epoch(loader, model, optimizer, device, config, train):
                     optimizer.grad_sync.begin()
                 step_loss.backward()
                 optimizer.step()
-    # one host sync per epoch
+    # one host sync per epoch.  Data-parallel validation: the shards differ in size (drop_last=False), so the sums — not the per-rank
+    # ratios — are all-reduced: accuracy and losses are the same global numbers a single-GPU run logs
+    if not train and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        keys = sorted(sums)
+        t = torch.stack([total_sum, correct, torch.tensor(float(n_total), device=device)] + [sums[k].float() for k in keys])
+        torch.distributed.all_reduce(t)
+        total_sum, correct, n_total = t[0], t[1], float(t[2])
+        sums = {k: t[3 + i] for i, k in enumerate(keys)}
     detail = {k: float(v) for k, v in sums.items()}
     return float(total_sum), float(correct) / max(n_total, 1.0) * 100.0, detail
 
@@ -161,6 +168,20 @@ def produce_emb_file(dataset, model, device, save_path, batch_size=10):
                 fh.write("{} {} {}\n".format(f, cm[0], cm[1]))
     _score_loop(dataset, model, device, batch_size, emit)
     print("Scores saved to {}".format(save_path))
+
+
+def merge_rank_outputs(path, world, n_items):
+    """Rank r scored items r, r + world, ...: interleave the shards back into protocol order and drop them."""
+    shards = []
+    for r in range(world):
+        with open("%s.rank%d" % (path, r)) as fh:
+            shards.append(fh.read().splitlines())
+    with open(path, "a+") as out:
+        for i in range(n_items):
+            out.write(shards[i % world][i // world] + "\n")
+    for r in range(world):
+        os.remove("%s.rank%d" % (path, r))
+    print("Scores of %d ranks merged into %s" % (world, path))
 
 
 def build_parser():
@@ -217,12 +238,14 @@ def main(argv=None):
         config = yaml.load(f, Loader=yaml.FullLoader)
     data_mod = importlib.import_module("datautils." + config["data"]["name"])
     genList, Dataset_for, Dataset_for_eval = data_mod.genList, data_mod.Dataset_for, data_mod.Dataset_for_eval
-    model = MODEL_REGISTRY[config["model"]["name"]](config["model"], device)
+    # --seed initialises the weights (02_train.sh: "random seed to initialize the weight") and, with the rank, the dropout stream
+    model = MODEL_REGISTRY[config["model"]["name"]](config["model"], device, seed=args.seed, rank=rank)
     print("nb_params:", sum(p.numel() for p in model.parameters()))
 
     from scl_amd.optim import FusedAdamW
     from scl_amd.parallel import GradSync, shard_indices
-    sync = GradSync(model.P.grad) if world > 1 else None
+    g_lo, g_hi = model.trainable_range()
+    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo) if world > 1 else None
     optimizer = FusedAdamW(model, lr=args.max_lr, weight_decay=args.weight_decay, grad_sync=sync)
     scheduler = torch.optim.lr_scheduler.CyclicLR(optimizer, base_lr=args.min_lr, max_lr=args.max_lr, step_size_up=3,
                                                   mode="exp_range", gamma=0.85, cycle_momentum=False)
@@ -233,21 +256,35 @@ def main(argv=None):
         print("Model loaded")
     else:
         print("Model initialized")
+        if not getattr(model, "pretrained_loaded", False):
+            msg = ("no --model_path and no pre-trained XLS-R checkpoint (pretrained/xlsr2_300m.pt, model/xlsr.py:14): the 300 M-parameter "
+                   "encoder starts from seeded random noise")
+            if args.eval:
+                sys.exit("main.py --eval: " + msg + "; refusing to score with it")
+            print("WARNING: " + msg + " — the reference fine-tunes the pre-trained encoder")
 
     proto = os.path.join(args.database_path, "protocol.txt")
     if args.eval:
+        if not args.eval_output:
+            sys.exit("main.py --eval needs --eval_output")
         _, file_eval = genList(dir_meta=proto, is_train=False, is_eval=True)
         print("no. of eval trials", len(file_eval))
         eval_set = Dataset_for_eval(list_IDs=file_eval, base_dir=os.path.join(args.database_path + "/"), padding_type=args.padding_type)
+        final_output = args.eval_output
         if world > 1:
             eval_set = Subset(eval_set, list(range(rank, len(eval_set), world)))
-            args.eval_output = "%s.rank%d" % (args.eval_output, rank)
+            if not args.emb:          # per-rank score shards, merged below in protocol order (embeddings are one file per utterance)
+                args.eval_output = "%s.rank%d" % (final_output, rank)
         if args.predict:
             produce_prediction_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
         elif args.emb:
             produce_emb_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
         else:
             produce_evaluation_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
+        if world > 1 and not args.emb:
+            torch.distributed.barrier()
+            if rank == 0:
+                merge_rank_outputs(final_output, world, len(file_eval))
         return 0
 
     repeat = args.padding_type == "repeat"
@@ -276,10 +313,6 @@ def main(argv=None):
             train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=0, shuffle=True, drop_last=True)
         running_loss, train_acc, train_detail = run_epoch(train_loader, model, optimizer, device, config, train=True)
         val_loss, val_acc, val_detail = run_epoch(dev_loader, model, None, device, config, train=False)
-        if world > 1:
-            t = torch.tensor([val_acc], device=device)
-            torch.distributed.all_reduce(t)
-            val_acc = float(t) / world
         if writer is not None:
             for k, v in (("train_accuracy", train_acc), ("val_accuracy", val_acc), ("val_loss", val_loss), ("loss", running_loss)):
                 writer.add_scalar(k, v, epoch)

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .encoder import Encoder, W2VConfig, param_specs
-from .model_linear import init_parameters_, loss_custom
+from .model_linear import init_parameters_, loss_custom, maybe_load_pretrained
 from .ops import Op
 from .params import FlatParams, register_by_name
 
@@ -66,7 +66,7 @@ class FrontHeadModel(nn.Module):
     def _ssl_train(self):
         return bool(self.training)
 
-    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0):
+    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0, rank=0):
         super().__init__()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -118,6 +118,12 @@ class FrontHeadModel(nn.Module):
         # Python-level fallback can catch.
         self.use_graphs = os.environ.get("SCL_HEAD_GRAPH", "0") == "1"
         self.__dict__["_graphed"] = {}
+        self.pretrained_loaded = maybe_load_pretrained(self, args)
+        if rank:      # torch dropout in the back-end: decorrelate the data-parallel ranks' masks
+            torch.cuda.manual_seed(int(seed) * 1000003 + int(rank))
+
+    def trainable_range(self):
+        return 0, self.P.n_train
 
     # nn.Module plumbing ----------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):

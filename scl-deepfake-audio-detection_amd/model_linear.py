@@ -64,6 +64,26 @@ def init_parameters_(P, cfg, seed=0):
     P.mark_dirty()
 
 
+def dropout_stream_seed(seed, rank):
+    return (int(seed) * 2654435761 + int(rank) * 40503 + 12345) & 0x7FFFFFFF
+
+
+def maybe_load_pretrained(model, args):
+    """The reference's SSLModel loads pretrained/xlsr2_300m.pt at construction (model/xlsr.py:14-16).  Do the same when the file
+    (or the YAML's optional `pretrained:` path) exists; take encoder_layerdrop from its cfg unless the YAML overrides it."""
+    import os
+    from . import checkpoint
+    explicit = hasattr(args, "get") and args.get("pretrained")
+    path = explicit or checkpoint.DEFAULT_PRETRAINED
+    if not os.path.exists(path) or (not explicit and model.cfg.layers != 24):     # toy encoders never pick up the default file
+        return False
+    probs = checkpoint.load_pretrained_into(model, path)
+    if "encoder_layerdrop" in probs and "encoder_layerdrop" not in args:
+        model.cfg.encoder_layerdrop = probs["encoder_layerdrop"]
+    print("[scl] XLS-R weights loaded from %s (encoder_layerdrop %.3f)" % (path, model.cfg.encoder_layerdrop))
+    return True
+
+
 class _ModelFn(torch.autograd.Function):
     """Autograd boundary around the whole network: forward runs the kernels and keeps the activation
     buffers; backward consumes (d_logp, d_feats, d_emb) and fills the flat gradient buffer."""
@@ -83,7 +103,7 @@ class _ModelFn(torch.autograd.Function):
 
 
 class Model(nn.Module):
-    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0):
+    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0, rank=0):
         super().__init__()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -112,9 +132,15 @@ class Model(nn.Module):
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._hbufs = {}
         self._states = {}
-        self._step_seed = 0
+        self._step_seed = dropout_stream_seed(seed, rank)   # head dropout masks differ per --seed and per data-parallel rank
         self.out_dim = self.cfg.embed
         self.grad_sync = None   # scl_amd.parallel.GradSync when data-parallel (set by FusedAdamW)
+        self.pretrained_loaded = maybe_load_pretrained(self, args)
+
+    def trainable_range(self):
+        """[lo, hi) of the flat buffer that receives gradients: with flag_fix_ssl the encoder backward is skipped, and
+        torch.optim.AdamW in the reference leaves parameters whose .grad is None untouched (no weight decay, no all-reduce)."""
+        return (self.P.off("LL.weight") if self.flag_fix_ssl else 0), self.P.n_train
 
     # nn.Module plumbing ----------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):

@@ -15,9 +15,12 @@ from .resnet_head import DEFAULT_RESNET, ResNetHead
 
 
 class Model(FrontHeadModel):
-    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0):
-        super().__init__(args, device, is_train=is_train, w2v_cfg=w2v_cfg, seed=seed)
+    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0, rank=0):
+        super().__init__(args, device, is_train=is_train, w2v_cfg=w2v_cfg, seed=seed, rank=rank)
         self.flag_fix_ssl = bool(args.get("flag_fix_ssl", False))
+
+    def trainable_range(self):
+        return (self.P.off("LL.weight") if self.flag_fix_ssl else 0), self.P.n_train
 
     def _build_head(self, args):
         return ResNetHead(args.get("resnet") or DEFAULT_RESNET)

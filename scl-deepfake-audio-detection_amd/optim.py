@@ -102,8 +102,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.grad_sync is not None:
             scale = self.grad_sync.finish()
         self.step_count += 1
-        ops.adamw_flat(self.P.flat, self.P.grad, self.exp_avg, self.exp_avg_sq, self.P.bf16, self.P.n_train, float(g["lr"]),
-                       g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, scale)
+        # parameters that received no gradient (the whole encoder under flag_fix_ssl) are skipped, as torch.optim.AdamW skips
+        # .grad is None: no weight decay on frozen weights
+        lo, hi = self.model.trainable_range() if hasattr(self.model, "trainable_range") else (0, self.P.n_train)
+        ops.adamw_flat(self.P.flat[lo:hi], self.P.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.P.bf16[lo:hi], hi - lo,
+                       float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, scale)
         self.model.optimizer_stepped(bf16_fresh=True)
         return None
 

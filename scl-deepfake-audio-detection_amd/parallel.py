@@ -27,8 +27,11 @@ def shard_indices(n_items, rank, world, epoch_seed=None, drop_last=True):
 
 
 class GradSync:
-    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024):
+    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0):
+        """flat_grad: the slice of the flat gradient buffer that receives gradients (model.trainable_range()); `base` = its first
+        element's offset in the whole buffer (ready_above() is called with whole-buffer offsets)."""
         self.grad = flat_grad
+        self.base = int(base)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = flat_grad.numel()
@@ -49,6 +52,7 @@ class GradSync:
         """All gradient elements at offsets >= lo_offset are final: launch every bucket above it."""
         if self.world == 1:
             return
+        lo_offset = max(0, lo_offset - self.base)
         while self.launched < len(self.bounds) and self.bounds[self.launched][0] >= lo_offset:
             lo, hi = self.bounds[self.launched]
             self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -110,3 +110,48 @@ def test_fast_sampler_statistics():
     frac = np.array([len(p) / 64000 for p, _ in isd])
     assert 0 <= frac.min() and frac.max() <= 0.10 and 0.03 < frac.mean() < 0.07
     assert all(len(np.unique(p)) == len(p) for p, _ in isd)
+
+
+def test_fairseq_checkpoint_reader_survives_missing_packages(tmp_path):
+    """pretrained/xlsr2_300m.pt is a fairseq checkpoint: {'model': tensors, 'cfg': {'model': <omegaconf / dataclass object>}}.
+    The reader must work without fairseq / omegaconf installed: classes that cannot be imported become inert stubs, tensors and
+    the dropout / layerdrop probabilities are recovered (model/xlsr.py:14-16)."""
+    import pickle
+    import sys
+    import types
+    import torch
+    from scl_amd import checkpoint
+    mod = types.ModuleType("fairseq_like_pkg")
+
+    class FakeCfg:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    FakeCfg.__module__ = "fairseq_like_pkg"
+    FakeCfg.__qualname__ = "FakeCfg"
+    mod.FakeCfg = FakeCfg
+    sys.modules["fairseq_like_pkg"] = mod
+    sd = {"encoder.layers.0.fc1.weight": torch.arange(6.0).view(2, 3), "mask_emb": torch.ones(4)}
+    ck = {"model": sd, "cfg": {"model": FakeCfg(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0,
+                                                 dropout_features=0.0, encoder_layerdrop=0.05, _name="wav2vec2"), "task": FakeCfg(x=1)}}
+    path = tmp_path / "fake_fairseq.pt"
+    torch.save(ck, str(path), pickle_module=pickle)
+    del sys.modules["fairseq_like_pkg"]                      # the class is gone when the file is read back
+    tensors, probs = checkpoint.read_fairseq_checkpoint(str(path))
+    assert set(tensors) == set(sd) and torch.equal(tensors["encoder.layers.0.fc1.weight"], sd["encoder.layers.0.fc1.weight"])
+    assert probs["encoder_layerdrop"] == 0.05 and probs["dropout"] == 0.0 and len(probs) == 6
+    # old-style checkpoints carry an argparse.Namespace under 'args'
+    import argparse
+    torch.save({"model": sd, "args": argparse.Namespace(dropout=0.1, encoder_layerdrop=0.0)}, str(path))
+    _, probs = checkpoint.read_fairseq_checkpoint(str(path))
+    assert probs == {"dropout": 0.1, "encoder_layerdrop": 0.0}
+
+
+def test_merge_rank_outputs_restores_protocol_order(tmp_path):
+    import main as M
+    path = str(tmp_path / "scores.txt")
+    lines = ["utt%d 0.%d 1" % (i, i) for i in range(7)]
+    for r in range(3):
+        with open("%s.rank%d" % (path, r), "w") as fh:
+            fh.write("\n".join(lines[r::3]) + "\n")
+    M.merge_rank_outputs(path, 3, 7)
+    assert open(path).read().splitlines() == lines and not os.path.exists(path + ".rank0")
