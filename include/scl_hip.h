@@ -39,6 +39,7 @@ const char* scl_last_error(void);
  * the kernel family `kid` (SCL_KID_*) is bracketed by two hipEvents on the launch stream.
  * scl_prof_read synchronises those events and returns launch count and summed milliseconds. */
 #define SCL_KID_GEMM 0
+#define SCL_KID_GEMM_F32 2   /* the f32-operand GEMM (scoring path, AASIST / ResNet back-ends) */
 #define SCL_KID_AUG  1   /* the RawBoost chain: scl_fir_multi_f32, scl_clip_stats_f32, scl_isd_scatter_f32, scl_clip_affine_f32 */
 #define SCL_KID_MAX  8
 int scl_prof_enable(int kid, int on);
@@ -81,6 +82,7 @@ typedef struct SclOperand {
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
 #define SCL_GEMM_NO_W8    0x01000000  /* never the wide-tile (<=208/256 x 256, runtime row pitch) ping-pong kernel of gemm_w8.hip */
 #define SCL_GEMM_FORCE_W8 0x02000000  /* pick it whenever it can address the operands (testing / A-B comparison) */
+#define SCL_GEMM_AB_F32   0x40000000  /* A and B are f32 (strides in f32 elements, multiples of 4): exact-fp32 MFMA kernel (gemm_f32.hip) */
 #define SCL_GEMM_STAMPS   0x20000000  /* diagnostic: the wide kernels record per-block time stamps (scl_debug_gemm_stamps) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
 #define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */

@@ -649,6 +649,9 @@ __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* 
     }
 }
 
+}  // namespace
+
+namespace sclg {
 // Granlund-Montgomery round-up magic: q = (mulhi(magic, n) + n) >> shift for all n < 2^31, 1 <= d < 2^31
 void make_magic(unsigned dv, unsigned* magic, unsigned* shift) {
     unsigned l = 0;
@@ -657,32 +660,32 @@ void make_magic(unsigned dv, unsigned* magic, unsigned* shift) {
     *magic = (unsigned)((((1ull << l) - dv) << 32) / dv + 1);
 }
 
-bool fill_operand(const SclOperand& o, const char* name, long long rows, long long contig, OpK* k) {
+// host SclOperand -> device OpK for elements of `esz` bytes (2: bf16, 4: f32); 16-byte vectors = 16 / esz elements
+bool fill_operand(const SclOperand& o, const char* name, long long rows, long long contig, OpK* k, int esz) {
+    const int vec = 16 / esz;
     if (!o.ptr || ((uintptr_t)o.ptr & 15)) { scl_set_error("gemm: %s ptr null or not 16B aligned", name); return false; }
-    if (o.rpb < 1 || o.cin < 8) { scl_set_error("gemm: %s rpb/cin invalid", name); return false; }
-    if ((o.ld & 7) || (o.rbstride & 7) || (o.cout & 7) || (o.bs1 & 7) || (o.bs2 & 7)) {
-        scl_set_error("gemm: %s strides must be multiples of 8 elements", name); return false;
+    if (o.rpb < 1 || o.cin < vec) { scl_set_error("gemm: %s rpb/cin invalid", name); return false; }
+    if ((o.ld % vec) || (o.rbstride % vec) || (o.cout % vec) || (o.bs1 % vec) || (o.bs2 % vec) || (o.cin != 0x7fffffff && (o.cin % vec))) {
+        scl_set_error("gemm: %s strides must be multiples of %d elements", name, vec); return false;
     }
-    unsigned sh = 31, mask = 0x7fffffffu;
-    if (o.cin != 0x7fffffff) {
-        if (o.cin & (o.cin - 1)) { scl_set_error("gemm: %s cin must be a power of two (or flat)", name); return false; }
-        sh = 0; while ((1 << sh) < o.cin) ++sh;
-        mask = (unsigned)o.cin - 1;
-    }
-    // largest element offset this launch can touch must stay below 2^31 elements (32-bit byte offsets)
+    // largest element offset this launch can touch must stay below 2^32 bytes (32-bit byte offsets)
     const long long rq = (rows - 1) / o.rpb, rr = o.rpb == 0x7fffffff ? rows - 1 : (long long)o.rpb - 1;
     const long long cq = o.cin == 0x7fffffff ? 0 : (contig - 1) / o.cin;
     const long long cr = o.cin == 0x7fffffff ? contig - 1 : (long long)o.cin - 1;
-    const long long maxoff = rq * o.rbstride + (rr < rows - 1 ? rr : rows - 1) * (long long)o.ld + cq * o.cout + cr + 8;
-    if (maxoff < 0 || maxoff >= (1ll << 31) - 16 || rows >= (1ll << 31)) {
+    const long long maxoff = rq * o.rbstride + (rr < rows - 1 ? rr : rows - 1) * (long long)o.ld + cq * o.cout + cr + vec;
+    if (maxoff < 0 || maxoff * esz >= (1ll << 32) - 32 || rows >= (1ll << 31)) {
         scl_set_error("gemm: %s extent exceeds 32-bit byte offsets (%lld elements)", name, maxoff); return false;
     }
-    k->ptr = o.ptr; k->bs1 = o.bs1 * 2; k->bs2 = o.bs2 * 2;
-    k->rb_bytes = (unsigned)(o.rbstride * 2); k->ld_bytes = (unsigned)o.ld * 2u; k->cout_bytes = (unsigned)(o.cout * 2);
+    k->ptr = o.ptr; k->bs1 = o.bs1 * esz; k->bs2 = o.bs2 * esz;
+    k->rb_bytes = (unsigned)(o.rbstride * esz); k->ld_bytes = (unsigned)o.ld * (unsigned)esz; k->cout_bytes = (unsigned)(o.cout * esz);
     k->rpb = (unsigned)o.rpb; make_magic((unsigned)o.rpb, &k->rpb_magic, &k->rpb_shift);
-    k->cin_shift = sh; k->cin_mask = mask;
+    k->cin = (unsigned)o.cin; make_magic((unsigned)o.cin, &k->cin_magic, &k->cin_mshift);
+    k->esz_shift = esz == 4 ? 2u : 1u;
     return true;
 }
+}  // namespace sclg
+
+namespace {
 
 // wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the problem fills at
 // least half a round of them and the operands advance linearly along K
@@ -711,8 +714,11 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     SCL_REQUIRE(d.nb1 >= 1 && d.nb2 >= 1 && d.splitk >= 1, "gemm: nb1/nb2/splitk must be >= 1");
     const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
     GemmK k;
-    if (!fill_operand(d.A, "A", at ? d.K : d.M, at ? d.M : d.K, &k.A)) return SCL_EINVAL;
-    if (!fill_operand(d.B, "B", bt ? d.K : d.N, bt ? d.N : d.K, &k.B)) return SCL_EINVAL;
+    const bool f32ab = d.flags & SCL_GEMM_AB_F32;
+    if (!f32ab) {
+        if (!fill_operand(d.A, "A", at ? d.K : d.M, at ? d.M : d.K, &k.A, 2)) return SCL_EINVAL;
+        if (!fill_operand(d.B, "B", bt ? d.K : d.N, bt ? d.N : d.K, &k.B, 2)) return SCL_EINVAL;
+    }
     SCL_REQUIRE(d.C && d.c_rpb >= 1, "gemm: C null or c_rpb < 1");
     const int rmode = (d.flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
     SCL_REQUIRE(rmode == 0 || d.R, "gemm: RMODE set but R is null");
@@ -739,6 +745,12 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     dim3 grid(tiles, 1, (unsigned)zdim), block(256);
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
+    if (f32ab) {
+        SclProfScope prof(SCL_KID_GEMM_F32, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
+        const int rc = scl_gemm_f32_launch(d, k, s);
+        if (rc != SCL_OK) return rc;
+        return scl_check_launch("scl_gemm_bf16(f32 operands)");
+    }
     {
         SclProfScope prof(SCL_KID_GEMM, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
         // LDS-DMA staging cannot mask a partially valid 16-byte vector: use it only when none can occur

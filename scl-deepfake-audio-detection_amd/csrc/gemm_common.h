@@ -14,7 +14,7 @@ struct OpK {             // device-side operand description (bytes, 32-bit)
     long long bs1, bs2;  // batch strides in BYTES
     unsigned rb_bytes, ld_bytes, cout_bytes;
     unsigned rpb, rpb_magic, rpb_shift;
-    unsigned cin_shift, cin_mask;
+    unsigned cin, cin_magic, cin_mshift, esz_shift;   // contiguous-index block length (any value, magic division); log2(element bytes)
 };
 struct GemmK {
     OpK A, B;
@@ -34,7 +34,8 @@ __device__ __forceinline__ unsigned row_off(const OpK& o, unsigned r) {
     return q * o.rb_bytes + (r - q * o.rpb) * o.ld_bytes;
 }
 __device__ __forceinline__ unsigned col_off(const OpK& o, unsigned c) {
-    return (c >> o.cin_shift) * o.cout_bytes + ((c & o.cin_mask) << 1);
+    const unsigned q = udiv_magic(c, o.cin_magic, o.cin_mshift);
+    return q * o.cout_bytes + ((c - q * o.cin) << o.esz_shift);
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -216,6 +217,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& d, f32x4 (&acc)[4][4]
 
 
 
+
+// gemm.hip (host side)
+void make_magic(unsigned dv, unsigned* magic, unsigned* shift);
+bool fill_operand(const SclOperand& o, const char* name, long long rows, long long contig, OpK* k, int esz);
+int scl_gemm_f32_launch(const SclGemmDesc& d, GemmK& k, hipStream_t s);   // gemm_f32.hip
 
 // gemm_w8.hip (host side)
 struct W8Plan { int variant, tiles_m, tile_m; long long tiles, cost; };

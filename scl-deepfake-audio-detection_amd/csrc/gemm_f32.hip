@@ -1,0 +1,240 @@
+// gemm_f32.hip — the fp32 member of the GEMM family: C = epilogue(alpha * A * B^T) with f32 operands on the f32-input matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 products and fp32 accumulation — a k-ordered fmaf chain, no reduced-precision pass).
+//
+// Two users, both of which need fp32 end to end where the bf16 kernels cannot give it:
+//   * the scoring path (main.py --eval / --predict / --emb; reference main.py:161-214 runs fp32, north_star asks for scores within
+//     1e-3 of it): every encoder / head contraction with f32 activations and the f32 master weights;
+//   * the AASIST / ResNet back-ends (model/wav2vec2_aasist.py:377-604, model/resnet.py:47-191): their 2-D convolutions as implicit
+//     GEMMs over channels-last maps (rows = output positions with overlapping windows, K = (kh; kw*C + c) through the operand's
+//     2-level contiguous index, one batch entry per utterance) and their small linears, forward / dgrad / wgrad.
+// Same descriptor, operand addressing (rpb / rbstride / ld / cin / cout / batch strides), split-K and fused epilogue as scl_gemm_bf16.
+//
+// Design: 128x128 (or 64x64 for small problems) tile per 256-thread block, 4 waves as 2x2, BK = 32, LDS double buffer, register-staged
+// 16-byte global loads.  The K order inside a 32-deep step is permuted so that a lane's 8 operands of one row are contiguous in LDS
+// (lane group q = lane>>4 owns k = 8q .. 8q+7; MFMA j of the step multiplies k = {j, 8+j, 16+j, 24+j}): two ds_read_b128 per
+// fragment instead of eight ds_read_b32.  Transposed operands are staged as they lie in memory ([k][128 contiguous]) and read
+// element-wise.  MFMA operands are swapped (D = B-frag x A-frag) so the epilogue of gemm_common.h applies unchanged.
+#include "gemm_common.h"
+
+using namespace sclg;
+
+namespace {
+
+constexpr int FBK = 32;
+constexpr int LDK = 36;      // words per row of a K-contiguous image ([rows][32 k] + 4 pad: 16-byte aligned rows, spread banks)
+constexpr int LDT = 132;     // words per k-row of a transposed image ([32 k][128 contiguous] + 4 pad), 68 for the 64-wide tile
+
+template <int TM> struct F32Geom {
+    static constexpr int ROWS = TM;                       // tile rows (= columns)
+    static constexpr int WT = TM / 2;                     // per-wave rows
+    static constexpr int NB = WT / 16;                    // 16-row blocks per wave (4 or 2)
+    static constexpr int LDT_ = TM + 4;
+    static constexpr int IMG = (TM * LDK > FBK * (TM + 4) ? TM * LDK : FBK * (TM + 4));   // words per operand image
+};
+
+// ---- staging: global -> registers -> LDS -----------------------------------------------------------------------------------------
+template <int TM, bool T> struct F32Stage;
+
+template <int TM> struct F32Stage<TM, false> {      // K-contiguous: TM rows x 32 k; thread loads NV float4 (row = t/8 + 32 i, k chunk t%8)
+    static constexpr int NV = TM / 32;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned rowoff[NV];
+    int kcur, kend;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int row0, int rowlimit, int kbegin, int kend_, int tid) {
+        rsrc = make_rsrc(base);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            rowoff[i] = r < rowlimit ? row_off(o, (unsigned)r) : OOB;
+        }
+        kcur = kbegin + 4 * (tid & 7); kend = kend_;
+    }
+    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[NV]) const {
+        const unsigned koff = col_off(o, (unsigned)kcur);
+        const int nvalid = kend - kcur;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned off = (nvalid > 0 && rowoff[i] != OOB) ? rowoff[i] + koff : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            if (nvalid < 4) {     // partial vector at the K tail (K % 4 != 0 is legal for f32 operands whose ld keeps rows 16-byte aligned)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e >= nvalid) r[i][e] = 0u;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* img, const u32x4 (&r)[NV], int tid) const {
+        const int c = tid & 7;                       // logical k chunk (4 k); lane group q = c>>1 owns k 8q..8q+7
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4*>(img + ((tid >> 3) + 32 * i) * LDK + 4 * c) = r[i];
+    }
+    __device__ __forceinline__ void advance() { kcur += FBK; }
+};
+
+template <int TM> struct F32Stage<TM, true> {       // transposed: 32 k rows x TM contiguous; thread loads NV float4 (k = t/(TM/4) + step i)
+    static constexpr int CPR = TM / 4;               // float4 chunks per k row
+    static constexpr int KSTEP = 256 / CPR;          // k rows covered per pass (8 for TM = 128, 16 for 64)
+    static constexpr int NV = FBK / KSTEP;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned coloff;
+    int kcur, kend, ncolvalid;
+    __device__ __forceinline__ void init(const OpK& o, const char* base, int col0, int collimit, int kbegin, int kend_, int tid) {
+        rsrc = make_rsrc(base);
+        const int col = col0 + 4 * (tid % CPR);
+        int nv = collimit - col; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+        ncolvalid = nv;
+        coloff = nv > 0 ? col_off(o, (unsigned)col) : OOB;
+        kcur = kbegin + tid / CPR; kend = kend_;
+    }
+    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int rr = kcur + KSTEP * i;
+            const unsigned off = (rr < kend && coloff != OOB) ? row_off(o, (unsigned)rr) + coloff : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            if (ncolvalid < 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e >= ncolvalid) r[i][e] = 0u;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* img, const u32x4 (&r)[NV], int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4*>(img + (tid / CPR + KSTEP * i) * (TM + 4) + 4 * (tid % CPR)) = r[i];
+    }
+    __device__ __forceinline__ void advance() { kcur += FBK; }
+};
+
+// fragment of one 16-row block for the whole 32-deep step: v[j] = operand[row = blk*16 + (lane&15)][k = 8*(lane>>4) + j]
+template <int TM, bool T>
+__device__ __forceinline__ void f32_frag(const float* img, int blk, int lane, float (&v)[8]) {
+    const int row = blk * 16 + (lane & 15), q = lane >> 4;
+    if (!T) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(img + row * LDK + 8 * q);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(img + row * LDK + 8 * q + 4);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = img[(8 * q + j) * (TM + 4) + row];
+    }
+}
+
+template <int TM, bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void scl_gemm_f32_kernel(const GemmK d) {
+    typedef F32Geom<TM> G;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + TM - 1) / TM;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + TM - 1) / TM, tiles_n, tm, tn, d.group_m);
+    const int m0 = tm * TM, n0 = tn * TM;
+    int z = blockIdx.z;
+    const int ksplit = z % d.splitk; z /= d.splitk;
+    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + FBK - 1) / FBK;
+    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int kbegin = ksplit * nk_per * FBK;
+    int kend = kbegin + nk_per * FBK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + FBK - 1) / FBK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    F32Stage<TM, AT> sa;
+    F32Stage<TM, BT> sb;
+    sa.init(d.A, Ab, m0, d.M, kbegin, kend, tid);
+    sb.init(d.B, Bb, n0, d.N, kbegin, kend, tid);
+
+    f32x4 acc[G::NB][G::NB];
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[F32Stage<TM, AT>::NV], rb[F32Stage<TM, BT>::NV];
+    if (nk > 0) {
+        sa.load(d.A, ra); sb.load(d.B, rb);
+        sa.store(smem, ra, tid); sb.store(smem + G::IMG, rb, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) { sa.advance(); sb.advance(); sa.load(d.A, ra); sb.load(d.B, rb); }
+        const float* tA = smem + cur * 2 * G::IMG;
+        const float* tB = tA + G::IMG;
+        float fa[G::NB][8], fb[G::NB][8];
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i) {
+            f32_frag<TM, AT>(tA, wr * G::NB + i, lane, fa[i]);
+            f32_frag<TM, BT>(tB, wc * G::NB + i, lane, fb[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                for (int n = 0; n < G::NB; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0);
+        if (more) {
+            float* nA = smem + (cur ^ 1) * 2 * G::IMG;
+            sa.store(nA, ra, tid); sb.store(nA + G::IMG, rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if constexpr (G::NB == 4) {
+        f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0][0]);
+        gemm_epilogue_blk<4>(d, a4, m0 + wr * 64, n0 + wc * 64, d.M, 4, z1, z2, ksplit, lane);
+    } else {
+        // 32 x 32 per wave: the shared epilogue walks 4 column blocks per row block — hand it 2 x 2 padded to [2][4] with the unused
+        // columns masked by an N limit (nt >= 2 columns fall outside [nbase, nbase + 32))
+        f32x4 a24[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a24[i][0] = acc[i][0]; a24[i][1] = acc[i][1]; a24[i][2] = f32x4{0.f, 0.f, 0.f, 0.f}; a24[i][3] = a24[i][2]; }
+        GemmK dd = d;
+        const int nlim = n0 + wc * 32 + 32;
+        dd.N = nlim < d.N ? nlim : d.N;
+        gemm_epilogue_blk<2>(dd, a24, m0 + wr * 32, n0 + wc * 32, d.M, 2, z1, z2, ksplit, lane);
+    }
+}
+
+template <int TM>
+void f32_launch(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s) {
+    const size_t lds = 4 * (size_t)F32Geom<TM>::IMG * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const dim3 block(256);
+    if (!at && !bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, false, false>), grid, block, lds, s, k);
+    else if (!at && bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, false, true>), grid, block, lds, s, k);
+    else if (at && !bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, true, false>), grid, block, lds, s, k);
+    else hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, true, true>), grid, block, lds, s, k);
+}
+
+}  // namespace
+
+namespace sclg {
+
+int scl_gemm_f32_launch(const SclGemmDesc& d, GemmK& k, hipStream_t s) {
+    const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
+    if (!fill_operand(d.A, "A", at ? d.K : d.M, at ? d.M : d.K, &k.A, 4)) return SCL_EINVAL;
+    if (!fill_operand(d.B, "B", bt ? d.K : d.N, bt ? d.N : d.K, &k.B, 4)) return SCL_EINVAL;
+    const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
+    // 128x128 tiles once they fill the chip twice over; otherwise 64x64 (4x the blocks: the back-ends' maps are small)
+    const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
+    if (t128 >= 512 && d.M >= 128 && d.N >= 128) {
+        f32_launch<128>(k, at, bt, dim3((unsigned)(t128 / zdim), 1, (unsigned)zdim), s);
+    } else {
+        const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+        f32_launch<64>(k, at, bt, dim3((unsigned)t64, 1, (unsigned)zdim), s);
+    }
+    return SCL_OK;
+}
+
+}  // namespace sclg

@@ -71,7 +71,7 @@ struct W8K {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
         }
     }
-    __device__ __forceinline__ static unsigned kstep(const OpK& o) { return o.cin_shift == 6 ? o.cout_bytes : 128u; }
+    __device__ __forceinline__ static unsigned kstep(const OpK& o) { return o.cin == 64 ? o.cout_bytes : 128u; }
 };
 // transposed operand, 2 sub-tiles of [64 k rows][128 contiguous]: piece p -> sub-tile p >> 4, k rows 4*(p & 15) .. +3
 struct W8T {

@@ -48,10 +48,12 @@ GEMM_NO_P8 = 0x00400000
 GEMM_FORCE_P8 = 0x00800000
 GEMM_NO_W8 = 0x01000000
 GEMM_FORCE_W8 = 0x02000000
+GEMM_AB_F32 = 0x40000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 KID_GEMM = 0
 KID_AUG = 1
+KID_GEMM_F32 = 2
 
 _vp, _i32, _i64, _f32, _f64, _u32 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
                                      ctypes.c_double, ctypes.c_uint32)

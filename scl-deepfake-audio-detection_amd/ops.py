@@ -76,7 +76,7 @@ class Op:
     __slots__ = ("t", "ld", "rpb", "rbstride", "cin", "cout", "bs1", "bs2", "offset")
 
     def __init__(self, t, ld, rpb=FLAT, rbstride=0, cin=FLAT, cout=0, bs1=0, bs2=0, offset=0):
-        assert t.dtype == torch.bfloat16, "GEMM operands are bf16"
+        assert t.dtype in (torch.bfloat16, torch.float32), "GEMM operands are bf16, or f32 for the exact-fp32 kernel"
         self.t, self.ld, self.rpb, self.rbstride = t, ld, rpb, rbstride
         self.cin, self.cout, self.bs1, self.bs2, self.offset = cin, cout, bs1, bs2, offset
 
@@ -110,6 +110,9 @@ def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=N
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
     flags = 0
+    assert A.t.dtype == B.t.dtype, "A and B must have the same element type"
+    if A.t.dtype == torch.float32:
+        flags |= L.GEMM_AB_F32
     if a_t:
         flags |= L.GEMM_A_T
     if b_t:

@@ -334,3 +334,56 @@ def test_wide_tile_kernel_conv_and_grouped_addressing(dev):
                  K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=pbias, bias_bs2=Cg, act=1, c2=pre, R=x0, rmode=1, **kw)
         outs.append((xo, pre))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(300, 200, 136, 1), (128, 128, 64, 1), (2112, 64, 64, 1), (1000, 520, 260, 1), (64, 72, 1000, 3), (6432, 1024, 512, 1)])
+def test_f32_operand_kernel_matches_fp64(dev, a_t, b_t, M, N, K, splitk):
+    """scl_gemm_bf16 with f32 operands (gemm_f32.hip: v_mfma_f32_16x16x4_f32, exact fp32 products, fp32 accumulation) against an fp64
+    reference: 2e-6 of the row scale — the fp32 bar of north_star (1e-3) with three orders of margin; ragged M / N / K (K % 4 != 0
+    rows are zero-padded to the 16-byte vector), split-K slabs, bias + GELU epilogue."""
+    pad4 = lambda v: (v + 3) // 4 * 4
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g); B = torch.randn(N, K, generator=g)
+    ref = (A.double() @ B.double().t())
+    def operand(mat, t):
+        m = mat.t().contiguous() if t else mat
+        buf = torch.full((m.shape[0] + 2, pad4(m.shape[1]) + 4), float("nan"))
+        buf[: m.shape[0], : m.shape[1]] = m
+        if not t:
+            buf[: m.shape[0], m.shape[1]: pad4(m.shape[1])] = 0.0   # K tail inside the last 16-byte vector must be finite zeros
+        return buf.to(dev), buf.shape[1]
+    bufA, ldA = operand(A, a_t); bufB, ldB = operand(B, b_t)
+    if splitk > 1:
+        C = torch.full((splitk, M, N), float("nan"), device=dev)
+        ops.gemm(ops.Op(bufA, ldA), ops.Op(bufB, ldB), C, M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N)
+        got = C.sum(0)
+    else:
+        bias = torch.randn(N, generator=g)
+        got = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(ops.Op(bufA, ldA), ops.Op(bufB, ldB), got, M, N, K, a_t=a_t, b_t=b_t, bias=bias.to(dev), act=1)
+        ref = torch.nn.functional.gelu(ref + bias.double())
+    torch.cuda.synchronize()
+    err = ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-6, err
+
+
+def test_f32_kernel_addresses_a_2d_convolution_in_place(dev):
+    """A 3x3, stride-(2,1) convolution over a channels-last, zero-padded map as ONE batched GEMM without an im2col buffer: rows =
+    output positions (rpb = OW, rbstride = sh * Wp * C, ld = sw * C, one batch entry per utterance), K = (kh; kw*C + c) through the
+    2-level contiguous index with cin = 3*C = 48 — not a power of two (magic division in col_off)."""
+    Bz, H, W, C, Co, kh, kw, sh, sw = 3, 21, 18, 16, 24, 3, 3, 2, 1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Bz, C, H, W, generator=g); w = torch.randn(Co, C, kh, kw, generator=g); b = torch.randn(Co, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=(sh, sw), padding=1)          # [B, Co, OH, OW]
+    OH, OW = ref.shape[2], ref.shape[3]
+    Hp, Wp = H + 2, W + 2
+    xp = torch.zeros(Bz, Hp, Wp, C); xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    wk = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * C).contiguous()                                       # [Co][kh][kw][C]
+    xp_d = torch.cat([xp.reshape(-1), torch.zeros(4096)]).to(dev)
+    y = torch.full((Bz, OH * OW, Co), float("nan"), device=dev)
+    ops.gemm(ops.Op(xp_d, sw * C, rpb=OW, rbstride=sh * Wp * C, cin=kw * C, cout=Wp * C, bs1=Hp * Wp * C), ops.Op(wk.to(dev), kh * kw * C), y,
+             OH * OW, Co, kh * kw * C, nb1=Bz, c_bs1=OH * OW * Co, bias=b.to(dev))
+    torch.cuda.synchronize()
+    got = y.view(Bz, OH, OW, Co).permute(0, 3, 1, 2).double().cpu()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
