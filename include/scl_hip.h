@@ -126,6 +126,35 @@ int scl_debug_gemm_stamps(unsigned long long* out, int nblocks);
 int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* AASIST / ResNet back-end pieces over channels-last fp32 maps (csrc/nn.hip)                  */
+/* ------------------------------------------------------------------------------------------ */
+/* BatchNorm over the rows of x [N, C] (C a power of two <= 512) fused with an activation (act: 0 none, 1 ReLU, 2 SELU).
+ * training != 0: batch statistics (part: f32 [scl_bn_nslabs(N)][2][C] scratch), running_mean / running_var / num_batches_tracked
+ * updated like torch (momentum, unbiased variance); else the running statistics are used.  Saves mean / rstd [C].  Writes
+ * y [N, C] f32 (may be NULL) and / or y2: element (row r = (b,i,j), c) at y2[m_base + b*m_bs + i*m_rs + j*m_cs + c] with
+ * i = (r % m_HW) / m_W, j = r % m_W — the interior of the zero-padded map the next convolution reads (f32, or bf16 when y2_bf16).
+ * Replaces nn.BatchNorm2d / nn.BatchNorm1d (+ F.relu / nn.SELU) of model/resnet.py:47-191, model/wav2vec2_aasist.py:62-155,377-604. */
+int scl_bn_nslabs(int N);
+int scl_bn_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               long long* num_batches_tracked, int training, float momentum, float eps, int act, float* part, float* mean,
+               float* rstd, float* y, void* y2, int y2_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs, int64_t m_cs,
+               int64_t m_base, void* stream);
+/* backward of the above: dz = dy * act'(y); dgamma = sum dz * xhat, dbeta = sum dz (either may be NULL); dx = gamma * rstd *
+ * (dz - [training] (sum dz + xhat * sum dz*xhat) / N).  part: as above; sums: f32 [2*C] scratch. */
+int scl_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int N, int C,
+               int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, void* stream);
+/* src [rows, C] contiguous f32 -> mapped (padded / dilated) destination, f32 or bf16 (row mapping as scl_bn_fwd's y2) */
+int scl_pad_nhwc_f32(const float* src, int64_t rows, int C, void* dst, int dst_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs,
+                     int64_t m_cs, int64_t m_base, void* stream);
+/* F.max_pool2d(x, (3, 3)) of a single-channel map given by strides (elements): y [B, H/3, W/3], idx = flat argmax inside x[b]
+ * (model/wav2vec2_aasist.py:517); the backward scatters dy into a zeroed dx. */
+int scl_maxpool3_fwd(const float* x, int64_t xs_h, int64_t xs_w, int64_t xs_b, int H, int W, int B, float* y, int* idx, void* stream);
+int scl_maxpool3_bwd(const float* dy, const int* idx, int H, int W, int B, float* dx, int64_t xs_h, int64_t xs_w, int64_t xs_b, void* stream);
+/* y[b][c] = mean_r x[b][r][c] (F.adaptive_avg_pool2d(x, 1) on a channels-last map, model/resnet.py:186) and its backward */
+int scl_avgpool_fwd(const float* x, int B, int R, int C, float* y, void* stream);
+int scl_avgpool_bwd(const float* dy, int B, int R, int C, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* LayerNorm (+GELU), column reductions                                                        */
 /* ------------------------------------------------------------------------------------------ */
 /* y = act(LN(x) * gamma + beta) per row of [M, C]; x f32 or bf16; y to bf16 and/or f32; saves mean / rstd.

@@ -1,24 +1,13 @@
-"""AASIST graph-attention back-end on HIP kernels, channels-last.
-
-The arithmetic is the reference's — model/wav2vec2_aasist.py:62-155 (GraphAttentionLayer), :158-332 (HtrgGraphAttentionLayer), :336-374
-(GraphPool), :377-433 (Residual_block), :436-604 (Model) — and so are the parameter names, so its checkpoints load.  The execution
-is not torch's: the spectro-temporal map lives as [B, 42, T/3, C] (channels last); the 2-D convolutions are implicit GEMMs on the
-exact-fp32 matrix-core kernel (hipnn.conv2d), every BatchNorm(+SELU) is a fused HIP kernel pair (hipnn.batch_norm), the pairwise
-attention scores are the fused kernels of csrc/gat.hip, projections / att @ x / the 1x1 attention convolutions are the fp32 GEMM
-(hipnn.linear / hipnn.bmm), the 3x3 max pool is csrc/nn.hip.  torch carries tensors, the autograd tape and the remaining
-element-wise glue (soft-max over <= 66 nodes, top-k, gathers).  nn.Linear / nn.BatchNorm* objects below are parameter and buffer
-containers under the reference's state-dict names; their torch forwards are never called.
-
-Reference quirks kept on purpose: Residual_block applies conv1 to its INPUT (the bn1+SELU result is discarded, :414-420; in training
-that BatchNorm still updates its running statistics); the temporal / spectral attention pools share one 1x1-conv score map.
+"""ORACLE (test infrastructure; never imported by the product path).  CPU restatement in plain torch of the AASIST back-end —
+model/wav2vec2_aasist.py:62-155 (GraphAttentionLayer), :158-332 (HtrgGraphAttentionLayer), :336-374 (GraphPool), :377-433
+(Residual_block), :436-604 (Model) — with the reference's parameter names.  Pinned to the reference's own classes by
+tests/test_aasist_cpu.py through tests/golden/aasist.npz (oracle/gen_golden.py::gen_aasist imports the reference).  Reference quirks
+kept: Residual_block applies conv1 to its INPUT (the bn1 + SELU result is discarded, :414-420); the temporal / spectral attention
+pools share one 1x1-conv score map.  The GPU tests use it as the fp32 reference of scl_amd/aasist_head.py (HIP kernels).
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
-
-from . import hipnn
-from .gat import gat_score
-from .resnet_head import ConvWeight
 
 UPSTREAM_AASIST = {"filts": [128, [1, 32], [32, 32], [32, 64], [64, 64]], "gat_dims": [64, 32],
                    "pool_ratios": [0.5, 0.5, 0.5, 0.5], "temperatures": [2.0, 2.0, 100.0, 100.0], "nclasses": 2}
@@ -30,8 +19,9 @@ def _xavier(*size):
     return p
 
 
-def _lin(layer, x):
-    return hipnn.linear(x, layer.weight, layer.bias)
+def _pairwise(x):
+    """[B, N, D] -> [B, N, N, D] element-wise products of every node pair."""
+    return x.unsqueeze(2) * x.unsqueeze(1)
 
 
 class GraphAttentionLayer(nn.Module):
@@ -47,10 +37,11 @@ class GraphAttentionLayer(nn.Module):
 
     def forward(self, x):
         x = self.input_drop(x)
-        # s[i][j] = tanh(att_proj(x_i * x_j)) . att_weight, soft-max over j (fused: nothing of size N*N*D reaches HBM)
-        att = F.softmax(gat_score(x, self.att_proj.weight, self.att_proj.bias, self.att_weight.t()) / self.temp, dim=-1)
-        y = _lin(self.proj_with_att, hipnn.bmm(att, x)) + _lin(self.proj_without_att, x)
-        return hipnn.batch_norm(y, self.bn, hipnn.ACT_SELU)
+        att = torch.tanh(self.att_proj(_pairwise(x))) @ self.att_weight          # [B, N, N, 1]
+        att = F.softmax(att / self.temp, dim=-2).squeeze(-1)
+        y = self.proj_with_att(att @ x) + self.proj_without_att(x)
+        y = self.bn(y.reshape(-1, y.shape[-1])).view_as(y)
+        return F.selu(y)
 
 
 class HtrgGraphAttentionLayer(nn.Module):
@@ -74,19 +65,24 @@ class HtrgGraphAttentionLayer(nn.Module):
 
     def forward(self, x1, x2, master=None):
         n1, n2 = x1.size(1), x2.size(1)
-        x = torch.cat([_lin(self.proj_type1, x1), _lin(self.proj_type2, x2)], dim=1)
+        x = torch.cat([self.proj_type1(x1), self.proj_type2(x2)], dim=1)
         if master is None:
             master = x.mean(dim=1, keepdim=True)
         x = self.input_drop(x)
-        # heterogeneous attention map: one weight vector per (type, type) block of the pair matrix
-        a = torch.cat([self.att_weight11, self.att_weight22, self.att_weight12], dim=1).t()          # [3, D']
-        att = F.softmax(gat_score(x, self.att_proj.weight, self.att_proj.bias, a, n1) / self.temp, dim=-1)
+        # heterogeneous attention map: one weight vector per (type, type) block
+        h = torch.tanh(self.att_proj(_pairwise(x)))                                # [B, N, N, D']
+        board = torch.zeros_like(h[..., :1])
+        board[:, :n1, :n1] = h[:, :n1, :n1] @ self.att_weight11
+        board[:, n1:, n1:] = h[:, n1:, n1:] @ self.att_weight22
+        board[:, :n1, n1:] = h[:, :n1, n1:] @ self.att_weight12
+        board[:, n1:, :n1] = h[:, n1:, :n1] @ self.att_weight12
+        att = F.softmax(board / self.temp, dim=-2).squeeze(-1)
         # master node: attention of every node towards the master
-        am = (torch.tanh(_lin(self.att_projM, x * master)) * self.att_weightM.t()).sum(-1, keepdim=True)     # [B, N, 1]
+        am = torch.tanh(self.att_projM(x * master)) @ self.att_weightM             # [B, N, 1]
         am = F.softmax(am / self.temp, dim=-2)
-        master = _lin(self.proj_with_attM, hipnn.bmm(am.transpose(1, 2), x)) + _lin(self.proj_without_attM, master)
-        y = _lin(self.proj_with_att, hipnn.bmm(att, x)) + _lin(self.proj_without_att, x)
-        y = hipnn.batch_norm(y, self.bn, hipnn.ACT_SELU)
+        master = self.proj_with_attM(am.squeeze(-1).unsqueeze(1) @ x) + self.proj_without_attM(master)
+        y = self.proj_with_att(att @ x) + self.proj_without_att(x)
+        y = F.selu(self.bn(y.reshape(-1, y.shape[-1])).view_as(y))
         return y[:, :n1], y[:, n1:n1 + n2], master
 
 
@@ -98,7 +94,7 @@ class GraphPool(nn.Module):
         self.drop = nn.Dropout(p=p) if p > 0 else nn.Identity()
 
     def forward(self, h):
-        scores = torch.sigmoid(_lin(self.proj, self.drop(h)))                       # [B, N, 1]
+        scores = torch.sigmoid(self.proj(self.drop(h)))                             # [B, N, 1]
         keep = max(int(h.size(1) * self.k), 1)
         idx = torch.topk(scores, keep, dim=1)[1].expand(-1, -1, h.size(2))
         return torch.gather(h * scores, 1, idx)
@@ -110,20 +106,18 @@ class Residual_block(nn.Module):
         self.first = first
         if not first:
             self.bn1 = nn.BatchNorm2d(nb_filts[0])
-        self.conv1 = ConvWeight(nb_filts[0], nb_filts[1], (2, 3), 1, (1, 1), bias=True)
+        self.conv1 = nn.Conv2d(nb_filts[0], nb_filts[1], kernel_size=(2, 3), padding=(1, 1), stride=1)
         self.bn2 = nn.BatchNorm2d(nb_filts[1])
-        self.conv2 = ConvWeight(nb_filts[1], nb_filts[1], (2, 3), 1, (0, 1), bias=True)
+        self.conv2 = nn.Conv2d(nb_filts[1], nb_filts[1], kernel_size=(2, 3), padding=(0, 1), stride=1)
         self.downsample = nb_filts[0] != nb_filts[1]
         if self.downsample:
-            self.conv_downsample = ConvWeight(nb_filts[0], nb_filts[1], (1, 3), 1, (0, 1), bias=True)
+            self.conv_downsample = nn.Conv2d(nb_filts[0], nb_filts[1], padding=(0, 1), kernel_size=(1, 3), stride=1)
 
-    def run(self, x):
-        """x [B, H, W, C] channels-last."""
-        if not self.first and self.training:
-            hipnn.batch_norm(x.detach(), self.bn1, hipnn.ACT_SELU)       # result discarded by the reference (:414-420): running stats only
-        dt = torch.float32
-        out = self.conv2.conv(hipnn.batch_norm(self.conv1.conv(x, dt), self.bn2, hipnn.ACT_SELU), dt)
-        return out + (self.conv_downsample.conv(x, dt) if self.downsample else x)
+    def forward(self, x):
+        if not self.first:
+            F.selu(self.bn1(x))            # computed and discarded by the reference (:414-420); kept for the BN running stats
+        out = self.conv2(F.selu(self.bn2(self.conv1(x))))
+        return out + (self.conv_downsample(x) if self.downsample else x)
 
 
 class AasistHead(nn.Module):
@@ -140,8 +134,8 @@ class AasistHead(nn.Module):
         self.encoder = nn.Sequential(nn.Sequential(Residual_block(filts[1], first=True)), nn.Sequential(Residual_block(filts[2])),
                                      nn.Sequential(Residual_block(filts[3])), nn.Sequential(Residual_block(filts[4])),
                                      nn.Sequential(Residual_block(filts[4])), nn.Sequential(Residual_block(filts[4])))
-        # containers for attention.{0,2,3}: 1x1 conv (64 -> 128, bias), SELU, BatchNorm2d(128), 1x1 conv (128 -> 64, bias)
-        self.attention = nn.Sequential(ConvWeight(64, 128, 1, bias=True), nn.SELU(), nn.BatchNorm2d(128), ConvWeight(128, 64, 1, bias=True))
+        self.attention = nn.Sequential(nn.Conv2d(64, 128, kernel_size=(1, 1)), nn.SELU(), nn.BatchNorm2d(128),
+                                       nn.Conv2d(128, 64, kernel_size=(1, 1)))
         self.pos_S = nn.Parameter(torch.randn(1, 42, filts[-1][-1]))
         self.master1 = nn.Parameter(torch.randn(1, 1, gat[0]))
         self.master2 = nn.Parameter(torch.randn(1, 1, gat[0]))
@@ -160,18 +154,12 @@ class AasistHead(nn.Module):
         self.out_layer = nn.Linear(5 * gat[1], cfg["nclasses"])
 
     def forward(self, feats):
-        # [B, T, 128] -> the single-channel map [B, 128 (frequency bins), T] -> 3x3 max pool -> [B, 42, T/3, 1] channels last
-        x = hipnn.max_pool3(feats.transpose(1, 2)).unsqueeze(-1)
-        x = hipnn.batch_norm(x, self.first_bn, hipnn.ACT_SELU)
-        for blk in self.encoder:
-            x = blk[0].run(x)
-        x = hipnn.batch_norm(x, self.first_bn1, hipnn.ACT_SELU)                    # [B, 42, T/3, 64]
-        a0, a2, a3 = self.attention[0], self.attention[2], self.attention[3]
-        w = hipnn.linear(x, a0.weight.view(a0.weight.shape[0], -1), a0.bias)
-        w = hipnn.batch_norm(F.selu(w), a2, hipnn.ACT_NONE)
-        w = hipnn.linear(w, a3.weight.view(a3.weight.shape[0], -1), a3.bias)      # one score map for both poolings
-        e_S = (x * F.softmax(w, dim=2)).sum(2) + self.pos_S                        # spectral nodes  [B, 42, 64]
-        e_T = (x * F.softmax(w, dim=1)).sum(1)                                     # temporal nodes  [B, T/3, 64]
+        x = feats.transpose(1, 2).unsqueeze(1)                                     # [B, 1, 128, T]
+        x = F.selu(self.first_bn(F.max_pool2d(x, (3, 3))))
+        x = F.selu(self.first_bn1(self.encoder(x)))                                # [B, 64, 42, T/3]
+        w = self.attention(x)
+        e_S = (x * F.softmax(w, dim=-1)).sum(-1).transpose(1, 2) + self.pos_S      # spectral nodes  [B, 42, 64]
+        e_T = (x * F.softmax(w, dim=-2)).sum(-2).transpose(1, 2)                   # temporal nodes  [B, T/3, 64]
         out_S = self.pool_S(self.GAT_layer_S(e_S))
         out_T = self.pool_T(self.GAT_layer_T(e_T))
         # two heterogeneous branches
@@ -188,4 +176,4 @@ class AasistHead(nn.Module):
         last_hidden = torch.cat([out_T.abs().max(dim=1)[0], out_T.mean(dim=1), out_S.abs().max(dim=1)[0], out_S.mean(dim=1),
                                  master.squeeze(1)], dim=1)
         last_hidden = self.drop(last_hidden)
-        return _lin(self.out_layer, last_hidden), last_hidden
+        return self.out_layer(last_hidden), last_hidden

@@ -118,8 +118,10 @@ __device__ __forceinline__ void f32_frag(const float* img, int blk, int lane, fl
     }
 }
 
+// the 64x64 tile needs 60-90 VGPRs and 36 KiB of LDS: four blocks per CU hide its single-stage global prefetch (measured on the AASIST
+// convolution wgrads: 192 blocks at one per CU ran at the HBM latency, 1.6 us per 32-deep step)
 template <int TM, bool AT, bool BT>
-__global__ __launch_bounds__(256, 2) void scl_gemm_f32_kernel(const GemmK d) {
+__global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(const GemmK d) {
     typedef F32Geom<TM> G;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);

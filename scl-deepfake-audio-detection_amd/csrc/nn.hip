@@ -1,0 +1,285 @@
+// nn.hip — the non-GEMM pieces of the AASIST / ResNet back-ends over channels-last fp32 maps [rows = (b, h, w)][C]:
+// BatchNorm (batch or running statistics) fused with its activation (ReLU / SELU), forward and backward; copies into the zero-padded
+// (and, for strided transposed convolutions, zero-dilated) maps the implicit-GEMM convolutions read; the 3x3 max pool in front of the
+// AASIST encoder; global average pooling.  Replaces nn.BatchNorm2d / nn.BatchNorm1d / F.relu / nn.SELU / F.max_pool2d /
+// F.adaptive_avg_pool2d of model/wav2vec2_aasist.py:377-433, 436-604, model/resnet.py:47-191, model/wav2vec2_resnet_nll.py:51-74 and
+// their autograd backward (main.py:79).  HBM-bound streaming kernels: 16-byte accesses when C % 4 == 0, fp32 throughout; statistics
+// are accumulated per 512-row slab in fp32 and combined over slabs in fp64 (the reference's CPU path accumulates in double).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_SLAB = 128;          // rows per statistics slab (a multiple of 256 / C for every legal C keeps a thread on one channel)
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+
+__device__ __forceinline__ float nn_act(int act, float v) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? SELU_SCALE * v : SELU_SCALE * SELU_ALPHA * (__expf(v) - 1.0f);
+    return v;
+}
+// derivative of the activation expressed through its OUTPUT y (ReLU: y > 0; SELU: y > 0 ? scale : y + scale*alpha)
+__device__ __forceinline__ float nn_act_grad_from_y(int act, float y) {
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? SELU_SCALE : y + SELU_SCALE * SELU_ALPHA;
+    return 1.f;
+}
+
+// partial (sum a, sum a*b) per slab and channel; a = f(row, c), b = g(row, c).  Thread t owns channel (t % C) when C <= 256 (C divides
+// 256), channels t and t + 256 when C == 512: consecutive threads read consecutive addresses.
+template <class F>
+__device__ __forceinline__ void slab_reduce(int N, int C, float* part, F f) {
+    __shared__ float red[2][256];
+    const int slab = blockIdx.x, t = threadIdx.x;
+    const long long e0 = (long long)slab * BN_SLAB * C, e1 = min((long long)(slab + 1) * BN_SLAB, (long long)N) * C;
+    const int nacc = C > 256 ? C / 256 : 1;
+    for (int a = 0; a < nacc; ++a) {
+        float s0 = 0.f, s1 = 0.f;
+        const int ch = (t + 256 * a) & (C - 1);       // C is a power of two and divides the slab start
+        for (long long e = e0 + t + 256 * a; e < e1; e += 256 * nacc) {
+            float u, v;
+            f(e, ch, u, v);
+            s0 += u; s1 += v;
+        }
+        red[0][t] = s0; red[1][t] = s1;
+        __syncthreads();
+        const int cc = C > 256 ? 256 : C;          // threads t, t + cc, t + 2cc ... share a channel
+        if (t < cc) {
+            float r0 = 0.f, r1 = 0.f;
+            for (int k = t; k < 256; k += cc) { r0 += red[0][k]; r1 += red[1][k]; }
+            part[((long long)slab * 2 + 0) * C + t + 256 * a] = r0;
+            part[((long long)slab * 2 + 1) * C + t + 256 * a] = r1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ part) {
+    slab_reduce(N, C, part, [&](long long e, int, float& u, float& v) { const float a = x[e]; u = a; v = a * a; });
+}
+
+// mean / rstd from the slab partials (training) or from the running statistics (eval); training also updates the running
+// statistics with momentum (unbiased variance, as torch) and num_batches_tracked
+// 64 channels per block x 16 slab lanes: the slab loop is split sixteen ways and combined through LDS (fp64)
+__global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict__ part, int nslab, int N, int C, float eps, float momentum, int training,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                 float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (training && c < C)
+        for (int k = lane4; k < nslab; k += 16) { s += (double)part[((long long)k * 2) * C + c]; q += (double)part[((long long)k * 2 + 1) * C + c]; }
+    red[0][lane4][cl] = s; red[1][lane4][cl] = q;
+    __syncthreads();
+    if (lane4 != 0 || c >= C) return;
+    if (!training) {
+        mean[c] = running_mean[c];
+        rstd[c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+        return;
+    }
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+    const double m = s / N;
+    double var = q / N - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = N > 1 ? var * N / (N - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+    if (nbt && c == 0) *nbt += 1;
+}
+
+struct RowMap { int W, HW; long long bs, rs, cs, base; };    // row r = (b, i, j): element offset base + b*bs + i*rs + j*cs (+ c)
+__device__ __forceinline__ long long map_row(const RowMap& m, long long r) {
+    const long long b = r / m.HW; const int ij = (int)(r - b * m.HW);
+    const int i = ij / m.W, j = ij - i * m.W;
+    return m.base + b * m.bs + (long long)i * m.rs + (long long)j * m.cs;
+}
+
+// y = act((x - mean) * rstd * gamma + beta) -> contiguous f32 (kept for the backward) and / or a mapped (padded) f32 / bf16 map
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, long long n, int C, int act,
+                                                       float* __restrict__ y, void* __restrict__ y2, int y2_bf16, RowMap map) {
+    const int cshift = __ffs(C) - 1;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e & (C - 1));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float v = nn_act(act, (x[e] - mean[c]) * rstd[c] * g + b);
+        if (y) y[e] = v;
+        if (y2) {
+            const long long o = map_row(map, e >> cshift) + c;
+            if (y2_bf16) reinterpret_cast<bf16_t*>(y2)[o] = f2bf(v); else reinterpret_cast<float*>(y2)[o] = v;
+        }
+    }
+}
+
+// backward, pass 1: per slab and channel (sum dz, sum dz * xhat) with dz = dy * act'(y)
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C, int act,
+                                                           float* __restrict__ part) {
+    slab_reduce(N, C, part, [&](long long e, int c, float& u, float& v) {
+        const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
+        u = dz; v = dz * (x[e] - mean[c]) * rstd[c];
+    });
+}
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __restrict__ part, int nslab, int C, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ sums) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int k = lane4; k < nslab; k += 16) { s += (double)part[((long long)k * 2) * C + c]; q += (double)part[((long long)k * 2 + 1) * C + c]; }
+    red[0][lane4][cl] = s; red[1][lane4][cl] = q;
+    __syncthreads();
+    if (lane4 != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    sums[c] = (float)s; sums[C + c] = (float)q;
+}
+// pass 2: dx = gamma * rstd * (dz - [training] (sum dz + xhat * sum dz*xhat) / N)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, long long n, int N, int C, int act, int training,
+                                                           float* __restrict__ dx) {
+    const float invN = 1.0f / (float)N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e & (C - 1));
+        const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
+        const float xh = (x[e] - mean[c]) * rstd[c];
+        const float g = gamma ? gamma[c] : 1.f;
+        float v = dz;
+        if (training) v -= (sums[c] + xh * sums[C + c]) * invN;
+        dx[e] = g * rstd[c] * v;
+    }
+}
+
+// src [B, H, W, C] contiguous f32 -> interior of a padded / dilated map: dst[b][ph + i*dh][pw + j*dw][c]  (f32 or bf16)
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(const float* __restrict__ src, long long n, int C, void* __restrict__ dst, int dst_bf16, RowMap map) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long o = map_row(map, e / C) + (e % C);       // any C here (the encoder input map has C = 1)
+        if (dst_bf16) reinterpret_cast<bf16_t*>(dst)[o] = f2bf(src[e]); else reinterpret_cast<float*>(dst)[o] = src[e];
+    }
+}
+
+// 3x3 / stride 3 max pool of a single-channel map x[b][H][W] (floor mode): y[b][H/3][W/3], idx = flat argmax inside x[b] (first maximum in
+// row-major window order, as torch)
+__global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ x, long long xs_h, long long xs_w, long long xs_b, int H, int W, int B,
+                                                           float* __restrict__ y, int* __restrict__ idx) {
+    const int OH = H / 3, OW = W / 3;
+    const long long n = (long long)B * OH * OW;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / (OH * OW)), r = (int)(e - (long long)b * OH * OW), oh = r / OW, ow = r - oh * OW;
+        float best = -INFINITY; int bi = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int h = 3 * oh + i, w = 3 * ow + j;
+                const float v = x[b * xs_b + h * xs_h + w * xs_w];
+                if (v > best || (v != v && best == best)) { best = v; bi = h * W + w; }
+            }
+        y[e] = best; idx[e] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, int H, int W, int B,
+                                                           float* __restrict__ dx, long long xs_h, long long xs_w, long long xs_b) {
+    // windows do not overlap (stride = kernel): every input element belongs to at most one window -> plain stores into a zeroed dx
+    const int OH = H / 3, OW = W / 3;
+    const long long n = (long long)B * OH * OW;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / (OH * OW));
+        const int h = idx[e] / W, w = idx[e] - h * W;
+        dx[b * xs_b + h * xs_h + w * xs_w] = dy[e];
+    }
+}
+
+// y[b][c] = mean_r x[b][r][c]   /   dx[b][r][c] = dy[b][c] / R
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ y) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += x[((long long)b * R + r) * C + c];
+        y[(long long)b * C + c] = s / (float)R;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int R, int C, long long n, float* __restrict__ dx) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long b = e / ((long long)R * C);
+        dx[e] = dy[b * C + (e % C)] / (float)R;
+    }
+}
+
+int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+bool bn_channels_ok(int C) { return C >= 1 && (C == 512 || (C <= 256 && 256 % C == 0)); }
+
+}  // namespace
+
+extern "C" int scl_bn_nslabs(int N) { return (N + BN_SLAB - 1) / BN_SLAB; }
+
+extern "C" int scl_bn_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, int training, float momentum, float eps, int act, float* part, float* mean,
+                          float* rstd, float* y, void* y2, int y2_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs, int64_t m_cs,
+                          int64_t m_base, void* stream) {
+    SCL_REQUIRE(x && mean && rstd && (y || y2) && N >= 1 && bn_channels_ok(C), "bn_fwd: bad args (C must divide 256 or be 512)");
+    SCL_REQUIRE(training ? part != nullptr : (running_mean && running_var), "bn_fwd: training needs `part`, eval needs running statistics");
+    SCL_REQUIRE(act >= 0 && act <= 2, "bn_fwd: act");
+    hipStream_t s = (hipStream_t)stream;
+    const int nslab = scl_bn_nslabs(N);
+    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, s, x, N, C, part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, part, nslab, N, C, eps, momentum, training, running_mean, running_var,
+                       num_batches_tracked, mean, rstd);
+    const RowMap map = {m_W > 0 ? m_W : 1, m_HW > 0 ? m_HW : 1, m_bs, m_rs, m_cs, m_base};
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, x, mean, rstd, gamma, beta, (long long)N * C, C, act, y, y2,
+                       y2_bf16, map);
+    return scl_check_launch("scl_bn_fwd");
+}
+
+extern "C" int scl_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int N, int C,
+                          int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, void* stream) {
+    SCL_REQUIRE(dy && x && mean && rstd && part && sums && dx && N >= 1 && bn_channels_ok(C), "bn_bwd: bad args");
+    SCL_REQUIRE(act == 0 || y, "bn_bwd: the activation gradient needs the forward output y");
+    hipStream_t s = (hipStream_t)stream;
+    const int nslab = scl_bn_nslabs(N);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, part);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, part, nslab, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, dy, y, x, mean, rstd, gamma, sums, (long long)N * C, N, C,
+                       act, training, dx);
+    return scl_check_launch("scl_bn_bwd");
+}
+
+extern "C" int scl_pad_nhwc_f32(const float* src, int64_t rows, int C, void* dst, int dst_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs,
+                                int64_t m_cs, int64_t m_base, void* stream) {
+    SCL_REQUIRE(src && dst && rows >= 1 && C >= 1 && m_W >= 1 && m_HW >= 1, "pad_nhwc: bad args");
+    const RowMap map = {m_W, m_HW, m_bs, m_rs, m_cs, m_base};
+    hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, src, rows * C, C, dst, dst_bf16, map);
+    return scl_check_launch("scl_pad_nhwc_f32");
+}
+
+extern "C" int scl_maxpool3_fwd(const float* x, int64_t xs_h, int64_t xs_w, int64_t xs_b, int H, int W, int B, float* y, int* idx, void* stream) {
+    SCL_REQUIRE(x && y && idx && H >= 3 && W >= 3 && B >= 1, "maxpool3_fwd: bad args");
+    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(grid_for((long long)B * (H / 3) * (W / 3))), dim3(256), 0, (hipStream_t)stream, x, (long long)xs_h,
+                       (long long)xs_w, (long long)xs_b, H, W, B, y, idx);
+    return scl_check_launch("scl_maxpool3_fwd");
+}
+extern "C" int scl_maxpool3_bwd(const float* dy, const int* idx, int H, int W, int B, float* dx, int64_t xs_h, int64_t xs_w, int64_t xs_b, void* stream) {
+    SCL_REQUIRE(dy && idx && dx && H >= 3 && W >= 3 && B >= 1, "maxpool3_bwd: bad args");
+    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_for((long long)B * (H / 3) * (W / 3))), dim3(256), 0, (hipStream_t)stream, dy, idx, H, W, B, dx,
+                       (long long)xs_h, (long long)xs_w, (long long)xs_b);
+    return scl_check_launch("scl_maxpool3_bwd");
+}
+
+extern "C" int scl_avgpool_fwd(const float* x, int B, int R, int C, float* y, void* stream) {
+    SCL_REQUIRE(x && y && B >= 1 && R >= 1 && C >= 1, "avgpool_fwd: bad args");
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, R, C, y);
+    return scl_check_launch("scl_avgpool_fwd");
+}
+extern "C" int scl_avgpool_bwd(const float* dy, int B, int R, int C, float* dx, void* stream) {
+    SCL_REQUIRE(dy && dx && B >= 1 && R >= 1 && C >= 1, "avgpool_bwd: bad args");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long long)B * R * C)), dim3(256), 0, (hipStream_t)stream, dy, R, C, (long long)B * R * C, dx);
+    return scl_check_launch("scl_avgpool_bwd");
+}

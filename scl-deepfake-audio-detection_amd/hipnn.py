@@ -1,0 +1,331 @@
+"""Autograd-visible building blocks of the AASIST / ResNet back-ends, every one of them a HIP kernel behind the C ABI.
+
+The two back-ends (model/wav2vec2_aasist.py:62-604, model/resnet.py:47-191) are a few hundred small layers; what they need from a
+device library is: 2-D convolution, BatchNorm (+ReLU / SELU), Linear, a batched matrix product, a 3x3 max pool and global average
+pooling — forward and backward.  Here those are
+
+  * convolutions as IMPLICIT GEMMs over channels-last maps: the input is copied once into a zero-padded [B, Hp, Wp, C] map and the
+    GEMM kernel addresses the sliding windows in place (rows = output positions with overlapping windows, K = (kh; kw*C + c)
+    through the operand's 2-level contiguous index, one batch entry per utterance) — forward, backward-data (a stride-1
+    correlation of the zero-dilated, padded output gradient with the flipped weights) and backward-weights (both operands
+    transposed, one slab per utterance + a deterministic reduce).  fp32 operands run on the exact-fp32 matrix-core kernel
+    (csrc/gemm_f32.hip), bf16 operands on the bf16 kernels (csrc/gemm.hip);
+  * BatchNorm + activation, pooling: csrc/nn.hip;  Linear / bmm: the same GEMM entry point.
+
+torch is the tensor container and the autograd tape; no torch.nn.functional compute op of those kinds is called.
+Maps are channels-last throughout ([B, H, W, C]); the callers (aasist_head.py, resnet_head.py) are written for that layout.
+"""
+import torch
+
+from . import ops
+from .lib import FLAT
+from .ops import Op
+
+ACT_NONE, ACT_RELU, ACT_SELU = 0, 1, 2
+
+# Re-laid-out copies of the convolution weights ([Co][kh][kw][Cp] for the forward / wgrad, flipped [Ci][kh][kw][Cop] for the dgrad) are
+# pure functions of the weights: they are rebuilt once per optimizer step (the model bumps the epoch), not once per call.
+_WEIGHT_EPOCH = 0
+
+
+def weights_changed():
+    """Called by the model after every optimizer step / load_state_dict (the fused AdamW kernel writes through raw pointers, which
+    torch's per-tensor version counter does not see)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def _packed(weight, kind, dtype, build):
+    cache = weight.__dict__.setdefault("_scl_packed", {})        # lives and dies with the parameter object
+    hit = cache.get((kind, dtype))
+    if hit is None or hit[0] != (_WEIGHT_EPOCH, weight._version):
+        hit = ((_WEIGHT_EPOCH, weight._version), build())
+        cache[(kind, dtype)] = hit
+    return hit[1]
+
+
+def _ceil(v, m):
+    return (v + m - 1) // m * m
+
+
+def _colsum(x2d, M, N):
+    """Column sums of a contiguous f32 [M, N] (bias gradients): the self-finishing HIP reduction when its 8-column vectors fit."""
+    if N % 8:
+        return x2d.view(M, N).sum(0)          # the 2-class / 1-score layers (computed 4 wide): a handful of columns
+    out = torch.empty(N, device=x2d.device)
+    part = torch.empty(ops.colsum_nparts(M) * N, device=x2d.device)
+    ops.colsum_reduce(x2d, part, out, M, N)
+    return out
+
+
+# ---- convolution ---------------------------------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dtype):
+        """x [B, H, W, Ci] f32; weight [Co, Ci, kh, kw] (torch layout); bias [Co] or None -> y [B, OH, OW, Co] f32."""
+        B, H, W, Ci = x.shape
+        Co, _, kh, kw = weight.shape
+        sh, sw = stride
+        ph, pw = padding
+        vec = 8 if dtype == torch.bfloat16 else 4
+        Cp = _ceil(Ci, vec)
+        Hp, Wp = H + 2 * ph, W + 2 * pw
+        OH, OW = (Hp - kh) // sh + 1, (Wp - kw) // sw + 1
+        dev = x.device
+        xp = torch.zeros(B * Hp * Wp * Cp + 4096, dtype=dtype, device=dev)        # tail slack: tile rows past the map are masked, not skipped
+        xc = x.contiguous()
+        ops.pad_nhwc(xc, B * H * W, Ci, xp, (W, H * W, Hp * Wp * Cp, Wp * Cp, Cp, (ph * Wp + pw) * Cp))
+        def pack_fwd():
+            w = torch.zeros(Co, kh, kw, Cp, dtype=torch.float32, device=dev)
+            w[..., :Ci] = weight.detach().permute(0, 2, 3, 1)
+            return w.reshape(Co, kh * kw * Cp).to(dtype)
+        wk = _packed(weight, "fwd", dtype, pack_fwd)
+        K = kh * kw * Cp
+        y = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
+        ops.gemm(Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp), Op(wk, K), y, OH * OW, Co, K,
+                 nb1=B, c_bs1=OH * OW * Co, bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(xp, weight)
+        ctx.geom = (B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, has_bias = ctx.geom
+        dev = dy.device
+        dy = dy.contiguous().float()
+        vec = 8 if dtype == torch.bfloat16 else 4
+        Cop = _ceil(Co, vec)
+        K = kh * kw * Cp
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, B * OH * OW, Co)
+        dyc = dy if (dtype == torch.float32 and Cop == Co) else None
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            # dW[co][(kh,kw,c)] = sum_b sum_(oh,ow) dy[b,oh,ow,co] * xp[b, oh*sh+kh, ow*sw+kw, c]: both operands transposed (rows = the
+            # reduction index), one [Co, K] slab per utterance, summed in a fixed order
+            if dyc is None:
+                dyc = torch.zeros(B * OH * OW * Cop + 4096, dtype=dtype, device=dev)
+                ops.pad_nhwc(dy, B * OH * OW, Co, dyc, (OW, OH * OW, OH * OW * Cop, OW * Cop, Cop, 0))
+            tile = 64 if dtype == torch.float32 else 128
+            tiles = ((Co + tile - 1) // tile) * ((K + tile - 1) // tile) * B
+            sk = max(1, min(8, 1024 // max(tiles, 1), (OH * OW) // 256))          # enough blocks to hide the single-stage prefetch
+            slabs = torch.empty(B * sk, Co, K, dtype=torch.float32, device=dev)
+            ops.gemm(Op(dyc, Cop, bs1=OH * OW * Cop), Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp),
+                     slabs, Co, K, OH * OW, a_t=True, b_t=True, nb1=B, c_bs1=sk * Co * K, splitk=sk, c_split_stride=Co * K if sk > 1 else 0)
+            dwk = torch.empty(Co, K, dtype=torch.float32, device=dev)
+            ops.reduce_slabs(slabs, dwk, Co * K, B * sk, Co * K)
+            dw = dwk.view(Co, kh, kw, Cp)[..., :Ci].permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0]:
+            # dx = stride-1 correlation of the zero-dilated output gradient (padded by k-1-p) with the flipped, transposed weights
+            Hd, Wd = H + kh - 1, W + kw - 1
+            dyp = torch.zeros(B * Hd * Wd * Cop + 4096, dtype=dtype, device=dev)
+            ops.pad_nhwc(dy, B * OH * OW, Co, dyp, (OW, OH * OW, Hd * Wd * Cop, sh * Wd * Cop, sw * Cop, ((kh - 1 - ph) * Wd + (kw - 1 - pw)) * Cop))
+            Kd = kh * kw * Cop
+
+            def pack_bwd():
+                w = torch.zeros(Ci, kh, kw, Cop, dtype=torch.float32, device=dev)
+                w[..., :Co] = weight.detach().flip(2, 3).permute(1, 2, 3, 0)
+                return w.reshape(Ci, Kd).to(dtype)
+            wd = _packed(weight, "bwd", dtype, pack_bwd)
+            dx = torch.empty(B, H, W, Ci, dtype=torch.float32, device=dev)
+            ops.gemm(Op(dyp, Cop, rpb=W, rbstride=Wd * Cop, cin=kw * Cop, cout=Wd * Cop, bs1=Hd * Wd * Cop), Op(wd, Kd), dx, H * W, Ci, Kd,
+                     nb1=B, c_bs1=H * W * Ci)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dtype=torch.float32):
+    """Channels-last 2-D convolution (cross-correlation, as nn.Conv2d): x [B, H, W, Ci] -> [B, OH, OW, Co]."""
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), dtype)
+
+
+# ---- BatchNorm (+ activation) --------------------------------------------------------------------------------------------------------
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act):
+        C = x.shape[-1]
+        xc = x.contiguous().float()
+        N = xc.numel() // C
+        dev = x.device
+        part = torch.empty(ops.bn_nslabs(N) * 2 * C, device=dev)
+        mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        y = torch.empty_like(xc)
+        ops.bn_fwd(xc, N, C, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act, part, mean, rstd, y)
+        ctx.save_for_backward(xc, y, mean, rstd, weight)
+        ctx.cfg = (N, C, act, training, weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, y, mean, rstd, weight = ctx.saved_tensors
+        N, C, act, training, has_w, has_b = ctx.cfg
+        dev = dy.device
+        dyc = dy.contiguous().float()
+        part = torch.empty(ops.bn_nslabs(N) * 2 * C, device=dev)
+        sums = torch.empty(2 * C, device=dev)
+        dg = torch.empty(C, device=dev) if has_w else None
+        db = torch.empty(C, device=dev) if has_b else None
+        dx = torch.empty_like(xc)
+        ops.bn_bwd(dyc, y, xc, mean, rstd, weight, N, C, act, training, part, sums, dg, db, dx)
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, act=ACT_NONE):
+    """nn.BatchNorm1d / 2d semantics over the LAST dimension of x (channels-last), fused with `act`; `bn` supplies weight, bias, the
+    running statistics and the training flag (its forward is never called)."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, training,
+                              momentum, bn.eps, act)
+
+
+# ---- Linear / bmm ----------------------------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape
+        xc = x.contiguous().float().view(-1, K)
+        M = xc.shape[0]
+        wc = weight.detach().contiguous().float()
+        y = torch.empty(M, N, device=x.device)
+        ops.gemm(Op(xc, K), Op(wc, K), y, M, N, K, bias=None if bias is None else bias.detach().contiguous().float())
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.shape, bias is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        xshape, has_b = ctx.meta
+        N, K = wc.shape
+        M = xc.shape[0]
+        dev = dy.device
+        dyc = dy.contiguous().float().view(M, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dev)
+            ops.gemm(Op(dyc, N), Op(wc, K), dx, M, K, N, b_t=True)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K, device=dev)
+            # a [<= 128, <= 128] output is one or two tiles: split the reduction over the rows so that the launch is not a single
+            # block walking M / 32 steps at HBM latency, then sum the slabs in a fixed order
+            tiles = ((N + 63) // 64) * ((K + 63) // 64)
+            sk = max(1, min(32, 256 // tiles, M // 128))
+            if sk > 1:
+                slabs = torch.empty(sk, N, K, device=dev)
+                ops.gemm(Op(dyc, N), Op(xc, K), slabs, N, K, M, a_t=True, b_t=True, splitk=sk, c_split_stride=N * K)
+                ops.reduce_slabs(slabs, dw, N * K, sk, N * K)
+            else:
+                ops.gemm(Op(dyc, N), Op(xc, K), dw, N, K, M, a_t=True, b_t=True)
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dyc, M, N)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear on the exact-fp32 GEMM.  16-byte operand vectors need in_features % 4 == 0 and out_features % 4 == 0: narrower outputs
+    (the 2-class and 1-score layers) are computed 4 wide with zero rows and sliced."""
+    N, K = weight.shape
+    if K % 4:
+        pad = 4 - K % 4
+        x = torch.nn.functional.pad(x, (0, pad))
+        weight = torch.nn.functional.pad(weight, (0, pad))
+    if N % 4:
+        pad = 4 - N % 4
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, pad))
+        bias = None if bias is None else torch.nn.functional.pad(bias, (0, pad))
+        return _LinearFn.apply(x, weight, bias)[..., :N]
+    return _LinearFn.apply(x, weight, bias)
+
+
+class _BmmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        """a [B, M, K] @ b [B, K, N] -> [B, M, N]   (K % 4 == 0 and N % 4 == 0)."""
+        B, M, K = a.shape
+        N = b.shape[2]
+        ac, bc = a.contiguous().float(), b.contiguous().float()
+        c = torch.empty(B, M, N, device=a.device)
+        ops.gemm(Op(ac, K, bs1=M * K), Op(bc, N, bs1=K * N), c, M, N, K, b_t=True, nb1=B, c_bs1=M * N)
+        ctx.save_for_backward(ac, bc)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        ac, bc = ctx.saved_tensors
+        B, M, K = ac.shape
+        N = bc.shape[2]
+        dcc = dc.contiguous().float()
+        da = db = None
+        if ctx.needs_input_grad[0]:          # dA[m][k] = sum_n dC[m][n] B[k][n]
+            da = torch.empty(B, M, K, device=dc.device)
+            ops.gemm(Op(dcc, N, bs1=M * N), Op(bc, N, bs1=K * N), da, M, K, N, nb1=B, c_bs1=M * K)
+        if ctx.needs_input_grad[1]:          # dB[k][n] = sum_m A[m][k] dC[m][n]
+            db = torch.empty(B, K, N, device=dc.device)
+            ops.gemm(Op(ac, K, bs1=M * K), Op(dcc, N, bs1=M * N), db, K, N, M, a_t=True, b_t=True, nb1=B, c_bs1=K * N)
+        return da, db
+
+
+def bmm(a, b):
+    """torch.bmm on the exact-fp32 GEMM; the contraction and the output width are zero-padded to multiples of 4 (graph sizes such as 42
+    or 66 nodes are not)."""
+    K, N = a.shape[2], b.shape[2]
+    pk, pn = (-K) % 4, (-N) % 4
+    if pk:
+        a = torch.nn.functional.pad(a, (0, pk))
+        b = torch.nn.functional.pad(b, (0, 0, 0, pk))
+    if pn:
+        b = torch.nn.functional.pad(b, (0, pn))
+    c = _BmmFn.apply(a, b)
+    return c[..., :N] if pn else c
+
+
+# ---- pooling ---------------------------------------------------------------------------------------------------------------------------
+class _MaxPool3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        """x [B, H, W] f32 (any strides) -> [B, H // 3, W // 3]  (F.max_pool2d(x, (3, 3)) of a single-channel map)."""
+        B, H, W = x.shape
+        y = torch.empty(B, H // 3, W // 3, device=x.device)
+        idx = torch.empty(B, H // 3, W // 3, dtype=torch.int32, device=x.device)
+        xf = x.float()
+        ops.maxpool3_fwd(xf, xf.stride(1), xf.stride(2), xf.stride(0), H, W, B, y, idx)
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        dx = torch.zeros(B, H, W, device=dy.device)
+        ops.maxpool3_bwd(dy.contiguous().float(), idx, H, W, B, dx, W, 1, H * W)
+        return dx
+
+
+def max_pool3(x):
+    return _MaxPool3Fn.apply(x)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        """x [B, R, C] -> [B, C] mean over R."""
+        B, R, C = x.shape
+        y = torch.empty(B, C, device=x.device)
+        ops.avgpool_fwd(x.contiguous().float(), B, R, C, y)
+        ctx.shape = (B, R, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, R, C = ctx.shape
+        dx = torch.empty(B, R, C, device=dy.device)
+        ops.avgpool_bwd(dy.contiguous().float(), B, R, C, dx)
+        return dx
+
+
+def avg_pool_rows(x):
+    return _AvgPoolFn.apply(x)

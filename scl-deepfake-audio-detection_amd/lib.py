@@ -72,6 +72,16 @@ def _protos():
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
         "scl_debug_gemm_stamps": ([_vp, _i32], _i32),
         "scl_gemm_uses_wide_tiles": ([P(SclGemmDesc)], _i32),
+        # nn.hip
+        "scl_bn_nslabs": ([_i32], _i32),
+        "scl_bn_fwd": ([_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64,
+                        _i64, _i64, _vp], _i32),
+        "scl_bn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+        "scl_pad_nhwc_f32": ([_vp, _i64, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp], _i32),
+        "scl_maxpool3_fwd": ([_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
+        "scl_maxpool3_bwd": ([_vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp], _i32),
+        "scl_avgpool_fwd": ([_vp, _i32, _i32, _i32, _vp, _vp], _i32),
+        "scl_avgpool_bwd": ([_vp, _i32, _i32, _i32, _vp, _vp], _i32),
         # norm.hip
         "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
         "scl_layernorm_bwd_nparts": ([_i32], _i32),

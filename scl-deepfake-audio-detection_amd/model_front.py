@@ -133,11 +133,15 @@ class FrontHeadModel(nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict=True):
+        from . import hipnn
         r = super().load_state_dict(state_dict, strict=strict)
+        hipnn.weights_changed()
         self.P.mark_dirty()
         return r
 
     def optimizer_stepped(self, bf16_fresh):
+        from . import hipnn
+        hipnn.weights_changed()      # the back-end's re-laid-out convolution weights are rebuilt on next use
         self.P.mark_dirty()
         if bf16_fresh:
             self.P.bf16_version = self.P.version

@@ -397,3 +397,41 @@ def gat_score_fwd(x, W, bias, a, s, B, N, D, Do, n1):
 
 def gat_score_bwd(x, W, bias, a, ds, dP, part, dx, B, N, D, Do, n1):
     _call("scl_gat_score_bwd", _p(x), _p(W), _p(bias), _p(a), _p(ds), _p(dP), _p(part), _p(dx), B, N, D, Do, n1, _stream())
+
+
+# ---- back-end pieces over channels-last fp32 maps (csrc/nn.hip) ----------------------------------------------------------------------
+def bn_nslabs(N):
+    return L.load().scl_bn_nslabs(N)
+
+
+def bn_fwd(x, N, C, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, part, mean, rstd, y, y2=None, rowmap=None):
+    """rowmap = (W, HW, bs, rs, cs, base) of the mapped second output y2 (f32 or bf16)."""
+    W_, HW, bs, rs, cs, base = rowmap if rowmap is not None else (1, 1, 0, 0, 0, 0)
+    _call("scl_bn_fwd", _p(x), N, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt), 1 if training else 0, momentum, eps, act,
+          _p(part), _p(mean), _p(rstd), _p(y), _p(y2), 1 if (y2 is not None and y2.dtype == torch.bfloat16) else 0, W_, HW, bs, rs, cs, base, _stream())
+
+
+def bn_bwd(dy, y, x, mean, rstd, gamma, N, C, act, training, part, sums, dgamma, dbeta, dx):
+    _call("scl_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), N, C, act, 1 if training else 0, _p(part), _p(sums), _p(dgamma),
+          _p(dbeta), _p(dx), _stream())
+
+
+def pad_nhwc(src, rows, C, dst, rowmap):
+    W_, HW, bs, rs, cs, base = rowmap
+    _call("scl_pad_nhwc_f32", _p(src), rows, C, _p(dst), 1 if dst.dtype == torch.bfloat16 else 0, W_, HW, bs, rs, cs, base, _stream())
+
+
+def maxpool3_fwd(x, xs_h, xs_w, xs_b, H, W_, B, y, idx):
+    _call("scl_maxpool3_fwd", _p(x), xs_h, xs_w, xs_b, H, W_, B, _p(y), _p(idx), _stream())
+
+
+def maxpool3_bwd(dy, idx, H, W_, B, dx, xs_h, xs_w, xs_b):
+    _call("scl_maxpool3_bwd", _p(dy), _p(idx), H, W_, B, _p(dx), xs_h, xs_w, xs_b, _stream())
+
+
+def avgpool_fwd(x, B, R, C, y):
+    _call("scl_avgpool_fwd", _p(x), B, R, C, _p(y), _stream())
+
+
+def avgpool_bwd(dy, B, R, C, dx):
+    _call("scl_avgpool_bwd", _p(dy), B, R, C, _p(dx), _stream())

@@ -1,6 +1,7 @@
-"""AASIST back-end (scl_amd/aasist_head.py, torch-composed) against the reference's own model/wav2vec2_aasist.py::Model,
-via tests/golden/aasist.npz (oracle/gen_golden.py::gen_aasist).  fp32 on both sides: tolerance 2e-4 relative to the
-tensor's max magnitude (different op grouping only)."""
+"""Pins the ORACLE restatement of the AASIST back-end (oracle/aasist_head.py, plain torch on the CPU) to the reference's own
+model/wav2vec2_aasist.py::Model via tests/golden/aasist.npz (oracle/gen_golden.py::gen_aasist).  fp32 on both sides: tolerance 2e-4
+relative to the tensor's max magnitude (different op grouping only).  The product back-end (scl_amd/aasist_head.py, HIP kernels) is
+checked against the same vectors on the GPU in tests/test_aasist_gpu.py."""
 import os
 
 import numpy as np
@@ -8,7 +9,7 @@ import pytest
 import torch
 
 from oracle.aasist import fill_state
-from scl_amd.aasist_head import UPSTREAM_AASIST, AasistHead
+from oracle.aasist_head import UPSTREAM_AASIST, AasistHead
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aasist.npz"))
 TOL = 2e-4

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import head as OH  # noqa: E402
 from oracle import wav2vec2 as W  # noqa: E402
 from oracle.aasist import fill_state  # noqa: E402
+from oracle.aasist_head import AasistHead as OracleHead
 from scl_amd.aasist_head import UPSTREAM_AASIST, AasistHead  # noqa: E402
 from scl_amd.encoder import W2VConfig  # noqa: E402
 from scl_amd.model_aasist import Model  # noqa: E402
@@ -40,7 +41,7 @@ class CpuRef(torch.nn.Module):
         self.cfg = cfg
         self.ssl = {k: v.clone() for k, v in ssl_sd.items()}
         self.LL = torch.nn.Linear(cfg.embed, 128)
-        head = AasistHead(UPSTREAM_AASIST)
+        head = OracleHead(UPSTREAM_AASIST)          # plain-torch CPU restatement, pinned to the reference by tests/test_aasist_cpu.py
         for n, c in head.named_children():
             self.add_module(n, c)
         for n in ("pos_S", "master1", "master2"):
@@ -49,7 +50,7 @@ class CpuRef(torch.nn.Module):
 
     def forward(self, x):
         feats = self.LL(W.forward(self.ssl, self.cfg, x))
-        out, hid = AasistHead.forward(self, feats)
+        out, hid = OracleHead.forward(self, feats)
         return out, feats, hid
 
 
@@ -119,7 +120,7 @@ def test_train_step_gradients_and_update(dev):
     # (1) back-end + losses: the CPU copy of the head on the SAME features (the graph pooling's top-k is discontinuous, so the
     #     bf16 encoder error must not enter this comparison): fp32 torch on both sides, 2e-3
     f_leaf = feats.detach().cpu().requires_grad_(True)
-    ro, rh = AasistHead.forward(ref, f_leaf)
+    ro, rh = OracleHead.forward(ref, f_leaf)
     rl = OH.model_loss(ro, f_leaf, rh, y, 1)
     sum(rl.values()).backward()
     for k in rl:
@@ -199,3 +200,58 @@ def test_backend_as_hip_graphs_equals_eager(dev):
     assert all(np.isfinite(e).all() for e in errs)
     assert rl2(gbn, ebn) < 5e-2
     assert (gp - ep).abs().max().item() <= 2.2e-4 * 3
+
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aasist.npz"))
+
+
+class _HeadWithLL(torch.nn.Module):
+    """LL (test harness, torch) + the product back-end under the reference's state-dict names, on the GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.LL = torch.nn.Linear(16, 128)
+        head = AasistHead(UPSTREAM_AASIST)
+        for n, c in head.named_children():
+            self.add_module(n, c)
+        for n in ("pos_S", "master1", "master2"):
+            self.register_parameter(n, getattr(head, n))
+
+    def forward(self, x):
+        return AasistHead.forward(self, self.LL(x))
+
+
+@pytest.mark.parametrize("case", ["eval", "train"])
+def test_hip_backend_matches_the_reference_golden(dev, case):
+    """tests/golden/aasist.npz: inputs, filled weights and the outputs / gradients / BatchNorm buffers of the REFERENCE's own
+    wav2vec2_aasist Model (oracle/gen_golden.py::gen_aasist imports it).  The HIP back-end (implicit-GEMM convolutions and
+    projections on the exact-fp32 matrix-core kernel, fused BatchNorm+SELU, fused pairwise attention scores, HIP max pool) must
+    reproduce them at fp32 round-off: 2e-4 of each tensor's max magnitude."""
+    m = _HeadWithLL().to(dev)
+    sd = m.state_dict()
+    filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    if case == "eval":
+        m.eval()
+    else:
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    x = torch.from_numpy(G["x"]).to(dev).requires_grad_(True)
+    logits, hidden = m(x)
+    (logits * torch.from_numpy(G["w_logits"]).to(dev)).sum().add((hidden * torch.from_numpy(G["w_hidden"]).to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+
+    def close(a, b, name, tol=2e-4):
+        a, b = np.asarray(torch.as_tensor(a).detach().cpu(), dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert a.shape == b.shape, name
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+        assert err < tol, "%s: rel err %.3e" % (name, err)
+    close(logits, G[case + ":logits"], "logits"); close(hidden, G[case + ":hidden"], "hidden"); close(x.grad, G[case + ":grad_x"], "grad_x")
+    params = dict(m.named_parameters())
+    for k in G.files:
+        if k.startswith(case + ":grad:"):
+            close(params[k.split(":", 2)[2]].grad, G[k], k)
+        if k.startswith(case + ":buf:"):
+            close(m.state_dict()[k.split(":", 2)[2]], G[k], k)

@@ -1,6 +1,7 @@
-"""`wav2vec2_resnet_nll` plugin on the GPU: HIP encoder + LL + losses, torch-composed ResNet back-end on flat-buffer views.
-Reference = oracle wav2vec2 restatement (fp32, CPU) -> LL -> the ResNetHead class that tests/test_resnet_cpu.py pins to the
-reference's own Model.  bf16 bar (rel-L2 < 1e-2) on the encoder-side tensors, fp32 round-off (2e-3) on the back-end."""
+"""`wav2vec2_resnet_nll` plugin on the GPU: HIP encoder + LL + losses + HIP ResNet back-end (scl_amd/resnet_head.py) on flat-buffer
+views.  (1) The back-end alone against the reference's own Model through tests/golden/resnet.npz — exact-fp32 convolutions at
+2e-4, the default bf16-operand convolutions at the bf16 bar.  (2) The whole plugin against the CPU chain oracle wav2vec2 (fp32) ->
+LL -> oracle/resnet_head.py (pinned to the same golden by tests/test_resnet_cpu.py)."""
 import os
 import sys
 
@@ -15,6 +16,7 @@ from oracle.aasist import fill_state  # noqa: E402
 from scl_amd.encoder import W2VConfig  # noqa: E402
 from scl_amd.model_resnet import Model  # noqa: E402
 from scl_amd.optim import FusedAdamW  # noqa: E402
+from oracle import resnet_head as ORH  # noqa: E402
 from scl_amd.resnet_head import DEFAULT_RESNET, ResNetHead  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -34,14 +36,21 @@ def rl2(got, ref):
 
 
 class CpuRef(torch.nn.Module):
+    """oracle head (functional forward over the reference's state-dict names) + LL on the CPU."""
+
     def __init__(self, ssl_sd, cfg, head_sd):
         super().__init__()
         self.cfg = cfg
         self.ssl = {k: v.clone() for k, v in ssl_sd.items()}
         self.LL = torch.nn.Linear(cfg.embed, 128)
-        for n, c in ResNetHead(DEFAULT_RESNET).named_children():
+        tree = ORH.ParamTree({k: tuple(v.shape) for k, v in head_sd.items() if not k.startswith("LL.")})
+        for n, c in tree.named_children():
             self.add_module(n, c)
         self.load_state_dict(head_sd)
+
+    def head(self, feats):
+        t = dict(self.named_parameters()); t.update(dict(self.named_buffers()))
+        return ORH.forward(t, feats, self.training)
 
 
 def make(dev, seed, args=ARGS):
@@ -76,7 +85,7 @@ def test_eval_forward_and_train_step(dev):
     m.eval(); ref.eval()
     with torch.no_grad():
         rf = ref.LL(W.forward(ref.ssl, cfg, x))
-        ro, re = ResNetHead.forward(ref, rf)
+        ro, re = ref.head(rf)
         out, feats, emb = m(x.to(dev))
     assert out.shape == (4, 2) and emb.shape == (4, 256)
     assert rl2(feats, rf) < 1e-2 and rl2(emb, re) < 3e-2 and rl2(out, ro) < 3e-2, (rl2(feats, rf), rl2(emb, re), rl2(out, ro))
@@ -92,14 +101,14 @@ def test_eval_forward_and_train_step(dev):
         head2 = CpuRef(ref.ssl, cfg, {k: v.cpu() for k, v in m.state_dict().items() if not k.startswith("ssl_model.")})
         head2.train()
         f_leaf = feats.detach().cpu().requires_grad_(True)
-        o2, e2 = ResNetHead.forward(head2, f_leaf)
+        o2, e2 = head2.head(f_leaf)
         rl = {k: v * 4 for k, v in OH.model_loss(o2, f_leaf, e2, y, 1).items()}
         sum(rl.values()).backward()
         for k in rl:
             assert abs(float(losses[k].detach()) - float(rl[k].detach())) < 2e-3 * abs(float(rl[k].detach())) + 1e-5, (use_graphs, k)
         refp = dict(head2.named_parameters())
         for k in ("resnet.fc.weight", "resnet.conv5.weight", "resnet.layer2.0.shortcut.0.weight", "resnet.conv1.weight", "first_bn.weight"):
-            assert rl2(m.P.g(k), refp[k].grad) < 2e-2, (use_graphs, k, rl2(m.P.g(k), refp[k].grad))   # MIOpen fp32 (Winograd) vs CPU direct conv, through train-mode BatchNorm at batch 4
+            assert rl2(m.P.g(k), refp[k].grad) < 2e-2, (use_graphs, k, rl2(m.P.g(k), refp[k].grad))   # exact-fp32 HIP convolutions vs the fp32 CPU oracle (summation order), through train-mode BatchNorm at batch 4
         for n in [n for n, _, tr in W.param_shapes(cfg) if tr]:
             ref.ssl[n].requires_grad_(True)
             ref.ssl[n].grad = None
@@ -125,3 +134,66 @@ def test_frozen_encoder_gets_no_gradient(dev):
     torch.cuda.synchronize()
     lo = m.P.off("LL.weight")
     assert m.P.grad[:lo].abs().max().item() == 0.0 and m.P.grad[lo:].abs().max().item() > 0.0
+
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "resnet.npz"))
+
+
+class _HeadWithLL(torch.nn.Module):
+    """LL (test harness, torch) + the product back-end under the reference's state-dict names, on the GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.LL = torch.nn.Linear(16, 128)
+        for n, c in ResNetHead(DEFAULT_RESNET).named_children():
+            self.add_module(n, c)
+
+    def forward(self, x):
+        feats = self.LL(x)
+        out, emb = ResNetHead.forward(self, feats)
+        return out, feats, emb
+
+
+@pytest.mark.parametrize("conv,tol,gtol", [("f32", 2e-4, 2e-3), ("bf16", 2e-2, None)])
+@pytest.mark.parametrize("case", ["eval", "train"])
+def test_hip_backend_matches_the_reference_golden(dev, monkeypatch, case, conv, tol, gtol):
+    """tests/golden/resnet.npz holds inputs, filled weights and the outputs / loss terms / gradients / BatchNorm buffers of the
+    REFERENCE's wav2vec2_resnet_nll Model (generated by importing it, oracle/gen_golden.py::gen_resnet).  The HIP back-end — implicit
+    GEMM convolutions, fused BatchNorm kernels, HIP pooling and Linear — must reproduce them: 2e-4 with the exact-fp32 convolution
+    kernel (the default; gradients 2e-3: fp32 summation order through train-mode BatchNorm at batch 4 — the CPU oracle needs 1e-3),
+    forward at the bf16 bar with the opt-in bf16-operand convolutions (their gradients are not asserted: 10-28 % off on this
+    golden's early layers, which is why they are opt-in)."""
+    monkeypatch.setenv("SCL_RESNET_CONV", conv)
+    m = _HeadWithLL().to(dev)
+    sd = m.state_dict()
+    filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=7)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.eval() if case == "eval" else m.train()
+    x = torch.from_numpy(G["x"]).to(dev).requires_grad_(True)
+    y = torch.from_numpy(G["y"])
+    out, feats, emb = m(x)
+    bz = out.shape[0]
+    losses = {k: v * bz for k, v in OH.model_loss(out.cpu(), feats.cpu(), emb.cpu(), y, 1).items()}     # this plugin's Model.loss has no 1/bz
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+
+    def close(a, b, name, t):
+        a, b = np.asarray(torch.as_tensor(a).detach().cpu(), dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert a.shape == b.shape, name
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+        assert err < t, "%s: rel err %.3e" % (name, err)
+    close(out, G[case + ":logits"], "logits", tol); close(emb, G[case + ":emb"], "emb", tol); close(feats, G[case + ":feats"], "feats", 2e-4)
+    for k, v in losses.items():
+        close(v, G[case + ":loss:" + k], "loss " + k, tol)
+    if gtol is None:
+        return
+    close(x.grad, G[case + ":grad_x"], "grad_x", gtol)
+    params = dict(m.named_parameters())
+    for k in G.files:
+        if k.startswith(case + ":grad:"):
+            close(params[k.split(":", 2)[2]].grad, G[k], k, gtol)
+        if k.startswith(case + ":gradfp:"):
+            g = params[k.split(":", 2)[2]].grad.cpu()
+            close(np.concatenate([[g.norm().item(), g.sum().item()], g.flatten()[:16].numpy()]), G[k], k, gtol)
+        if k.startswith(case + ":buf:"):
+            close(m.state_dict()[k.split(":", 2)[2]], G[k], k, tol)
