@@ -241,6 +241,9 @@ int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
  * back by the backward instead of being recomputed */
 int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, void* z, float* stats,
                   int B, int L, int C, int k, int stride, float eps, void* stream);
+/* the same with an fp32 output map (scoring path: activations stay fp32 end to end) */
+int scl_conv0_fwd_f32(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, float* z,
+                      int B, int L, int C, int k, int stride, float eps, void* stream);
 int scl_conv0_bwd_nparts(int B, int L, int k, int stride);
 int scl_conv0_bwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const void* dz,
                   const float* stats, float* part_ws, float* dW, float* db, float* dgamma, float* dbeta, int B, int L, int C, int k,

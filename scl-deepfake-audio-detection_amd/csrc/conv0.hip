@@ -28,9 +28,10 @@ __device__ __forceinline__ void conv0_stage(float* wT, float* xs, const float* _
     for (int i = threadIdx.x; i < nx; i += blockDim.x) xs[i] = (x0 + i) < L ? x[x0 + i] : 0.f;
 }
 
+template <bool ZF32>     // ZF32: fp32 output (the scoring path keeps activations in fp32), else bf16
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* __restrict__ z, float* __restrict__ stats,
+                                                        const float* __restrict__ beta, void* __restrict__ zv, float* __restrict__ stats,
                                                         int L, int T0, int C, int k, int stride, int rows_per_block, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm0[];
     float* wT = sm0;
@@ -84,9 +85,16 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = gelu_f((y[ch][i] - mean) * rstd * gamma[c + i] + beta[c + i]);
-                uint4 u;
-                u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
-                *reinterpret_cast<uint4*>(z + ((int64_t)b * T0 + t0 + r) * C + c) = u;
+                const int64_t off = ((int64_t)b * T0 + t0 + r) * C + c;
+                if (ZF32) {
+                    float* z = reinterpret_cast<float*>(zv);
+                    *reinterpret_cast<float4*>(z + off) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(z + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+                    uint4 u;
+                    u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(zv) + off) = u;
+                }
             }
         }
     }
@@ -244,8 +252,20 @@ extern "C" int scl_conv0_fwd(const float* x, const float* w, const float* bias, 
     const int rows = 128;
     dim3 grid((T0 + rows - 1) / rows, B), block(256);
     const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
-    hipLaunchKernelGGL(conv0_fwd_kernel, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (bf16_t*)z, stats, L, T0, C, k, stride, rows, eps);
+    hipLaunchKernelGGL(conv0_fwd_kernel<false>, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, z, stats, L, T0, C, k, stride, rows, eps);
     return scl_check_launch("scl_conv0_fwd");
+}
+
+extern "C" int scl_conv0_fwd_f32(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                 float* z, int B, int L, int C, int k, int stride, float eps, void* stream) {
+    SCL_REQUIRE(x && w && bias && gamma && beta && z, "conv0_fwd_f32: null pointer");
+    SCL_REQUIRE(B > 0 && L >= k && C >= 8 && C <= 1024 && (C & 7) == 0 && k >= 1 && k <= MAXK && stride >= 1, "conv0_fwd_f32: bad dims");
+    const int T0 = (L - k) / stride + 1;
+    const int rows = 128;
+    dim3 grid((T0 + rows - 1) / rows, B), block(256);
+    const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
+    hipLaunchKernelGGL(conv0_fwd_kernel<true>, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (void*)z, nullptr, L, T0, C, k, stride, rows, eps);
+    return scl_check_launch("scl_conv0_fwd_f32");
 }
 
 extern "C" int scl_conv0_bwd_nparts(int B, int L, int k, int stride) {

@@ -302,6 +302,79 @@ class Encoder:
                           d["out"], None, d["omean"], d["orstd"], M, E)
         return d["out"], {"d": d, "x": x, "B": B, "L": L, "skipped": skipped}
 
+    # ---- fp32 scoring forward ----------------------------------------------------------------------
+    def _f32_weights(self):
+        """fp32 re-layouts of the weights that are not plain views of the flat buffer (conv stack [C][k*C], weight-normed grouped
+        positional conv [G][Cg][K*Cg]); rebuilt when the masters change.  A handful of small torch copies, scoring path only."""
+        P, cfg = self.P, self.cfg
+        if getattr(self, "_f32w_version", -1) == P.version:
+            return self._f32w
+        C, E, K, G = cfg.conv_dim, cfg.embed, cfg.pos_k, cfg.pos_groups
+        Cg = E // G
+        wk = [None] + [P.f32(self.n("feature_extractor.conv_layers.%d.0.weight" % i)).permute(0, 2, 1).reshape(C, -1).contiguous()
+                       for i in range(1, len(cfg.conv_kernels))]
+        v, g = P.f32(self.n("encoder.pos_conv.0.weight_v")), P.f32(self.n("encoder.pos_conv.0.weight_g"))
+        w = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())                              # weight_norm(dim=2)
+        pos = w.view(G, Cg, Cg, K).permute(0, 1, 3, 2).reshape(G, Cg, K * Cg).contiguous()       # k index = (tap, channel in group)
+        self._f32w, self._f32w_version = {"wk": wk, "pos": pos}, P.version
+        return self._f32w
+
+    def forward_f32(self, x):
+        """The encoder forward with fp32 activations and the fp32 master weights, every contraction on the exact-fp32 matrix-core
+        kernel (csrc/gemm_f32.hip) — what main.py --eval / --predict / --emb score with: the reference runs fp32 end to end
+        (main.py:161-214, no autocast) and north_star asks for scores within 1e-3 of it, which bf16 operands cannot give.
+        Forward only, one layer's activations live at a time.  x [B, L] fp32 on the GPU -> enc_out f32 [B*T, E]."""
+        cfg, P = self.cfg, self.P
+        B, L = x.shape
+        C, E, H, Fd, K, G = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k, cfg.pos_groups
+        D, Cg = E // H, E // G
+        Ts = cfg.conv_lens(L)
+        T = Ts[-1]
+        M, Tp = B * T, (T + 7) // 8 * 8
+        key = ("f32", B, L)
+        if key not in self._bufs:
+            f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+            slack = 128 * max(C, E)
+            self._bufs[key] = dict(z=[f32(B * t * C + slack) for t in Ts], y=f32(B * Ts[1] * C), stat=f32(2 * B * Ts[1]), h=f32(M * max(C, E) + slack),
+                                   x0=f32(M * E), xpad=torch.zeros(B * (T + K) * E + slack, device=self.dev), xa=f32(M * E), xb=f32(M * E),
+                                   x1=f32(M * E), qkv=f32(M * 3 * E + slack), S=f32(B * H * T * Tp), Pm=torch.zeros(B * H * T * Tp + 1024, device=self.dev),
+                                   ctx=f32(M * E + slack), a=f32(M * Fd + slack), out=f32(M * E))
+        d = self._bufs[key]
+        fw = self._f32_weights()
+        Wf = lambda name, ld: Op(P.flat, ld, offset=P.off(self.n(name)))
+        fe = "feature_extractor.conv_layers.%d."
+        mean, rstd = d["stat"][: B * Ts[1]], d["stat"][B * Ts[1]:]
+        ops.conv0_fwd_f32(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"), self.b(fe % 0 + "2.1.bias"),
+                          d["z"][0], B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0])
+        for i in range(1, len(Ts)):
+            k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
+            ops.gemm(Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), Op(fw["wk"][i], k * C), d["y"], B * Tout, C, k * C, bias=self.b(fe % i + "0.bias"))
+            ops.layernorm_fwd(d["y"], self.b(fe % i + "2.1.weight"), self.b(fe % i + "2.1.bias"), None, d["z"][i], mean, rstd, B * Tout, C, act=1)
+        ops.layernorm_fwd(d["z"][-1], self.b("layer_norm.weight"), self.b("layer_norm.bias"), None, d["h"], mean, rstd, M, C)
+        ops.gemm(Op(d["h"], C), Wf("post_extract_proj.weight", C), d["x0"], M, E, C, bias=self.b("post_extract_proj.bias"))
+        # positional conv: zero-padded rows (the pad rows of xpad are never written), GELU, residual
+        d["xpad"][: B * (T + K) * E].view(B, T + K, E)[:, K // 2: K // 2 + T].copy_(d["x0"].view(B, T, E))
+        xin, xout = d["xa"], d["xb"]
+        ops.gemm(Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(fw["pos"], K * Cg, bs2=Cg * K * Cg), xin, M, Cg, K * Cg,
+                 nb2=G, ldc=E, c_bs2=Cg, bias=self.b("encoder.pos_conv.0.bias"), bias_bs2=Cg, act=ACT_GELU, R=d["x0"], rmode=1)
+        qkv, S, Pm = d["qkv"], d["S"], d["Pm"]
+        for n in range(cfg.layers):
+            pn = "encoder.layers.%d." % n
+            ops.layernorm_fwd(xin, self.b(pn + "self_attn_layer_norm.weight"), self.b(pn + "self_attn_layer_norm.bias"), None, d["h"], mean, rstd, M, E)
+            ops.gemm(Op(d["h"], E), Wf(pn + "self_attn.q_proj.weight", E), qkv, M, 3 * E, E, bias=self.b(pn + "self_attn.q_proj.bias"))
+            ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), S, T, T, D, nb1=B, nb2=H, alpha=D ** -0.5,
+                     ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
+            Pm[: B * H * T * Tp].view(-1, Tp)[:, :T] = torch.softmax(S.view(-1, Tp)[:, :T], dim=-1)        # fp32 soft-max, as fairseq
+            ops.gemm(Op(Pm, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["ctx"], T, D, T, b_t=True,
+                     nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
+            ops.gemm(Op(d["ctx"], E), Wf(pn + "self_attn.out_proj.weight", E), d["x1"], M, E, E, bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
+            ops.layernorm_fwd(d["x1"], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"), None, d["h"], mean, rstd, M, E)
+            ops.gemm(Op(d["h"], E), Wf(pn + "fc1.weight", E), d["a"], M, Fd, E, bias=self.b(pn + "fc1.bias"), act=ACT_GELU)
+            ops.gemm(Op(d["a"], Fd), Wf(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"), R=d["x1"], rmode=1)
+            xin, xout = xout, xin
+        ops.layernorm_fwd(xin, self.b("encoder.layer_norm.weight"), self.b("encoder.layer_norm.bias"), None, d["out"], mean, rstd, M, E)
+        return d["out"], T
+
     # ---- backward --------------------------------------------------------------------------------
     def backward(self, ctx, d_out):
         """d_out: bf16 or f32 [M, E] gradient w.r.t. forward()'s output.  Writes every parameter

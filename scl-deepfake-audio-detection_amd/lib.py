@@ -112,6 +112,7 @@ def _protos():
         "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         # conv0.hip
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_conv0_fwd_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_conv0_bwd_nparts": ([_i32, _i32, _i32, _i32], _i32),
         "scl_conv0_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         # gat.hip

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .encoder import Encoder, W2VConfig, param_specs
-from .model_linear import init_parameters_, loss_custom, maybe_load_pretrained
+from .model_linear import SCORE_FP32, init_parameters_, loss_custom, maybe_load_pretrained
 from .ops import Op
 from .params import FlatParams, register_by_name
 
@@ -223,6 +223,12 @@ class FrontHeadModel(nn.Module):
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         if torch.is_grad_enabled():
             feats = _FrontFn.apply(self, x, self._anchor)
+        elif not self.training and SCORE_FP32:
+            # scoring: fp32 activations / master weights / exact-fp32 GEMMs through the encoder and LL (the back-end is fp32 anyway)
+            enc, T = self.ssl.forward_f32(x)
+            feats = torch.empty(x.shape[0], T, FEAT_DIM, device=self.device)
+            ops.gemm(Op(enc, self.cfg.embed), Op(self.P.flat, self.cfg.embed, offset=self.P.off("LL.weight")), feats, x.shape[0] * T, FEAT_DIM,
+                     self.cfg.embed, bias=self.P.f32("LL.bias"))
         else:
             feats = self._front_forward(x)[0].clone()
         output, last_hidden = self._head(feats)

@@ -22,8 +22,13 @@ from .lib import ACT_LEAKY, ACT_RELU
 from .ops import Op
 from .params import FlatParams, register_by_name
 
+import os
+
 HEAD_DIM = 128
 N_CLASS = 2
+# scoring (model.eval() under torch.no_grad(): main.py --eval / --predict / --emb, the validation pass) runs fp32 end to end unless
+# SCL_SCORE_FP32=0 asks for the bf16-operand training kernels (about 8x faster forward, scores to ~1e-2)
+SCORE_FP32 = os.environ.get("SCL_SCORE_FP32", "1") != "0"
 DROP_P = 0.5  # BackEnd(128, 128, 2, 0.5, False): torch.nn.Dropout(0.5) after each frame-level layer
 
 
@@ -290,12 +295,34 @@ class Model(nn.Module):
             self.encoder.backward(sv["ectx"], hb["denc"])
         return dict(drop_descs=drop_descs, meanpool_entry=mp_entry)
 
+    def _score_fp32(self, x):
+        """Scoring forward (no grad, eval mode): fp32 activations, fp32 master weights, exact-fp32 GEMMs end to end — the
+        reference's precision (main.py:161-214), for scores / embeddings within 1e-3 of it."""
+        P, E = self.P, self.cfg.embed
+        B = x.shape[0]
+        enc, T = self.encoder.forward_f32(x)
+        M = B * T
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        Wf = lambda name, ld: Op(P.flat, ld, offset=P.off(name))
+        feats, h0, h1 = f32(B, T, HEAD_DIM), f32(M, HEAD_DIM), f32(M, HEAD_DIM)
+        ops.gemm(Op(enc, E), Wf("LL.weight", E), h0, M, HEAD_DIM, E, bias=P.f32("LL.bias"), act=ACT_RELU, c2=feats)
+        for idx in (0, 3, 6):
+            ops.gemm(Op(h0, HEAD_DIM), Wf("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), h1, M, HEAD_DIM, HEAD_DIM,
+                     bias=P.f32("backend.m_frame_level.%d.bias" % idx), act=ACT_LEAKY)
+            h0, h1 = h1, h0
+        emb = h0.view(B, T, HEAD_DIM).mean(dim=1)
+        logp = f32(B, N_CLASS)
+        ops.utt_head_fwd(emb.contiguous(), P.f32("backend.m_utt_level.weight"), P.f32("backend.m_utt_level.bias"), logp, B, HEAD_DIM, N_CLASS)
+        return logp, feats, emb
+
     def _forward(self, x):
         if x.dim() == 3:
             x = x[:, :, 0]
         x = x.to(device=self.device, dtype=torch.float32).contiguous()   # main.py:60 hands over a transposed view
         if torch.is_grad_enabled() and any(p.requires_grad for p in (self._anchor,)):
             out, feats, emb = _ModelFn.apply(self, x, self._anchor)
+        elif not self.training and SCORE_FP32:
+            out, feats, emb = self._score_fp32(x)
         else:
             out, feats, emb, _ = self._run_forward(x)
             out, feats, emb = out.clone(), feats.clone(), emb.clone()

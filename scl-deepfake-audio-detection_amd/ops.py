@@ -313,6 +313,10 @@ def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5, stats=None
     _call("scl_conv0_fwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), _p(stats), B, Lx, C, k, stride, eps, _stream())
 
 
+def conv0_fwd_f32(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5):
+    _call("scl_conv0_fwd_f32", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), B, Lx, C, k, stride, eps, _stream())
+
+
 def conv0_bwd_nparts(B, Lx, k, stride):
     return L.load().scl_conv0_bwd_nparts(B, Lx, k, stride)
 

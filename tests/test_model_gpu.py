@@ -379,3 +379,27 @@ def test_batch_64_auto_selected_tiles_agree_with_the_validated_small_batch(dev):
     total.backward()
     torch.cuda.synchronize()
     assert 0.0 < total.item() < 1.0 and torch.isfinite(m.P.grad[: m.P.n_train]).all()
+
+
+def test_fp32_scoring_path_matches_oracle_to_1e3_at_xlsr_shape(dev):
+    """main.py --eval / --predict / --emb score with fp32 activations, the fp32 master weights and the exact-fp32 matrix-core GEMM
+    (Model._score_fp32 / Encoder.forward_f32): XLS-R-300M shape, 2 x 64600-sample clips (the eval pad length, T = 201), against the
+    fp32 CPU oracle — per-utterance log-probs, embeddings and frame features within north_star's fp32 bar, 1e-3 of the tensor's
+    scale (the bf16 training kernels give ~1e-2 on the same input, printed for comparison)."""
+    import scl_amd.model_linear as ML
+    m, ssl, head, ocfg = _full_size_model(dev, 71, 72)
+    x = 0.1 * torch.randn(2, 64600, generator=torch.Generator().manual_seed(99))
+    with torch.no_grad():
+        ro, rf, re = OH.full_forward(ssl, head, ocfg, x)
+        m.is_train = True
+        out, feats, emb = m(x.to(dev))
+        old, ML.SCORE_FP32 = ML.SCORE_FP32, False
+        try:
+            ob, fb, eb = m(x.to(dev))
+        finally:
+            ML.SCORE_FP32 = old
+    mx = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    print("fp32 scoring: max-rel logp %.2e emb %.2e feats %.2e | bf16 kernels: logp %.2e emb %.2e feats %.2e" %
+          (mx(out, ro), mx(emb, re), mx(feats, rf), mx(ob, ro), mx(eb, re), mx(fb, rf)))
+    assert mx(out, ro) < 1e-3 and mx(emb, re) < 1e-3 and mx(feats, rf) < 1e-3
+    assert (out.argmax(1).cpu() == ro.argmax(1)).all()
