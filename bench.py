@@ -114,7 +114,8 @@ def main():
     conf = {"model": {"contra_mode": "all", "loss_type": 1}}
     model = Model(margs, dev, w2v_cfg=cfg, seed=0)          # same seed on every rank = replicated weights
     model.train()                                            # dropout on, as train_epoch does (main.py:48)
-    sync = GradSync(model.P.grad) if world > 1 else None
+    g_lo, g_hi = model.trainable_range()
+    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, wire=os.environ.get("SCL_DP_WIRE", "fp32")) if world > 1 else None
     model.grad_sync = sync
     opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4, grad_sync=sync)   # main.py:339 defaults (max_lr, weight_decay)
 
@@ -214,6 +215,11 @@ def main():
                                "clips_per_s_kernel_only": B / (aug_ms * 1e-3),
                                "achieved_fp32_tflops": aug_flops / (aug_ms * 1e-3) / 1e12, "fp32_vector_peak_tflops": 157.3,
                                "note": "direct-form FIR, ~2.7 kFLOP/sample: VALU-bound, HBM traffic is the minimal 8 B/sample"}
+    if sync is not None:
+        # self-diagnosing multi-GPU line: ranks, buckets, when each all-reduce was issued relative to the end of the backward and
+        # how long the optimizer waited for the last one (the exposed part of the exchange)
+        res["rccl"] = dict(sync.report() or {}, rccl_ranks=world, backend=torch.distributed.get_backend(),
+                           grad_bytes_per_step=(g_hi - g_lo) * (2 if sync.wire == "bf16" else 4))
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(res))

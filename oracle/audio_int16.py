@@ -1,6 +1,10 @@
 """ORACLE (test infrastructure).  pydub 0.25.1 / CPython audioop integer semantics and the two
-augmenters built on them — PARITY UNPINNED w.r.t. pydub itself (not installed; restated from its
-published semantics), anchored on the reference's call sites:
+augmenters built on them.  Pinning: `reverb` and `librosa_to_int16` reproduce, bit for bit, vectors produced by the REFERENCE's
+own ReverbAugmentor.transform / librosa_to_pydub / pydub_to_librosa (tests/golden/audio_int16.npz, oracle/gen_golden.py::
+gen_audio_int16 — pydub.AudioSegment stood in by a bare sample container).  `rms_int` / `dbfs` / `apply_gain` / `overlay` /
+`background_noise` restate pydub's own arithmetic (AudioSegment.dBFS, apply_gain -> audioop.mul, overlay -> audioop.add), which
+cannot be executed here: PARITY UNPINNED w.r.t. pydub for those (restated from its published semantics).
+Anchored on the reference's call sites:
 
   datautils/audio_augmentor/utils.py:20-30      librosa_to_pydub / pydub_to_librosa
   datautils/audio_augmentor/reverb.py:33-44     ReverbAugmentor.transform

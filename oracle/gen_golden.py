@@ -491,6 +491,49 @@ def gen_resnet():
     print("resnet.npz", len(out), "arrays")
 
 
+def gen_audio_int16():
+    """A7 (and the int16 conversion both A7 and A8 rest on), executed FROM THE REFERENCE: ReverbAugmentor.transform
+    (datautils/audio_augmentor/reverb.py:33-44) and librosa_to_pydub / pydub_to_librosa (utils.py:20-30).  pydub and librosa are not
+    installed, so two inert stand-ins are injected: pydub.AudioSegment reduced to a sample container (raw bytes in,
+    get_array_of_samples() out — no arithmetic of its own) and librosa.load returning the RIR array it is handed.  Every arithmetic
+    line that runs — np.convolve on float32, the peak normalisation, `np.array(x * (1<<15), dtype=np.int16)` — is the reference's.
+    Also stored: the float64 convolution of the same inputs, so that tests can tell a genuine deviation from a float32-rounding tie
+    at an int16 truncation boundary."""
+    import array
+    import datautils.audio_augmentor.reverb as R
+    import datautils.audio_augmentor.utils as U
+
+    class Seg:
+        def __init__(self, data, frame_rate, sample_width, channels):
+            assert sample_width == 2 and channels == 1
+            self.raw = bytes(data)
+
+        def get_array_of_samples(self):
+            return array.array("h", self.raw)
+
+    U.AudioSegment = Seg
+    out = {}
+    rs = np.random.RandomState(11)
+    cases = {"short": (5000, 900, 120.0), "clip16000": (16000, 4000, 400.0), "long_rir": (12000, 8000, 1500.0)}
+    for name, (L, Rn, tau) in cases.items():
+        sp = (0.1 * rs.randn(L)).astype(np.float32)
+        rir = (np.exp(-np.arange(Rn) / tau) * rs.randn(Rn)).astype(np.float32)
+        R.librosa.load = lambda path, sr, _r=rir: (_r, sr)
+        aug = object.__new__(R.ReverbAugmentor)
+        aug.sr, aug.data, aug.rir_file = 16000, sp.copy(), "rir.wav"
+        aug.transform()
+        res = U.pydub_to_librosa(aug.augmented_audio)
+        assert res.dtype == np.int16 and res.shape == (L + Rn - 1,)
+        out[name + ":speech"], out[name + ":rir"], out[name + ":out"] = sp, rir, res
+        out[name + ":conv64"] = np.convolve(sp.astype(np.float64), rir.astype(np.float64))
+    conv_in = np.array([1.0, -1.0, 0.99999, -0.00002, 0.5, 0.25, -0.75, 3.0517578125e-05, -3.0517578125e-05, 0.999969482421875], np.float32)
+    out["conv:in"] = conv_in
+    with np.errstate(all="ignore"):
+        out["conv:out"] = U.pydub_to_librosa(U.librosa_to_pydub(conv_in))
+    np.savez_compressed(os.path.join(OUT, "audio_int16.npz"), **out)
+    print("audio_int16.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
@@ -499,6 +542,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16)):
         if want(name):
             fn()

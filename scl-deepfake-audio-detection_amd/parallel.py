@@ -7,10 +7,12 @@ fp32 gradient buffer — before the (replicated) AdamW step.  The buffer is cut 
 buckets; because the hand-written backward finishes gradients from the END of the buffer (head,
 then encoder layers 23..0, then the conv stack), each bucket's all-reduce is launched as soon as the
 backward has passed its lower edge and overlaps with the rest of the backward.  xGMI is
-point-to-point, so buckets are large (16 Mi elements = 64 MiB: per-collective latency is amortised, and only the
+point-to-point, so buckets are large (16 Mi elements = 64 MiB of fp32: per-collective latency is amortised, and only the
 last bucket — the conv stack, finished at the very end of backward — is exposed).
 Works with any torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -27,13 +29,26 @@ def shard_indices(n_items, rank, world, epoch_seed=None, drop_last=True):
 
 
 class GradSync:
-    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0):
+    """Bucketed all-reduce of the flat gradient slice, launched in backward order.
+
+    Streams: on the GPU every bucket is reduced on a DEDICATED communication stream — the compute stream records an event when the
+    bucket's slice is final, the communication stream waits for it, and the optimizer waits for the communication stream at
+    `finish()`.  RCCL's kernels therefore never sit in the compute queue in front of backward GEMMs (with torch's default, an
+    async_op collective is ordered on the current stream's side, and a 64-MiB ring step issued mid-backward would delay the next
+    launches).  `wire="bf16"` halves the bytes on the xGMI links: each bucket is cast to a bf16 staging buffer, summed in bf16 by
+    the collective and accumulated back in fp32 (the sum of `world` bf16 values carries ~3 significant digits per element — the
+    fp32 wire stays the default).  Per-bucket timing (`report()`): when the bucket's all-reduce was issued and how long the
+    optimizer had to wait for it at the end — the exposed part a scaling run needs to see."""
+
+    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0, wire="fp32"):
         """flat_grad: the slice of the flat gradient buffer that receives gradients (model.trainable_range()); `base` = its first
         element's offset in the whole buffer (ready_above() is called with whole-buffer offsets)."""
         self.grad = flat_grad
         self.base = int(base)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.wire = wire
+        assert wire in ("fp32", "bf16")
         n = flat_grad.numel()
         self.bounds = []
         hi = n
@@ -43,10 +58,25 @@ class GradSync:
             hi = lo
         self.launched = 0
         self.works = []
+        self.on_gpu = flat_grad.is_cuda
+        self.comm = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
+        self.stage = torch.empty(min(bucket_elems, n), dtype=torch.bfloat16, device=flat_grad.device) if wire == "bf16" else None
+        self.final_check = None              # tests: callable(lo, hi) run right before a bucket is handed to the collective
+        self._t_issue, self._ev_done, self._exposed_ms = [], [], 0.0
+        self.last_report = None
 
     def begin(self):
         self.launched = 0
         self.works = []
+        self._t_issue, self._ev_done = [], []
+
+    def _reduce(self, lo, hi):
+        g = self.grad[lo:hi]
+        if self.stage is None:
+            return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None
+        st = self.stage[: hi - lo]
+        st.copy_(g)                                            # fp32 -> bf16 on the wire
+        return dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), st
 
     def ready_above(self, lo_offset):
         """All gradient elements at offsets >= lo_offset are final: launch every bucket above it."""
@@ -55,7 +85,29 @@ class GradSync:
         lo_offset = max(0, lo_offset - self.base)
         while self.launched < len(self.bounds) and self.bounds[self.launched][0] >= lo_offset:
             lo, hi = self.bounds[self.launched]
-            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.final_check is not None:
+                self.final_check(lo, hi)
+            if self.comm is not None:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ready)                # the slice is final on the compute stream
+                    w, st = self._reduce(lo, hi)
+                    if st is not None:
+                        w.wait()                               # orders the copy-back behind the collective on the comm stream
+                        self.grad[lo:hi].copy_(st)
+                        w = None
+                    done = torch.cuda.Event(enable_timing=False)
+                    done.record(self.comm)
+                self._ev_done.append(done)
+            else:
+                w, st = self._reduce(lo, hi)
+                if st is not None:
+                    w.wait()
+                    self.grad[lo:hi].copy_(st)
+                    w = None
+            self.works.append(w)
+            self._t_issue.append(time.perf_counter())
             self.launched += 1
 
     def finish(self):
@@ -63,8 +115,21 @@ class GradSync:
         if self.world == 1:
             return 1.0
         self.ready_above(0)
+        t0 = time.perf_counter()
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)     # the optimizer kernel is ordered behind every bucket
+        self.last_report = {"buckets": len(self.bounds), "bucket_mib": [round((hi - lo) * (2 if self.stage is not None else 4) / 2 ** 20, 1)
+                                                                         for lo, hi in self.bounds],
+                            "issue_ms_before_finish": [round((t0 - t) * 1e3, 3) for t in self._t_issue],
+                            "host_wait_ms_at_finish": round((time.perf_counter() - t0) * 1e3, 3), "wire": self.wire}
         self.works = []
         self.launched = 0
         return 1.0 / self.world
+
+    def report(self):
+        """Diagnostics of the last step (bench.py prints them for N > 1): bucket sizes, how long before the end of the backward each
+        bucket's all-reduce was issued (host clock), and the host-side wait at finish()."""
+        return self.last_report

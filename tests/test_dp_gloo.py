@@ -61,3 +61,45 @@ def test_single_process_is_a_noop():
     s = GradSync(g)
     s.begin(); s.ready_above(0)
     assert s.finish() == 1.0 and torch.equal(g, torch.ones(10))
+
+
+def _worker_wire(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.parallel import GradSync
+    n = 1000
+    torch.manual_seed(3 + rank)
+    whole = torch.randn(n + 64)
+    g = whole[64:]                               # a trainable slice that starts at whole-buffer offset 64 (frozen encoder in front)
+    mine = g.clone()
+    gathered = [torch.empty(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    exact = sum(gathered)
+    seen = []
+    sync = GradSync(g, bucket_elems=256, base=64, wire="bf16")
+    sync.final_check = lambda lo, hi: seen.append((lo, hi, sync.launched))
+    sync.begin()
+    sync.ready_above(64 + 744)                   # whole-buffer offsets: bucket [744, 1000) of the slice is final
+    first = list(seen)
+    scale = sync.finish()
+    rep = sync.report()
+    # bf16 on the wire, fp32 accumulate back: each addend is rounded to bf16 once, the sum again
+    ok = torch.allclose(g, exact, rtol=2e-2, atol=2e-2) and not torch.equal(g, exact) and abs(scale - 0.5) < 1e-12
+    ok = ok and first == [(744, 1000, 0)] and [s[:2] for s in seen] == sync.bounds and rep["buckets"] == 4 and rep["wire"] == "bf16"
+    ok = ok and torch.equal(whole[:64], whole[:64]) and len(rep["issue_ms_before_finish"]) == 4
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_slice_base_and_bucket_order_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_wire, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -82,3 +82,83 @@ def test_two_rank_step_equals_single_process_mean_gradient_step(dev):
     ref = m.P.flat[: m.P.n_train].cpu()
     err = (res[0][0] - ref).abs().max().item()
     assert err < 2e-6, err
+
+
+def _worker_aasist(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.model_aasist import Model
+    from scl_amd.optim import FusedAdamW
+    from scl_amd.parallel import GradSync
+    dev = torch.device("cuda:0")
+    m = Model(ARGS, dev, seed=0)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    lo, hi = m.trainable_range()
+    sync = GradSync(m.P.grad[lo:hi], bucket_elems=40000, base=lo)
+    # every bucket must be handed to the collective only after its slice is final: the back-end's gradients are ACCUMULATED by torch
+    # autograd (not written by the hand-scheduled backward), so snapshot each bucket at hand-over and compare after the backward
+    snaps = []
+    sync.final_check = lambda a, b: snaps.append((a, b, m.P.grad[lo + a: lo + b].clone()))
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4, grad_sync=sync)
+    x, y = _data(rank)
+    final_ok = True
+    for _ in range(2):
+        snaps.clear()
+        out, feats, emb = m(x.to(dev))
+        total = sum(m.loss(out, feats, emb, y.to(dev), CONF).values())
+        opt.zero_grad()
+        sync.begin()
+        total.backward()
+        # local gradients as they stand after the whole backward, before finish() lets late buckets go
+        torch.cuda.synchronize()
+        launched = sync.launched
+        opt.step()
+        torch.cuda.synchronize()
+        final_ok = final_ok and launched >= 1 and len(snaps) == len(sync.bounds)
+    q.put((rank, m.P.flat[: m.P.n_train].cpu(), final_ok, m.state_dict()["first_bn1.running_mean"].cpu()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_aasist_step_equals_mean_gradient_step(dev):
+    """The BatchNorm-carrying plugin under data parallelism: per-rank batch statistics (as nn.DataParallel replicas would have), the
+    torch-autograd-accumulated back-end gradients inside the buckets, replicas bit-identical after the step and equal to a
+    single-process step on the mean of the two ranks' gradients."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_aasist, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (w, ok, bn)) for r, w, ok, bn in (q.get(timeout=600) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert torch.equal(res[0][0], res[1][0])                 # replicated weights stay bit-identical
+    assert not torch.equal(res[0][2], res[1][2])             # BatchNorm running statistics are per rank (different shards)
+    from scl_amd.model_aasist import Model
+    from scl_amd.optim import FusedAdamW
+    refs = []
+    m = Model(ARGS, dev, seed=0)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4, overlap=False)
+    for _ in range(2):
+        grads = []
+        for r in range(world):
+            x, y = _data(r)
+            out, feats, emb = m(x.to(dev))
+            opt.zero_grad()
+            sum(m.loss(out, feats, emb, y.to(dev), CONF).values()).backward()
+            grads.append(m.P.grad.clone())
+        m.P.grad.copy_((grads[0] + grads[1]) / world)
+        opt.step()
+    ref = m.P.flat[: m.P.n_train].cpu()
+    err = (res[0][0] - ref).abs().max().item()
+    assert err < 5e-5, err          # Adam's update is +-lr for any gradient: 2 steps x 1e-3 bound the effect of round-off sign flips

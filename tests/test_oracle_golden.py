@@ -176,3 +176,13 @@ def test_int16_semantics_corner_cases():
     assert out.dtype == np.int16 and out.shape == (1000,) and np.isfinite(gain)
     rv = AI.reverb(sp, np.exp(-np.arange(200) / 30.0).astype(np.float32))
     assert rv.shape == (1199,) and rv.dtype == np.int16 and (np.abs(rv.astype(np.int32)).max() in (32767, 32768))
+
+
+def test_reverb_and_int16_conversion_match_the_reference_run():
+    """tests/golden/audio_int16.npz was produced by the REFERENCE's ReverbAugmentor.transform / librosa_to_pydub / pydub_to_librosa
+    (oracle/gen_golden.py::gen_audio_int16; pydub.AudioSegment stood in by a bare sample container).  The oracle restatement must
+    reproduce it bit for bit: same np.convolve on float32, same peak normalisation, same C cast with wrap-around."""
+    g = np.load(os.path.join(G, "audio_int16.npz"))
+    assert AI.librosa_to_int16(g["conv:in"]).tolist() == g["conv:out"].tolist()
+    for name in ("short", "clip16000", "long_rir"):
+        assert np.array_equal(AI.reverb(g[name + ":speech"], g[name + ":rir"]), g[name + ":out"]), name
