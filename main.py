@@ -244,6 +244,7 @@ def main(argv=None):
 
     from scl_amd.optim import FusedAdamW
     from scl_amd.parallel import GradSync, shard_indices
+    from scl_amd.prefetch import Prefetcher
     g_lo, g_hi = model.trainable_range()
     sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo) if world > 1 else None
     optimizer = FusedAdamW(model, lr=args.max_lr, weight_decay=args.weight_decay, grad_sync=sync)
@@ -311,8 +312,10 @@ def main(argv=None):
             train_loader = DataLoader(epoch_set, batch_size=args.batch_size, num_workers=0, shuffle=False, drop_last=True)
         else:
             train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=0, shuffle=True, drop_last=True)
-        running_loss, train_acc, train_detail = run_epoch(train_loader, model, optimizer, device, config, train=True)
-        val_loss, val_acc, val_detail = run_epoch(dev_loader, model, None, device, config, train=False)
+        # pack i+1 is decoded / sampled / augmented by a prefetch thread on its own HIP stream while pack i trains (SCL_PREFETCH=0: inline)
+        wrap = (lambda ld: Prefetcher(ld, depth=2, device=device)) if os.environ.get("SCL_PREFETCH", "1") != "0" else (lambda ld: ld)
+        running_loss, train_acc, train_detail = run_epoch(wrap(train_loader), model, optimizer, device, config, train=True)
+        val_loss, val_acc, val_detail = run_epoch(wrap(dev_loader), model, None, device, config, train=False)
         if writer is not None:
             for k, v in (("train_accuracy", train_acc), ("val_accuracy", val_acc), ("val_loss", val_loss), ("loss", running_loss)):
                 writer.add_scalar(k, v, epoch)

@@ -17,18 +17,24 @@ def _stream():
 # identical from step to step.  The first step RECORDS them as (function, argument list) pairs; later
 # steps REPLAY the list (a ctypes call with pre-built arguments costs ~2 us instead of ~40 us of Python
 # descriptor building), which keeps the host ahead of the GPU.
-_REC = None
+# The recording state is PER THREAD: the prefetch thread (scl_amd/prefetch.py) launches augmentation kernels while the main thread may be
+# recording a train step — its calls must not end up in that plan (they would be replayed later on freed buffers).
+import threading
+
+_TLS = threading.local()
+
+
+def _rec():
+    return getattr(_TLS, "rec", None)
 
 
 def start_recording():
-    global _REC
-    _REC = []
-    return _REC
+    _TLS.rec = []
+    return _TLS.rec
 
 
 def stop_recording():
-    global _REC
-    plan, _REC = _REC, None
+    plan, _TLS.rec = _rec(), None
     return plan
 
 
@@ -41,17 +47,16 @@ def replay(plan):
 
 def host_callback(fn, *args):
     """Run a Python callback now and, when recording, at the same position of every replay (DP bucket launches)."""
-    global _REC
-    rec, _REC = _REC, None          # C-ABI calls the callback makes itself (optimizer slices) belong to the callback, not to the plan
+    rec, _TLS.rec = _rec(), None    # C-ABI calls the callback makes itself (optimizer slices) belong to the callback, not to the plan
     try:
         fn(*args)
     finally:
-        _REC = rec
-    if _REC is not None:
+        _TLS.rec = rec
+    if rec is not None:
         def _cb(*a, _fn=fn):
             _fn(*a)
             return 0
-        _REC.append((_cb, list(args), getattr(fn, "__name__", "callback"), None))
+        rec.append((_cb, list(args), getattr(fn, "__name__", "callback"), None))
 
 
 def _call(name, *args, keep=None):
@@ -59,9 +64,10 @@ def _call(name, *args, keep=None):
     rc = fn(*args)
     if rc != 0:
         L.check(rc, name)
-    if _REC is not None:
-        _REC.append((fn, list(args), name, keep))   # `keep` holds objects the arguments point into (GEMM descriptors)
-        return _REC[-1]
+    rec = _rec()
+    if rec is not None:
+        rec.append((fn, list(args), name, keep))   # `keep` holds objects the arguments point into (GEMM descriptors)
+        return rec[-1]
     return None
 
 
@@ -219,7 +225,7 @@ _COUNTERS = {}
 
 def _counters(device):
     """Ticket counters of the self-finishing reductions (zero between launches; one array per device, launches are stream-ordered)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)   # one set per stream
     if key not in _COUNTERS:
         _COUNTERS[key] = torch.zeros(128, dtype=torch.int32, device=device)
     return _COUNTERS[key]
@@ -231,7 +237,7 @@ _SCRATCH = {}
 def colreduce_seg(part, out, nparts, C, pstride=None, accumulate=False, out2=None, split=0):
     """colreduce over 8x more blocks, finished in-launch (LayerNorm parameter gradients: 768 partial rows x 2C or 3C);
     columns >= split go to out2 when given."""
-    key = (part.device.type, part.device.index)
+    key = (part.device.type, part.device.index, torch.cuda.current_stream(part.device).cuda_stream if part.is_cuda else 0)
     if key not in _SCRATCH:
         _SCRATCH[key] = torch.empty(8 * 4096, dtype=torch.float32, device=part.device)
     assert C <= 4096

@@ -90,6 +90,28 @@ def _dev(args):
     return torch.device(getattr(args, "device", "cuda"))
 
 
+# Decoded noise / RIR files stay resident in HBM (the reference decodes a possibly minutes-long MUSAN file from disk for every
+# view, background_noise.py:40-42): an LRU of device tensors bounded by SCL_AUDIO_BANK_GB (default 8 of the 288 GB).
+_BANK, _BANK_BYTES = {}, 0
+_BANK_LIMIT = int(float(os.environ.get("SCL_AUDIO_BANK_GB", "8")) * (1 << 30))
+
+
+def bank_tensor(path, sr, args, kind):
+    """kind 'i16': int16 PCM as pydub's AudioSegment.from_file would hold it; 'f32': float waveform (RIRs)."""
+    global _BANK_BYTES
+    key = (path, sr, kind, str(_dev(args)))
+    t = _BANK.pop(key, None)
+    if t is None:
+        x = _to_dev(load_audio(path, sr), args)
+        t = augment.to_int16(x) if kind == "i16" else x
+        _BANK_BYTES += t.numel() * t.element_size()
+        while _BANK_BYTES > _BANK_LIMIT and _BANK:
+            old = _BANK.pop(next(iter(_BANK)))
+            _BANK_BYTES -= old.numel() * old.element_size()
+    _BANK[key] = t            # most recently used last
+    return t
+
+
 def _to_dev(x, args):
     if torch.is_tensor(x):
         return x.to(_dev(args), dtype=torch.float32)
@@ -114,16 +136,14 @@ def background_noise_wrapper(x, args, sr=16000, audio_path=None):
     noise_list = list_audio_files(args.noise_path)
     noise_file = random.choice(noise_list)
     snr_db = random.randint(5, 15)
-    noise = load_audio(noise_file, sr)
-    noise_i16 = augment.to_int16(_to_dev(noise, args))   # AudioSegment.from_file decodes to int16 PCM
+    noise_i16 = bank_tensor(noise_file, sr, args, "i16")   # AudioSegment.from_file decodes to int16 PCM; resident in HBM after first use
     return augment.background_noise(_to_dev(x, args), noise_i16, snr_db)
 
 
 def reverb_wrapper(x, args, sr=16000, audio_path=None):
     """RIR convolution, augall_3:314-326 -> audio_augmentor/reverb.py:33-44 (returns int16-scaled values, length L+R-1)."""
     rir_file = random.choice(list_audio_files(args.rir_path))
-    rir = load_audio(rir_file, sr)
-    return augment.reverb(_to_dev(x, args), _to_dev(rir, args))
+    return augment.reverb(_to_dev(x, args), bank_tensor(rir_file, sr, args, "f32"))
 
 
 def speed_wrapper(x, args, sr=16000, audio_path=None):

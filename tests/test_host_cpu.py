@@ -155,3 +155,20 @@ def test_merge_rank_outputs_restores_protocol_order(tmp_path):
             fh.write("\n".join(lines[r::3]) + "\n")
     M.merge_rank_outputs(path, 3, 7)
     assert open(path).read().splitlines() == lines and not os.path.exists(path + ".rank0")
+
+
+def test_prefetcher_preserves_order_and_propagates_errors():
+    from scl_amd.prefetch import Prefetcher
+    items = [(i, torch.full((3,), float(i))) for i in range(7)]
+    got = list(Prefetcher(items, depth=2))
+    assert [g[0] for g in got] == list(range(7)) and all(torch.equal(a[1], b[1]) for a, b in zip(got, items))
+
+    def bad():
+        yield 1
+        raise ValueError("decode failed")
+    import pytest as _pt
+    with _pt.raises(ValueError, match="decode failed"):
+        list(Prefetcher(bad()))
+    it = iter(Prefetcher(range(1000), depth=1))        # early exit must not hang the producer thread
+    assert next(it) == 0
+    it.close()

@@ -41,6 +41,52 @@ for i in range(n):
     uid, x, y = ds[i % len(ids)]
 torch.cuda.synchronize()
 print("per pack: %.1f ms  (pack %s on %s)" % ((time.time() - t0) / n * 1e3, tuple(x.shape), x.device))
+# ---- does the host keep up with the GPU?  one optimizer step per pack (what 02_train.sh runs), pack building inline vs prefetched
+from torch.utils.data import DataLoader
+from scl_amd.model_linear import Model
+from scl_amd.optim import FusedAdamW
+from scl_amd.prefetch import Prefetcher
+dev = torch.device("cuda:0")
+model = Model({"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}, dev)
+model.train()
+opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4)
+conf = {"model": {"contra_mode": "all", "loss_type": 1}}
+
+
+class Rep(torch.utils.data.Dataset):
+    def __len__(self):
+        return 40
+
+    def __getitem__(self, i):
+        return ds[i % len(ids)]
+
+
+def epoch(loader):
+    torch.cuda.synchronize(); t0 = time.time(); n = 0
+    for uid, bx, by in loader:
+        x = bx.to(dev).squeeze(0).transpose(0, 1)
+        y = by.view(-1).long().to(dev)
+        out, feats, emb = model(x)
+        loss = sum(model.loss(out, feats, emb, y, conf).values())
+        opt.zero_grad(); loss.backward(); opt.step(); n += 1
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n * 1e3
+
+
+ld = DataLoader(Rep(), batch_size=1, shuffle=False, num_workers=0)
+epoch(ld)                                   # warm-up: launch plans recorded, banks resident
+t_inline = epoch(ld)
+t_pref = epoch(Prefetcher(ld, depth=2, device=dev))
+xs = ds[0][1].t().contiguous()
+ys = ds[0][2].long().to(dev)
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(20):
+    out, feats, emb = model(xs)
+    loss = sum(model.loss(out, feats, emb, ys, conf).values())
+    opt.zero_grad(); loss.backward(); opt.step()
+torch.cuda.synchronize()
+t_gpu = (time.time() - t0) / 20 * 1e3
+print("one optimizer step per 11-view pack: GPU step alone %.1f ms | pack building inline %.1f ms/iter | prefetch thread %.1f ms/iter" % (t_gpu, t_inline, t_pref))
 pr = cProfile.Profile()
 pr.enable()
 for i in range(n):
