@@ -133,6 +133,12 @@ def RawBoost12_online(x, args, sr=16000):
 
 def background_noise_wrapper(x, args, sr=16000, audio_path=None):
     """MUSAN overlay, augall_3:271-283 -> audio_augmentor/background_noise.py:40-56 (returns int16-scaled values)."""
+    if not getattr(args, "online_aug", True) and getattr(args, "aug_dir", None) and audio_path:
+        return _offline_cached("background_noise", x, args, sr, audio_path, lambda: _background_noise_online(x, args, sr), int16_values=True)
+    return _background_noise_online(x, args, sr)
+
+
+def _background_noise_online(x, args, sr):
     noise_list = list_audio_files(args.noise_path)
     noise_file = random.choice(noise_list)
     snr_db = random.randint(5, 15)
@@ -142,26 +148,44 @@ def background_noise_wrapper(x, args, sr=16000, audio_path=None):
 
 def reverb_wrapper(x, args, sr=16000, audio_path=None):
     """RIR convolution, augall_3:314-326 -> audio_augmentor/reverb.py:33-44 (returns int16-scaled values, length L+R-1)."""
+    if not getattr(args, "online_aug", True) and getattr(args, "aug_dir", None) and audio_path:
+        return _offline_cached("reverb", x, args, sr, audio_path, lambda: _reverb_online(x, args, sr), int16_values=True)
+    return _reverb_online(x, args, sr)
+
+
+def _reverb_online(x, args, sr):
     rir_file = random.choice(list_audio_files(args.rir_path))
     return augment.reverb(_to_dev(x, args), bank_tensor(rir_file, sr, args, "f32"))
 
 
+UNSUPPORTED_AUGMENTERS = {
+    "speed_wrapper": "pydub AudioSegment.speedup (chunk-drop + cross-fade in audioop integer arithmetic, audio_augmentor/speed.py:29-33)",
+    "pitch_wrapper": "librosa.effects.pitch_shift (phase vocoder + resampling, audio_augmentor/pitch.py:31-38)",
+}
+
+
 def speed_wrapper(x, args, sr=16000, audio_path=None):
-    raise NotImplementedError("speed_wrapper (conf-5 only) is outside the round-1 hot-path scope (SURVEY.md §8f rank 4)")
+    raise NotImplementedError("speed_wrapper: " + UNSUPPORTED_AUGMENTERS["speed_wrapper"] + " has no HIP implementation yet (SURVEY.md 8f rank 4)")
 
 
 def pitch_wrapper(x, args, sr=16000, audio_path=None):
-    raise NotImplementedError("pitch_wrapper (conf-5 only) is outside the round-1 hot-path scope (SURVEY.md §8f rank 4)")
+    raise NotImplementedError("pitch_wrapper: " + UNSUPPORTED_AUGMENTERS["pitch_wrapper"] + " has no HIP implementation yet (SURVEY.md 8f rank 4)")
 
 
-def _offline_cached(method, x, args, sr, audio_path, make):
-    """online_aug: false — reuse / create <aug_dir>/<method>/<utt> (PCM16), augall_3:366-374."""
+def _offline_cached(method, x, args, sr, audio_path, make, int16_values=False):
+    """online_aug: false — reuse / create <aug_dir>/<method>/<utt> (PCM16), augall_3:285-291,366-374.  The noise / reverb augmenters
+    hand back int16-VALUED samples (pydub_to_librosa keeps them unscaled) and the reference exports the AudioSegment itself, then
+    re-loads it with librosa.load, i.e. scaled to [-1, 1): the cached file holds the int16 values, a cache hit returns them / 32768."""
     aug_path = os.path.join(args.aug_dir, method, os.path.basename(audio_path))
     if os.path.exists(aug_path):
         return _to_dev(load_audio(aug_path, sr), args)
     y = make()
     os.makedirs(os.path.dirname(aug_path), exist_ok=True)
-    pcm = np.clip(np.round(y.detach().cpu().numpy() * 32767.0), -32768, 32767).astype("<i2")
+    if int16_values:
+        pcm = np.clip(y.detach().cpu().numpy(), -32768, 32767).astype("<i2")
+        y = y / 32768.0                   # the reference re-loads the file it just wrote with librosa.load (augall_3:288-291)
+    else:
+        pcm = np.clip(np.round(y.detach().cpu().numpy() * 32767.0), -32768, 32767).astype("<i2")
     if aug_path.lower().endswith(".wav"):
         with wave.open(aug_path, "wb") as w:
             w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
@@ -218,6 +242,13 @@ class PackDataset(Dataset):
         self.vocoders = list(vocoders)
         self.num_additional_real, self.num_additional_spoof = num_additional_real, num_additional_spoof
         self.methods = list(augmentation_methods) if len(augmentation_methods) >= 1 else ["RawBoost12"]
+        # fail at start-up, not on the first __getitem__ after the model has been built and the corpus listed
+        unknown = [m for m in self.methods if m not in AUGMENTERS]
+        missing = [m for m in self.methods if m in UNSUPPORTED_AUGMENTERS]
+        if unknown or missing:
+            raise NotImplementedError("augmentation_methods %s cannot run: %s" % (
+                unknown + missing, "; ".join(["%s is not a known augmenter" % m for m in unknown] +
+                                             ["%s needs %s" % (m, UNSUPPORTED_AUGMENTERS[m]) for m in missing])))
         if recipe in ("scl_normal", "augall_5"):
             # SCL_normal.py:69-71 switches on args.is_train; asvspoof_2019_augall_5.py:82 always reads <base>/spoof
             self.spoof_dir = os.path.join(base_dir, "spoof") if recipe == "augall_5" else \
