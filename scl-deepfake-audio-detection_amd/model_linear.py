@@ -117,8 +117,8 @@ class Model(nn.Module):
         self.flag_fix_ssl = args["flag_fix_ssl"]
         self.contra_mode = args["contra_mode"]
         self.loss_type = args["loss_type"]
-        if self.contra_mode != "all":
-            raise NotImplementedError("contra_mode 'one' (the reference's configs all use 'all')")
+        if self.contra_mode not in ("all", "one"):
+            raise ValueError("Unknown mode: {}".format(self.contra_mode))     # loss_metrics.py:161
         if w2v_cfg is None:
             # optional YAML key `w2v_arch`: "xlsr_300m" (default, the reference's only encoder) or "tiny" (tests / plumbing)
             w2v_cfg = W2VConfig.tiny() if args.get("w2v_arch", "xlsr_300m") == "tiny" else \
@@ -379,8 +379,11 @@ def loss_custom(output, feats, emb, labels, config):
     """model/loss_metrics.py:498-532 / Model.loss: dict of loss terms selected by loss_type."""
     L_CE, L_CF1, L_CF2 = _LossFn.apply(output, feats, emb, labels)
     lt = config["model"]["loss_type"]
-    if config["model"].get("contra_mode", "all") != "all":
-        raise NotImplementedError("contra_mode 'one'")
+    # contra_mode 'one' anchors only the first VIEW (loss_metrics.py:155-157); Model.loss hands supcon_loss exactly one view per
+    # utterance (feats.unsqueeze(1), wav2vec2_linear_nll.py:176-180), so anchor_feature == contrast_feature and anchor_count == nv == 1:
+    # both modes are the same computation here
+    if config["model"].get("contra_mode", "all") not in ("all", "one"):
+        raise ValueError("Unknown mode: {}".format(config["model"]["contra_mode"]))
     if lt == 1:
         return {"L_CE": L_CE, "L_CF1": L_CF1, "L_CF2": L_CF2}
     if lt == 2:
