@@ -307,8 +307,10 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
         w8_epilogue_pass(d, acc[0], 4, wlds, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         if (NH > 0) w8_epilogue_pass(d, acc[1], NH, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    w8_stamp(d, 3, lane, wave);
+    if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
+        w8_stamp(d, 3, lane, wave);
+    }
 }
 
 template <bool AT, bool BT, int RB0, int RB1>
@@ -442,8 +444,10 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
             w8_epilogue_pass(d, hi, RBW - 4, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    w8_stamp(d, 3, lane, wave);
+    if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
+        w8_stamp(d, 3, lane, wave);
+    }
 }
 
 template <bool AT, bool BT, int RB0, int RB1>

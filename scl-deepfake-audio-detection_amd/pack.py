@@ -73,6 +73,21 @@ def load_audio(path, sr=16000):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def require_decoder_for(paths, what):
+    """Fail at start-up when the corpus holds formats this image cannot decode: WAV goes through the stdlib, everything else
+    (ASVspoof ships FLAC, MUSAN / RIR corpora WAV) needs `soundfile` — or a loader registered with set_audio_loader()."""
+    if _LOADER is not None:
+        return
+    other = [p for p in paths if not str(p).lower().endswith(".wav")]
+    if not other:
+        return
+    try:
+        import soundfile  # noqa: F401
+    except ImportError as e:
+        raise RuntimeError("%s: %d files such as %s are not WAV and the `soundfile` package is not installed — install it or register "
+                           "a decoder with scl_amd.pack.set_audio_loader(fn)" % (what, len(other), other[0])) from e
+
+
 def list_audio_files(root):
     """Index of a noise / RIR corpus, built ONCE per path (the reference os.walk()s it for every sample,
     audio_augmentor/background_noise.py:22, reverb.py:30)."""
@@ -236,6 +251,7 @@ class PackDataset(Dataset):
         self.recipe, self.args = recipe, args
         args.noise_path, args.rir_path, args.aug_dir, args.online_aug = noise_path, rir_path, aug_dir, online_aug
         self.list_IDs = list_IDs
+        require_decoder_for(list_IDs, "training / validation list")
         self.bonafide_dir = os.path.join(base_dir, "bonafide")
         self.vocoded_dir = os.path.join(base_dir, "vocoded")
         self.trim_length, self.sample_rate, self.repeat_pad = trim_length, wav_samp_rate, repeat_pad
@@ -312,6 +328,7 @@ class PackDataset(Dataset):
 class EvalDataset(Dataset):
     def __init__(self, list_IDs, base_dir, padding_type="zero", subdir="eval"):
         self.list_IDs = list_IDs
+        require_decoder_for(list_IDs, "evaluation list")
         self.base_dir = os.path.join(base_dir, subdir) if subdir else base_dir
         self.cut = 64600
         self.padding_type = padding_type

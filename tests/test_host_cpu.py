@@ -172,3 +172,21 @@ def test_prefetcher_preserves_order_and_propagates_errors():
     it = iter(Prefetcher(range(1000), depth=1))        # early exit must not hang the producer thread
     assert next(it) == 0
     it.close()
+
+
+def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
+    from scl_amd import pack
+    pack.set_audio_loader(None)
+    pack.require_decoder_for(["a.wav", "b.WAV"], "list")                  # WAV: stdlib
+    try:
+        import soundfile  # noqa: F401
+        has_sf = True
+    except ImportError:
+        has_sf = False
+    if not has_sf:
+        import pytest as _pt
+        with _pt.raises(RuntimeError, match="soundfile"):
+            pack.require_decoder_for(["LA_T_1000137.flac"], "training / validation list")
+    pack.set_audio_loader(lambda p, sr: np.zeros(10, np.float32))
+    pack.require_decoder_for(["LA_T_1000137.flac"], "list")               # a registered loader decodes anything
+    pack.set_audio_loader(None)
