@@ -129,7 +129,7 @@ int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, 
 /* AASIST / ResNet back-end pieces over channels-last fp32 maps (csrc/nn.hip)                  */
 /* ------------------------------------------------------------------------------------------ */
 /* BatchNorm over the rows of x [N, C] (C a power of two <= 512) fused with an activation (act: 0 none, 1 ReLU, 2 SELU).
- * training != 0: batch statistics (part: f32 [scl_bn_nslabs(N)][2][C] scratch), running_mean / running_var / num_batches_tracked
+ * training != 0: batch statistics (part: scratch of scl_bn_nslabs(N) * 2 * C DOUBLES = 16 * nslabs * C bytes, 8-byte aligned), running_mean / running_var / num_batches_tracked
  * updated like torch (momentum, unbiased variance); else the running statistics are used.  Saves mean / rstd [C].  Writes
  * y [N, C] f32 (may be NULL) and / or y2: element (row r = (b,i,j), c) at y2[m_base + b*m_bs + i*m_rs + j*m_cs + c] with
  * i = (r % m_HW) / m_W, j = r % m_W — the interior of the zero-padded map the next convolution reads (f32, or bf16 when y2_bf16).

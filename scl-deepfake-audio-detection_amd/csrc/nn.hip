@@ -28,15 +28,22 @@ __device__ __forceinline__ float nn_act_grad_from_y(int act, float y) {
 // partial (sum a, sum a*b) per slab and channel; a = f(row, c), b = g(row, c).  Thread t owns channel (t % C) when C <= 256 (C divides
 // 256), channels t and t + 256 when C == 512: consecutive threads read consecutive addresses.
 template <class F>
-__device__ __forceinline__ void slab_reduce(int N, int C, float* part, F f) {
-    __shared__ float red[2][256];
+__device__ __forceinline__ void slab_reduce(int N, int C, double* part, F f) {
+    __shared__ double red[2][256];
     const int slab = blockIdx.x, t = threadIdx.x;
     const long long e0 = (long long)slab * BN_SLAB * C, e1 = min((long long)(slab + 1) * BN_SLAB, (long long)N) * C;
     const int nacc = C > 256 ? C / 256 : 1;
     for (int a = 0; a < nacc; ++a) {
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;      // fp64 from the first add: a scalar gradient such as first_bn.weight cancels 1e4 : 1
         const int ch = (t + 256 * a) & (C - 1);       // C is a power of two and divides the slab start
-        for (long long e = e0 + t + 256 * a; e < e1; e += 256 * nacc) {
+        const long long step = 256 * nacc;
+        long long e = e0 + t + 256 * a;
+        for (; e + 3 * step < e1; e += 4 * step) {    // four independent loads in flight per thread
+            float u0, v0, u1, v1, u2, v2, u3, v3;
+            f(e, ch, u0, v0); f(e + step, ch, u1, v1); f(e + 2 * step, ch, u2, v2); f(e + 3 * step, ch, u3, v3);
+            s0 += ((double)u0 + (double)u1) + ((double)u2 + (double)u3); s1 += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; e < e1; e += step) {
             float u, v;
             f(e, ch, u, v);
             s0 += u; s1 += v;
@@ -45,7 +52,7 @@ __device__ __forceinline__ void slab_reduce(int N, int C, float* part, F f) {
         __syncthreads();
         const int cc = C > 256 ? 256 : C;          // threads t, t + cc, t + 2cc ... share a channel
         if (t < cc) {
-            float r0 = 0.f, r1 = 0.f;
+            double r0 = 0.0, r1 = 0.0;
             for (int k = t; k < 256; k += cc) { r0 += red[0][k]; r1 += red[1][k]; }
             part[((long long)slab * 2 + 0) * C + t + 256 * a] = r0;
             part[((long long)slab * 2 + 1) * C + t + 256 * a] = r1;
@@ -54,14 +61,14 @@ __device__ __forceinline__ void slab_reduce(int N, int C, float* part, F f) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, double* __restrict__ part) {
     slab_reduce(N, C, part, [&](long long e, int, float& u, float& v) { const float a = x[e]; u = a; v = a * a; });
 }
 
 // mean / rstd from the slab partials (training) or from the running statistics (eval); training also updates the running
 // statistics with momentum (unbiased variance, as torch) and num_batches_tracked
 // 64 channels per block x 16 slab lanes: the slab loop is split sixteen ways and combined through LDS (fp64)
-__global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict__ part, int nslab, int N, int C, float eps, float momentum, int training,
+__global__ __launch_bounds__(1024) void bn_finish_kernel(const double* __restrict__ part, int nslab, int N, int C, float eps, float momentum, int training,
                                  float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
                                  float* __restrict__ mean, float* __restrict__ rstd) {
     __shared__ double red[2][16][64];
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
     if (training && c < C)
-        for (int k = lane4; k < nslab; k += 16) { s += (double)part[((long long)k * 2) * C + c]; q += (double)part[((long long)k * 2 + 1) * C + c]; }
+        for (int k = lane4; k < nslab; k += 16) { s += part[((long long)k * 2) * C + c]; q += part[((long long)k * 2 + 1) * C + c]; }
     red[0][lane4][cl] = s; red[1][lane4][cl] = q;
     __syncthreads();
     if (lane4 != 0 || c >= C) return;
@@ -105,6 +112,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, long long n, int C, int act,
                                                        float* __restrict__ y, void* __restrict__ y2, int y2_bf16, RowMap map) {
     const int cshift = __ffs(C) - 1;
+    if ((C & 3) == 0 && !y2) {       // 16-byte path (every map but the single-channel input)
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < (n >> 2); q += (long long)gridDim.x * 256) {
+            const long long e = q << 2;
+            const int c = (int)(e & (C - 1));
+            const float4 xv = *reinterpret_cast<const float4*>(x + e), mv = *reinterpret_cast<const float4*>(mean + c), rv = *reinterpret_cast<const float4*>(rstd + c);
+            float4 gv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gamma) gv = *reinterpret_cast<const float4*>(gamma + c);
+            if (beta) bv = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = nn_act(act, (xv.x - mv.x) * rv.x * gv.x + bv.x); o.y = nn_act(act, (xv.y - mv.y) * rv.y * gv.y + bv.y);
+            o.z = nn_act(act, (xv.z - mv.z) * rv.z * gv.z + bv.z); o.w = nn_act(act, (xv.w - mv.w) * rv.w * gv.w + bv.w);
+            *reinterpret_cast<float4*>(y + e) = o;
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
         const int c = (int)(e & (C - 1));
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -120,20 +142,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // backward, pass 1: per slab and channel (sum dz, sum dz * xhat) with dz = dy * act'(y)
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C, int act,
-                                                           float* __restrict__ part) {
+                                                           double* __restrict__ part) {
     slab_reduce(N, C, part, [&](long long e, int c, float& u, float& v) {
         const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
         u = dz; v = dz * (x[e] - mean[c]) * rstd[c];
     });
 }
-__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __restrict__ part, int nslab, int C, float* __restrict__ dgamma,
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const double* __restrict__ part, int nslab, int C, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ sums) {
     __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = lane4; k < nslab; k += 16) { s += (double)part[((long long)k * 2) * C + c]; q += (double)part[((long long)k * 2 + 1) * C + c]; }
+        for (int k = lane4; k < nslab; k += 16) { s += part[((long long)k * 2) * C + c]; q += part[((long long)k * 2 + 1) * C + c]; }
     red[0][lane4][cl] = s; red[1][lane4][cl] = q;
     __syncthreads();
     if (lane4 != 0 || c >= C) return;
@@ -149,6 +171,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sums, long long n, int N, int C, int act, int training,
                                                            float* __restrict__ dx) {
     const float invN = 1.0f / (float)N;
+    if ((C & 3) == 0) {
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < (n >> 2); q += (long long)gridDim.x * 256) {
+            const long long e = q << 2;
+            const int c = (int)(e & (C - 1));
+            const float4 dv = *reinterpret_cast<const float4*>(dy + e), xv = *reinterpret_cast<const float4*>(x + e);
+            const float4 mv = *reinterpret_cast<const float4*>(mean + c), rv = *reinterpret_cast<const float4*>(rstd + c);
+            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (act) yv = *reinterpret_cast<const float4*>(y + e);
+            if (gamma) gv = *reinterpret_cast<const float4*>(gamma + c);
+            const float d4[4] = {dv.x, dv.y, dv.z, dv.w}, x4[4] = {xv.x, xv.y, xv.z, xv.w}, m4[4] = {mv.x, mv.y, mv.z, mv.w};
+            const float r4[4] = {rv.x, rv.y, rv.z, rv.w}, y4[4] = {yv.x, yv.y, yv.z, yv.w}, g4[4] = {gv.x, gv.y, gv.z, gv.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dz = d4[i] * (act ? nn_act_grad_from_y(act, y4[i]) : 1.f);
+                const float xh = (x4[i] - m4[i]) * r4[i];
+                float v = dz;
+                if (training) v -= (sums[c + i] + xh * sums[C + c + i]) * invN;
+                o[i] = g4[i] * r4[i] * v;
+            }
+            *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
         const int c = (int)(e & (C - 1));
         const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
@@ -230,8 +276,8 @@ extern "C" int scl_bn_fwd(const float* x, int N, int C, const float* gamma, cons
     SCL_REQUIRE(act >= 0 && act <= 2, "bn_fwd: act");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = scl_bn_nslabs(N);
-    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, s, x, N, C, part);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, part, nslab, N, C, eps, momentum, training, running_mean, running_var,
+    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, s, x, N, C, (double*)part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, N, C, eps, momentum, training, running_mean, running_var,
                        num_batches_tracked, mean, rstd);
     const RowMap map = {m_W > 0 ? m_W : 1, m_HW > 0 ? m_HW : 1, m_bs, m_rs, m_cs, m_base};
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, x, mean, rstd, gamma, beta, (long long)N * C, C, act, y, y2,
@@ -245,8 +291,8 @@ extern "C" int scl_bn_bwd(const float* dy, const float* y, const float* x, const
     SCL_REQUIRE(act == 0 || y, "bn_bwd: the activation gradient needs the forward output y");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = scl_bn_nslabs(N);
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, part);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, part, nslab, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, (double*)part);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, C, dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, dy, y, x, mean, rstd, gamma, sums, (long long)N * C, N, C,
                        act, training, dx);
     return scl_check_launch("scl_bn_bwd");

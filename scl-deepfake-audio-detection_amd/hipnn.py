@@ -148,7 +148,7 @@ class _BatchNormFn(torch.autograd.Function):
         xc = x.contiguous().float()
         N = xc.numel() // C
         dev = x.device
-        part = torch.empty(ops.bn_nslabs(N) * 2 * C, device=dev)
+        part = torch.empty(ops.bn_nslabs(N) * 2 * C, dtype=torch.float64, device=dev)
         mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
         y = torch.empty_like(xc)
         ops.bn_fwd(xc, N, C, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act, part, mean, rstd, y)
@@ -162,7 +162,7 @@ class _BatchNormFn(torch.autograd.Function):
         N, C, act, training, has_w, has_b = ctx.cfg
         dev = dy.device
         dyc = dy.contiguous().float()
-        part = torch.empty(ops.bn_nslabs(N) * 2 * C, device=dev)
+        part = torch.empty(ops.bn_nslabs(N) * 2 * C, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * C, device=dev)
         dg = torch.empty(C, device=dev) if has_w else None
         db = torch.empty(C, device=dev) if has_b else None

@@ -1,3 +1,2 @@
-for g in 0 1; do for m in wav2vec2_aasist wav2vec2_resnet_nll; do SCL_HEAD_GRAPH=$g python bench.py --model $m --batch 32 --rawboost 0 --steps 6 --warmup 3 --no-cpu-baseline 2>gpurun_out/hb_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m graph=$g', 'ms/step %.2f utt/s %.1f loss %.4f'%(d['ms_per_step'], d['value'], d['final_loss']))"; grep -iE "error|fail|capture" gpurun_out/hb_err.log | head -3; done; done
-SCL_TEST_HEAD_GRAPH=1 python -m pytest tests/test_aasist_gpu.py -q -k "hip_graphs" 2>&1 | tail -3
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default', 'ms/step %.2f utt/s %.1f frac %.4f'%(d['ms_per_step'], d['value'], d['roofline']['frac']))"
+python -m pytest tests/test_resnet_gpu.py tests/test_aasist_gpu.py -q 2>&1 | tail -2
+for m in wav2vec2_aasist wav2vec2_resnet_nll; do python bench.py --model $m --batch 32 --rawboost 0 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', 'ms/step %.2f utt/s %.1f'%(d['ms_per_step'], d['value']))"; done
