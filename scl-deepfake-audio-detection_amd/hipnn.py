@@ -36,6 +36,8 @@ def weights_changed():
 
 
 def _packed(weight, kind, dtype, build):
+    if torch.cuda.is_current_stream_capturing():
+        return build()          # inside a hipGraph capture the re-layout must be part of the graph: every replay reads the live weights
     cache = weight.__dict__.setdefault("_scl_packed", {})        # lives and dies with the parameter object
     hit = cache.get((kind, dtype))
     if hit is None or hit[0] != (_WEIGHT_EPOCH, weight._version):

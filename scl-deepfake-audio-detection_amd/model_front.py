@@ -113,9 +113,8 @@ class FrontHeadModel(nn.Module):
         self.out_dim = self.cfg.embed
         self.grad_sync = None
         # Optional (SCL_HEAD_GRAPH=1): replay the back-end's training forward / backward as two captured hipGraphs per feature
-        # shape: AASIST 48.7 -> 44.3 ms/step at batch 32 (the back-end is ~890 small launches).  Off by default: capturing MIOpen
-        # convolutions is not robust on ROCm 7.2 — the ResNet back-end's capture segfaults inside hipStreamEndCapture, which no
-        # Python-level fallback can catch.
+        # shape.  Both HIP back-ends capture and replay correctly (tests/test_aasist_gpu.py), but the step is kernel-bound: AASIST
+        # 45.9 -> 45.5 ms/step at batch 32, ResNet +-0.  Off by default.
         self.use_graphs = os.environ.get("SCL_HEAD_GRAPH", "0") == "1"
         self.__dict__["_graphed"] = {}
         self.pretrained_loaded = maybe_load_pretrained(self, args)

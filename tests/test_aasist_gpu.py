@@ -164,8 +164,6 @@ def test_dropout_active_in_train_mode(dev):
     assert not torch.equal(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("SCL_TEST_HEAD_GRAPH", "0") != "1",
-                    reason="opt-in: hipGraph capture of library convolutions can crash the process on ROCm 7.2 (see model_front.py)")
 def test_backend_as_hip_graphs_equals_eager(dev):
     """In training the back-end is replayed as captured forward / backward hipGraphs: same outputs, same gradients, same
     BatchNorm running statistics as the eager launch sequence (dropout p = 0 on both sides; capture warm-up must leave no trace)."""
@@ -200,6 +198,26 @@ def test_backend_as_hip_graphs_equals_eager(dev):
     assert all(np.isfinite(e).all() for e in errs)
     assert rl2(gbn, ebn) < 5e-2
     assert (gp - ep).abs().max().item() <= 2.2e-4 * 3
+
+
+def test_graph_replay_reads_the_live_weights(dev):
+    """The captured back-end must not freeze anything derived from the weights (re-laid-out convolution filters are cached between
+    optimizer steps in eager mode): after the weights move, replay == eager on the new weights."""
+    m, _, _ = make(dev, 83)
+    m.use_graphs = True
+    m.train()
+    x = (0.1 * torch.randn(6, 20000, generator=torch.Generator().manual_seed(5))).to(dev)
+    out0 = m(x)[0].detach().clone()                      # captures
+    assert m._graphed and all(v is not False for v in m._graphed.values())
+    with torch.no_grad():
+        m.P.flat[m._head_lo: m.P.n_train].mul_(1.25)     # every back-end weight, in place, as the fused optimizer does
+    m.optimizer_stepped(False)
+    out_g = m(x)[0].detach().clone()                     # replay
+    m.use_graphs = False
+    out_e = m(x)[0].detach().clone()
+    torch.cuda.synchronize()
+    assert rl2(out_g, out_e) < 2e-3, (rl2(out_g, out_e), rl2(out_g, out0))
+    assert rl2(out_e, out0) > 1e-2                       # the weights did move the output
 
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "aasist.npz"))

@@ -3,8 +3,9 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r2}
 STEPS=4; WARM=1
+shift; EXTRA="$@"      # e.g. tools/prof_bench.sh aasist --model wav2vec2_aasist --batch 32 --rawboost 0
 rm -rf gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o bench -- python3 bench.py --no-cpu-baseline --steps $STEPS --warmup $WARM > gpurun_out/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o bench -- python3 bench.py --no-cpu-baseline --steps $STEPS --warmup $WARM $EXTRA > gpurun_out/prof_${TAG}_bench.log 2>&1
 python3 - $TAG $STEPS $WARM <<'PY'
 import csv,glob,sys,collections
 tag,steps,warm=sys.argv[1],int(sys.argv[2]),int(sys.argv[3])
@@ -15,7 +16,7 @@ tot=sum(float(r['TotalDurationNs']) for r in rows)
 out=open('gpurun_out/prof_%s_summary.txt'%tag,'w')
 def P(*a):
     s=" ".join(str(x) for x in a); print(s); out.write(s+"\n")
-for r in rows[:28]:
+for r in rows[:int(__import__('os').environ.get('PROF_TOP','28'))]:
     P("%-90s %6s %9.1f us %8.3f ms/step %5.1f%%"%(r['Name'][:90], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6/n, 100*float(r['TotalDurationNs'])/tot))
 P("total kernel time per step ms", tot/1e6/n)
 t=glob.glob('gpurun_out/prof_%s/**/*kernel_trace.csv'%tag,recursive=True)
@@ -31,4 +32,4 @@ for k,(c,d) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:40]:
     P("%-62s gx=%-8s gz=%-4s %6.1f %9.1f us %8.3f ms/step"%(k[0],k[1],k[2],c/n,d/c/1e3,d/1e6/n))
 PY
 tail -1 gpurun_out/prof_${TAG}_bench.log | cut -c1-600
-cp $(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/prof_${TAG}_kernel_stats.csv
+cp $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/prof_${TAG}_kernel_stats.csv
