@@ -306,6 +306,26 @@ int scl_i16_gain_overlay(const void* speech_i16, int64_t n, const void* noise_i1
 int scl_multiview_crop_f32(const float* src, const int64_t* off, const int* len, int V, int firstlen, int start, int out_len,
                            int repeat_pad, float* out, int64_t ldo, void* stream);
 
+/* ---- conf-5 augmenters (csrc/speedpitch.hip) ----------------------------------------------------------------------------------
+ * speed: datautils/audio_augmentor/speed.py:29-33 -> pydub 0.25.1 AudioSegment.speedup(speed_factor).  scl_i16_append_xfade is
+ * AudioSegment.append(chunk, crossfade) applied in place to the running 16-bit output `out` (n1 frames, capacity >= n1 + tail_n):
+ *   j < R:  out[a0 + j] = sat( floor(clip(out[a0 + j] * g1(j))) + floor(clip(chunk[j % m2] * g2(j % m2))) )      (audioop.mul / add)
+ *   t < tail_n:  out[n1 + t] = chunk[tail_off + t]
+ * g(i) = from + step * (per_ms ? i / frames_per_ms : i) in fp64, evaluated as CPython does (multiply, then add).  Positive
+ * crossfades mix the last R frames with the chunk's first R; pydub's negative crossfades (speed factor < 1) fade the whole output
+ * after its first |c| ms under a looped fade-in of the chunk (m2 < R).  The caller walks the chunk list (scl_amd/augment.py).
+ * pitch: datautils/audio_augmentor/pitch.py:31-38 -> librosa 0.10.0 effects.pitch_shift = stft (2048 / 512, periodic Hann, centred,
+ * zero padding; D is [frames][1025] complex64) -> phase_vocoder(rate) -> istft(length) -> resample(ratio = rate) -> fix_length.
+ * scl_resample_sinc_f32 stands where librosa calls soxr_hq: Kaiser-windowed sinc, 32 zero crossings, beta 14.77, cut-off
+ * 0.95 x the lower Nyquist, n_out = ceil(n_in * ratio) chosen by the caller.  frames_ws: [nframes][2048] f32 scratch. */
+int scl_i16_append_xfade(void* out_i16, int n1, const void* chunk_i16, int n2, int a0, int R, int per_ms1, double from1, double step1,
+                         int m2, int per_ms2, double from2, double step2, int tail_off, int tail_n, int frames_per_ms, void* stream);
+int scl_stft_nframes(int L);
+int scl_stft_f32(const float* y, int L, void* D_c64, int nframes, void* stream);
+int scl_phase_vocoder_c64(const void* D_c64, int nframes, double rate, void* out_c64, int nsteps, void* stream);
+int scl_istft_f32(const void* D_c64, int nframes, float* frames_ws, float* y, int length, void* stream);
+int scl_resample_sinc_f32(const float* x, int n_in, double ratio, float* out, int n_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

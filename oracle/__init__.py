@@ -11,5 +11,8 @@ Pinning: the restatements are checked against vectors produced by the reference'
   * wav2vec2 / XLS-R forward (fairseq @ a5402130 is not installed): cross-checked against
     `transformers.Wav2Vec2Model` with copied weights instead — "parity unpinned" w.r.t. fairseq;
   * pydub 0.25.1 / audioop integer semantics (MUSAN overlay, int16 conversions): restated from the
-    published semantics — "parity unpinned".
+    published semantics — "parity unpinned";
+  * pydub AudioSegment.speedup and librosa 0.10.0 effects.pitch_shift (conf-5's speed / pitch augmenters,
+    oracle/audio_speed_pitch.py): restated from the packages' published algorithms, checked against hand-derived
+    known answers only — "parity unpinned"; soxr's resampling filter is replaced by a Kaiser-windowed sinc.
 """

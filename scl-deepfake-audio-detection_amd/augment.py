@@ -317,6 +317,109 @@ def background_noise(x, noise_i16, snr_db):
     return out
 
 
+def _fade_params(from_gain_db, to_gain_db, duration_ms, sr):
+    """pydub AudioSegment.fade's gain ramp: (one step per millisecond?, from_power, scale_step) — fades longer than 100 ms step once
+    per millisecond, shorter ones once per frame.  Python float arithmetic, as pydub evaluates it."""
+    from_power = 10 ** (float(from_gain_db) / 20)
+    gain_delta = 10 ** (float(to_gain_db) / 20) - from_power
+    if duration_ms > 100:
+        return 1, from_power, gain_delta / duration_ms
+    return 0, from_power, gain_delta / (duration_ms * (sr / 1000.0))          # frame_count(ms=end) - frame_count(ms=0)
+
+
+def speed(x, speed_factor, sr=16000, chunk_size=150, crossfade=25):
+    """SpeedAugmentor.transform (speed.py:29-33) = pydub 0.25.1 AudioSegment.speedup(speed_factor) on the clip's int16 image
+    (librosa_to_pydub, utils.py:24-30); returns the int16 VALUES as fp32 (pydub_to_librosa).  The chunk list and pydub's
+    millisecond bookkeeping are walked here; every AudioSegment.append is one in-place kernel over the running output
+    (scl_i16_append_xfade).  For speed_factor < 1 pydub's crossfade comes out negative and the output is a few hundred
+    milliseconds long (see include/scl_hip.h) — the reference's behaviour, kept."""
+    if sr % 1000:
+        raise ValueError("speed: sample rates that are not whole frames per millisecond are not supported (got %d)" % sr)
+    F = sr // 1000
+    src = to_int16(x)
+    N = int(src.numel())
+    len_ms = round(1000 * (float(N) / sr))                                # AudioSegment.__len__
+    atk = 1.0 / speed_factor
+    if speed_factor < 2.0:
+        remove = int(chunk_size * (1 - atk) / atk)
+    else:
+        remove = int(chunk_size)
+        chunk_size = int(atk * chunk_size / (1 - atk))
+    crossfade = min(crossfade, remove - 1)
+    step = chunk_size + remove
+    if step <= 0:
+        raise ValueError("speed: chunk length %d ms" % step)
+    nchunks = int(math.ceil(len_ms / float(step)))
+    if nchunks < 2:
+        raise ValueError("Could not speed up AudioSegment, it was too short %.2fs for %d ms chunks at %.2fx" % (N / sr, chunk_size, speed_factor))
+    remove -= crossfade
+    if not 0 < remove < step:
+        raise ValueError("speed: cannot drop %d ms of a %d ms chunk" % (remove, step))
+    Lc = F * (step - remove)                                              # frames of every chunk but the last
+    s_last = F * (nchunks - 1) * step
+    e_last = F * min(nchunks * step, len_ms)
+    have_last = max(0, min(e_last, N) - s_last)
+    c = abs(crossfade)
+    cap = Lc + (nchunks - 2) * (Lc if crossfade >= 0 else F * c) + (e_last - s_last) + 64
+    out = torch.zeros(cap, dtype=torch.int16, device=x.device)           # zeros: pydub pads a short last slice with silence
+    none = (0, 1.0, 0.0)
+    ops.i16_append_xfade(out, 0, src, Lc, 0, 0, none, 0, none, 0, Lc, F)                     # out = chunks[0]
+    n = Lc
+    for i in range(1, nchunks - 1):
+        chunk = src[F * i * step:]
+        if crossfade == 0:
+            ops.i16_append_xfade(out, n, chunk, Lc, 0, 0, none, 0, none, 0, Lc, F)
+            n += Lc
+            continue
+        if crossfade > n // F or crossfade > Lc // F:
+            raise ValueError("speed: crossfade %d ms is longer than the segment" % crossfade)
+        if crossfade > 0:
+            R = m2 = F * crossfade
+            a0, tail_off, tail_n = n - R, R, Lc - R
+        else:                                                             # seg1[c:] faded out under looped seg2[:-c]; then seg2[-c:]
+            a0, R, m2 = F * c, n - F * c, Lc - F * c
+            tail_off, tail_n = Lc - F * c, F * c
+            if R <= 0 or m2 <= 0:
+                raise ValueError("speed: empty cross-fade (pydub divides by zero / never returns here)")
+        ops.i16_append_xfade(out, n, chunk, Lc, a0, R, _fade_params(0, -120, R // F, sr), m2, _fade_params(-120, 0, m2 // F, sr), tail_off, tail_n, F)
+        n += tail_n
+    if have_last:
+        ops.i16_append_xfade(out, n, src[s_last:], have_last, 0, 0, none, 0, none, 0, have_last, F)     # out += last_chunk
+    n += e_last - s_last                                                  # frames missing from the last slice stay silent
+    return out[:n].to(torch.float32)
+
+
+def pitch_shift(x, n_steps, sr=16000):
+    """PitchAugmentor.transform (pitch.py:31-38) = librosa 0.10.0 effects.pitch_shift(data, sr, n_steps) followed by the int16
+    round trip (librosa_to_pydub, pydub_to_librosa): stft -> phase vocoder (rate 2^(-n/12)) -> istft -> resample by `rate` ->
+    fix_length; returns the int16 VALUES as fp32.  The resampler is a Kaiser-windowed sinc where librosa calls soxr_hq."""
+    dev = x.device
+    x = x.contiguous().float()
+    L = int(x.numel())
+    rate = 2.0 ** (-float(n_steps) / 12)
+    nfr = ops.stft_nframes(L)
+    D = torch.empty(nfr * 1025 * 2, device=dev)
+    ops.stft(x, L, D, nfr)
+    nsteps = int(math.ceil(nfr / rate))                                   # len(np.arange(0, nfr, rate))
+    Ds = torch.empty(nsteps * 1025 * 2, device=dev)
+    ops.phase_vocoder(D, nfr, rate, Ds, nsteps)
+    len_stretch = int(round(L / rate))
+    nuse = min(nsteps, int(math.ceil((len_stretch + 2048) / 512)))
+    ws = torch.empty(nuse * 2048, device=dev)
+    ys = torch.empty(len_stretch, device=dev)
+    ops.istft(Ds, nuse, ws, ys, len_stretch)
+    if rate != 1.0:                                                       # librosa.resample returns its input when the rates agree
+        n_out = int(math.ceil(len_stretch * rate))
+        yr = torch.empty(n_out, device=dev)
+        ops.resample_sinc(ys, len_stretch, rate, yr, n_out)
+    else:
+        yr = ys
+    fixed = torch.zeros(L, device=dev)
+    m = min(L, int(yr.numel()))
+    fixed[:m] = yr[:m]
+    return to_int16(fixed).to(torch.float32)
+
+
 def multiview_crop(views, length, repeat_pad, random_trim=True):
     """batch_pad_for_multiview (wav_augmentation.py:209-282) for a list of 1-D device tensors;
     returns [V, out_len].  Draws one np.random.rand() under the reference's condition."""

@@ -397,6 +397,32 @@ def multiview_crop(src, off, lens, V, firstlen, start, out_len, repeat_pad, out,
                                             _p(out), ldo, _stream())
 
 
+def i16_append_xfade(out_i16, n1, chunk_i16, n2, a0, R, fade1, m2, fade2, tail_off, tail_n, frames_per_ms):
+    """fade = (per_ms, from_power, scale_step).  `chunk_i16` may be a view into the source clip."""
+    _call("scl_i16_append_xfade", _p(out_i16), n1, _p(chunk_i16), n2, a0, R, int(fade1[0]), float(fade1[1]), float(fade1[2]), m2,
+          int(fade2[0]), float(fade2[1]), float(fade2[2]), tail_off, tail_n, frames_per_ms, _stream())
+
+
+def stft_nframes(n):
+    return L.load().scl_stft_nframes(n)
+
+
+def stft(y, n, D, nframes):
+    _call("scl_stft_f32", _p(y), n, _p(D), nframes, _stream())
+
+
+def phase_vocoder(D, nframes, rate, out, nsteps):
+    _call("scl_phase_vocoder_c64", _p(D), nframes, float(rate), _p(out), nsteps, _stream())
+
+
+def istft(D, nframes, frames_ws, y, length):
+    _call("scl_istft_f32", _p(D), nframes, _p(frames_ws), _p(y), length, _stream())
+
+
+def resample_sinc(x, n_in, ratio, out, n_out):
+    _call("scl_resample_sinc_f32", _p(x), n_in, float(ratio), _p(out), n_out, _stream())
+
+
 def gat_score_nblocks(N):
     return L.load().scl_gat_score_nblocks(N)
 

@@ -173,18 +173,29 @@ def _reverb_online(x, args, sr):
     return augment.reverb(_to_dev(x, args), bank_tensor(rir_file, sr, args, "f32"))
 
 
-UNSUPPORTED_AUGMENTERS = {
-    "speed_wrapper": "pydub AudioSegment.speedup (chunk-drop + cross-fade in audioop integer arithmetic, audio_augmentor/speed.py:29-33)",
-    "pitch_wrapper": "librosa.effects.pitch_shift (phase vocoder + resampling, audio_augmentor/pitch.py:31-38)",
-}
+UNSUPPORTED_AUGMENTERS = {}      # name -> what it needs; every augmenter the reference's configs name runs (checked at start-up)
 
 
 def speed_wrapper(x, args, sr=16000, audio_path=None):
-    raise NotImplementedError("speed_wrapper: " + UNSUPPORTED_AUGMENTERS["speed_wrapper"] + " has no HIP implementation yet (SURVEY.md 8f rank 4)")
+    """pydub speed change, augall_5:342-361 -> audio_augmentor/speed.py:9-33: factor ~ random.uniform(0.9, 1.1) (augall_5:246-247)."""
+    if not getattr(args, "online_aug", True) and getattr(args, "aug_dir", None) and audio_path:
+        return _offline_cached("speed", x, args, sr, audio_path, lambda: _speed_online(x, args, sr), int16_values=True)
+    return _speed_online(x, args, sr)
+
+
+def _speed_online(x, args, sr):
+    return augment.speed(_to_dev(x, args), random.uniform(0.9, 1.1), sr)
 
 
 def pitch_wrapper(x, args, sr=16000, audio_path=None):
-    raise NotImplementedError("pitch_wrapper: " + UNSUPPORTED_AUGMENTERS["pitch_wrapper"] + " has no HIP implementation yet (SURVEY.md 8f rank 4)")
+    """Phase-vocoder pitch shift, augall_5:300-319 -> audio_augmentor/pitch.py:11-38: n_steps = random.randint(-1, 1) (augall_5:207-208)."""
+    if not getattr(args, "online_aug", True) and getattr(args, "aug_dir", None) and audio_path:
+        return _offline_cached("pitch", x, args, sr, audio_path, lambda: _pitch_online(x, args, sr), int16_values=True)
+    return _pitch_online(x, args, sr)
+
+
+def _pitch_online(x, args, sr):
+    return augment.pitch_shift(_to_dev(x, args), random.randint(-1, 1), sr)
 
 
 def _offline_cached(method, x, args, sr, audio_path, make, int16_values=False):

@@ -97,3 +97,97 @@ def test_multiview_crop_matches_reference_goldens(dev):
             for i in range(n):
                 ref = g["%s_rp%d_out%d" % (name, int(rp), i)][:, 0].astype(np.float32)
                 assert out[i].shape == ref.shape and np.array_equal(out[i], ref), (name, rp, i)
+
+
+# ---- conf-5 augmenters: speed (pydub speedup) and pitch (librosa pitch_shift) ---------------------------------------------------------
+from oracle import audio_speed_pitch as SP  # noqa: E402
+
+
+@pytest.mark.parametrize("n", [64000, 70001, 66010, 9000])
+def test_speed_is_bit_exact_against_the_pydub_restatement(dev, n):
+    """Every regime of AudioSegment.speedup the reference's U(0.9, 1.1) draw reaches: negative crossfades (factor < 1 and the first
+    0.66 % above 1), the plain-concatenation case (ms_to_remove 1), positive crossfades of 1..14 ms; clip lengths that are whole
+    milliseconds, that round down (trailing frames dropped) and up (silence-padded last slice).  Integer work: bit-exact."""
+    rs = np.random.RandomState(n)
+    x = (0.25 * rs.randn(n)).astype(np.float32)
+    x[100:140] = 1.5                                    # int16 wrap-around in the conversion, saturation in the overlays
+    for f in (0.9, 0.931, 0.97, 0.999, 1.0, 1.004, 1.0067, 1.01, 1.02, 1.05, 1.0999, 1.1):
+        ref = SP.speed(x, f)
+        got = AUG.speed(torch.from_numpy(x).to(dev), f).cpu().numpy()
+        assert got.dtype == np.float32 and got.shape == ref.shape, (f, got.shape, ref.shape)
+        assert np.array_equal(got.astype(np.int32), ref.astype(np.int32)), (f, np.abs(got - ref).max())
+
+
+def test_speed_raises_like_pydub_on_clips_shorter_than_two_chunks(dev):
+    x = torch.zeros(2000, device=dev)
+    with pytest.raises(ValueError):
+        AUG.speed(x, 1.05)
+    with pytest.raises(ValueError):
+        SP.speed(np.zeros(2000, np.float32), 1.05)
+
+
+def test_stft_phase_vocoder_istft_match_the_librosa_restatement(dev):
+    """The three stages one by one against oracle/audio_speed_pitch.py (fp32 FFT vs numpy's fp64: 2e-6 of the spectrum's scale)."""
+    from scl_amd import ops
+    rs = np.random.RandomState(3)
+    L = 16000
+    y = (0.1 * rs.randn(L)).astype(np.float32)
+    yd = torch.from_numpy(y).to(dev)
+    nfr = ops.stft_nframes(L)
+    assert nfr == 1 + L // 512
+    D = torch.empty(nfr * 1025 * 2, device=dev)
+    ops.stft(yd, L, D, nfr)
+    Dg = torch.view_as_complex(D.view(nfr, 1025, 2)).cpu().numpy().T
+    Dr = SP.stft(y)
+    assert Dg.shape == Dr.shape
+    assert np.abs(Dg - Dr).max() < 2e-6 * np.abs(Dr).max() * 10
+    for rate in (2.0 ** (1 / 12), 2.0 ** (-1 / 12), 1.0):
+        nsteps = len(np.arange(0, nfr, rate))
+        Dref = SP.phase_vocoder(Dr, rate)
+        Din = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(Dr.T)).to(dev)).contiguous()
+        Ds = torch.empty(nsteps * 1025 * 2, device=dev)
+        ops.phase_vocoder(Din, nfr, rate, Ds, nsteps)
+        Dsg = torch.view_as_complex(Ds.view(nsteps, 1025, 2)).cpu().numpy().T
+        assert Dsg.shape == Dref.shape
+        # float32 phase accumulators: a last-bit difference in an arctangent can move a phase by one float32 step of a value ~1e5
+        rel = np.linalg.norm(Dsg - Dref) / np.linalg.norm(Dref)
+        assert rel < 5e-3, (rate, rel)
+        assert np.abs(np.abs(Dsg) - np.abs(Dref)).max() < 1e-4 * np.abs(Dref).max()
+        length = int(round(L / rate))
+        nuse = min(nsteps, int(np.ceil((length + 2048) / 512)))
+        ws = torch.empty(nuse * 2048, device=dev)
+        out = torch.empty(length, device=dev)
+        Dd = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(Dref.T)).to(dev)).contiguous()
+        ops.istft(Dd, nuse, ws, out, length)
+        ref = SP.istft(Dref, length)
+        assert np.abs(out.cpu().numpy() - ref).max() < 2e-6, rate
+
+
+def test_sinc_resampler_matches_its_restatement(dev):
+    from scl_amd import ops
+    rs = np.random.RandomState(4)
+    x = (0.1 * rs.randn(6000)).astype(np.float32)
+    for ratio in (2.0 ** (1 / 12), 2.0 ** (-1 / 12)):
+        n_out = int(np.ceil(len(x) * ratio))
+        out = torch.empty(n_out, device=dev)
+        ops.resample_sinc(torch.from_numpy(x).to(dev), len(x), ratio, out, n_out)
+        ref = SP.resample_sinc(x, ratio)
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-6
+
+
+def test_pitch_matches_the_librosa_restatement(dev):
+    """End to end, int16 values out.  n_steps = 0 still goes through the phase vocoder (librosa does) and is NOT the identity."""
+    t = np.arange(16000) / 16000.0
+    rs = np.random.RandomState(5)
+    x = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 1230 * t + 1.0) + 0.01 * rs.randn(16000)).astype(np.float32)
+    for n in (-1, 0, 1):
+        ref = SP.pitch(x, n).astype(np.float64)
+        got = AUG.pitch_shift(torch.from_numpy(x).to(dev), n).cpu().numpy().astype(np.float64)
+        assert got.shape == ref.shape == (16000,)
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        print("pitch n_steps %+d: rel-L2 %.2e, max |diff| %.0f LSB, |diff| > 1 LSB on %.3f %%" % (n, rel, np.abs(got - ref).max(), 100 * (np.abs(got - ref) > 1).mean()))
+        assert rel < 2e-4 and np.abs(got - ref).max() <= 2
+        # and the pitch did move: the 440 Hz partial sits at 440 * 2^(n/12)
+        spec = np.abs(np.fft.rfft(got[2048:-2048] * np.hanning(len(got) - 4096)))
+        peak = np.argmax(spec[: int(800 * (len(got) - 4096) / 16000)]) * 16000.0 / (len(got) - 4096)
+        assert abs(peak - 440 * 2 ** (n / 12)) < 3.0, (n, peak)
