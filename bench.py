@@ -86,9 +86,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if rank != 0:
+        os.dup2(2, 1)       # only rank 0 owns stdout (library banners of the other ranks must not trail the JSON line)
+    # SCL_BENCH_FORCE_DP=1: initialise the backend and run the gradient exchange even with one rank (a one-rank RCCL all-reduce is the
+    # identity): the whole choreography — communication stream, events, async work handles — against the real library on a 1-GPU box
+    dp = world > 1 or os.environ.get("SCL_BENCH_FORCE_DP") == "1"
+    if dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # "nccl" is RCCL on ROCm.  SCL_BENCH_BACKEND=gloo + SCL_BENCH_ONE_DEVICE=1 rehearse the N > 1 code path on a one-GPU box
         dist.init_process_group(os.environ.get("SCL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -115,7 +121,7 @@ def main():
     model = Model(margs, dev, w2v_cfg=cfg, seed=0)          # same seed on every rank = replicated weights
     model.train()                                            # dropout on, as train_epoch does (main.py:48)
     g_lo, g_hi = model.trainable_range()
-    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, wire=os.environ.get("SCL_DP_WIRE", "fp32")) if world > 1 else None
+    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, wire=os.environ.get("SCL_DP_WIRE", "fp32"), force=True) if dp else None
     model.grad_sync = sync
     opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4, grad_sync=sync)   # main.py:339 defaults (max_lr, weight_decay)
 
@@ -143,7 +149,7 @@ def main():
         return total
 
     def fence():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -168,11 +174,12 @@ def main():
     # seeded random init, labels 5:6: CE/bz + 2 x SupCon/bz is a few tenths; the resnet plugin's loss has no 1/bz (x batch)
     hi = 2.0 * (B if args.model == "wav2vec2_resnet_nll" else 1.0)
     assert loss_val == loss_val and 0.0 < loss_val < hi, "final loss %r outside the band of a seeded-random-init step" % loss_val
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
+        torch.distributed.destroy_process_group()
         return
     utt_s = world * B * args.steps / dt
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
@@ -222,7 +229,14 @@ def main():
                            grad_bytes_per_step=(g_hi - g_lo) * (2 if sync.wire == "bf16" else 4))
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(res))
+    if dp:
+        torch.distributed.destroy_process_group()
+    # RCCL writes a version banner to the C stdout, which is flushed at exit — i.e. AFTER a Python print.  The JSON line must be the
+    # last thing on stdout: tear the backend down, flush the C stream, then print.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -40,13 +40,15 @@ class GradSync:
     fp32 wire stays the default).  Per-bucket timing (`report()`): when the bucket's all-reduce was issued and how long the
     optimizer had to wait for it at the end — the exposed part a scaling run needs to see."""
 
-    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0, wire="fp32"):
+    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0, wire="fp32", force=False):
         """flat_grad: the slice of the flat gradient buffer that receives gradients (model.trainable_range()); `base` = its first
-        element's offset in the whole buffer (ready_above() is called with whole-buffer offsets)."""
+        element's offset in the whole buffer (ready_above() is called with whole-buffer offsets).  `force`: run the collectives
+        even in a one-rank group (a single-GPU box can then rehearse the whole RCCL choreography: tests/test_dp_gpu.py)."""
         self.grad = flat_grad
         self.base = int(base)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.wire = wire
         assert wire in ("fp32", "bf16")
         n = flat_grad.numel()
@@ -59,7 +61,7 @@ class GradSync:
         self.launched = 0
         self.works = []
         self.on_gpu = flat_grad.is_cuda
-        self.comm = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
+        self.comm = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
         self.stage = torch.empty(min(bucket_elems, n), dtype=torch.bfloat16, device=flat_grad.device) if wire == "bf16" else None
         self.final_check = None              # tests: callable(lo, hi) run right before a bucket is handed to the collective
         self._t_issue, self._ev_done, self._exposed_ms = [], [], 0.0
@@ -80,7 +82,7 @@ class GradSync:
 
     def ready_above(self, lo_offset):
         """All gradient elements at offsets >= lo_offset are final: launch every bucket above it."""
-        if self.world == 1:
+        if not self.active:
             return
         lo_offset = max(0, lo_offset - self.base)
         while self.launched < len(self.bounds) and self.bounds[self.launched][0] >= lo_offset:
@@ -112,7 +114,7 @@ class GradSync:
 
     def finish(self):
         """Launch what is left, wait for everything, return the 1/world scale the optimizer applies."""
-        if self.world == 1:
+        if not self.active:
             return 1.0
         self.ready_above(0)
         t0 = time.perf_counter()
