@@ -35,6 +35,12 @@ extern "C" {
 int         scl_version(void);
 const char* scl_last_error(void);
 
+/* Stream ordering: work submitted to `waiter` after this call starts only when everything submitted to `signaler` before it has
+ * completed (one event record + one stream wait, events from an internal ring).  The encoder backward uses it to run the weight-
+ * gradient GEMMs and bias-gradient column sums on a second stream beside the data-gradient chain (autograd's engine does the same
+ * for independent branches of main.py:79's loss.backward() only when the user asks for streams; here it is explicit). */
+int scl_stream_wait_stream(void* waiter, void* signaler);
+
 /* Per-kernel HIP-event profiling used by bench.py's roofline leg: when enabled, every launch of
  * the kernel family `kid` (SCL_KID_*) is bracketed by two hipEvents on the launch stream.
  * scl_prof_read synchronises those events and returns launch count and summed milliseconds. */

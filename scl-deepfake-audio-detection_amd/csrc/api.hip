@@ -82,3 +82,27 @@ extern "C" int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, dou
     st.flops = 0.0;
     return SCL_OK;
 }
+
+
+// ---- stream ordering ---------------------------------------------------------------------------------------------------------------
+// "work submitted to `waiter` from now on starts after everything submitted to `signaler` so far": one event record + one stream
+// wait.  Events come from a ring (a wait captures the record that precedes it, so a slot may be re-recorded once its wait has been
+// issued).  Used by the encoder backward to run the weight-gradient GEMMs on a second stream (scl_amd/encoder.py).
+#include <mutex>
+extern "C" int scl_stream_wait_stream(void* waiter, void* signaler) {
+    static hipEvent_t ring[256];
+    static int created = 0, next = 0;
+    static std::mutex mu;
+    SCL_REQUIRE(waiter != signaler, "stream_wait_stream: a stream cannot wait for itself");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!created) {
+        for (int i = 0; i < 256; ++i)
+            if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) return SCL_ELAUNCH;
+        created = 1;
+    }
+    hipEvent_t e = ring[next];
+    next = (next + 1) & 255;
+    if (hipEventRecord(e, (hipStream_t)signaler) != hipSuccess) return SCL_ELAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess) return SCL_ELAUNCH;
+    return SCL_OK;
+}

@@ -59,6 +59,11 @@ def host_callback(fn, *args):
         rec.append((_cb, list(args), getattr(fn, "__name__", "callback"), None))
 
 
+def stream_wait(waiter, signaler):
+    """`waiter` (torch stream) does not start later work before `signaler`'s work so far is done; recorded into launch plans."""
+    _call("scl_stream_wait_stream", ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaler.cuda_stream))
+
+
 def _call(name, *args, keep=None):
     fn = getattr(L.load(), name)
     rc = fn(*args)
