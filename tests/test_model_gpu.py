@@ -192,6 +192,26 @@ def test_backward_is_bitwise_reproducible(dev):
         assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
 
 
+def test_second_stream_weight_gradients_equal_the_single_stream_backward(dev, monkeypatch):
+    """SCL_WGRAD_STREAM=1 moves the weight / bias gradients of the 24-layer loop to a second stream (event-ordered, three rotating
+    residual-gradient buffers): same bits as the one-stream backward, on the recorded step and on its replays."""
+    cfg = W.W2VConfig.tiny()
+    x = (0.1 * torch.randn(5, 9000, generator=torch.Generator().manual_seed(7))).to(dev)
+    y = torch.tensor([1, 1, 0, 0, 0], device=dev)
+    grads = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCL_WGRAD_STREAM", flag)
+        m = build(dev, W.init_state(cfg, seed=83), OH.init_head(cfg.embed, seed=84))
+        m.eval()
+        assert (m.encoder.wstream is not None) == (flag == "1")
+        for _ in range(3):
+            out, feats, emb = m(x)
+            sum(m.loss(out, feats, emb, y, CONF).values()).backward()
+        torch.cuda.synchronize()
+        grads[flag] = m.P.grad.clone()
+    assert torch.equal(grads["0"], grads["1"])
+
+
 def test_forward_matches_oracle_on_fresh_input_and_eval_scores(dev):
     cfg = W.W2VConfig.tiny()
     ssl = W.init_state(cfg, seed=21)
