@@ -225,7 +225,7 @@ def main():
     if sync is not None:
         # self-diagnosing multi-GPU line: ranks, buckets, when each all-reduce was issued relative to the end of the backward and
         # how long the optimizer waited for the last one (the exposed part of the exchange)
-        res["rccl"] = dict(sync.report() or {}, rccl_ranks=world, backend=torch.distributed.get_backend(),
+        res["rccl"] = dict(sync.report() or {}, rccl_ranks=world, backend=torch.distributed.get_backend(), gemm_cus=os.environ.get("SCL_GEMM_CUS", "256"),
                            grad_bytes_per_step=(g_hi - g_lo) * (2 if sync.wire == "bf16" else 4))
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)

@@ -694,7 +694,10 @@ bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long l
     if (d.flags & (SCL_GEMM_NO_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG | SCL_GEMM_NO_DMA)) return false;
     const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
     const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
-    if (!a_whole || !b_whole || !scl_gemm_w8_plan(k, at, bt, d, zdim, 256, plan)) return false;
+    // CUs the tile plan may count on: all 256, unless the caller says a communication library's persistent kernels hold some of
+    // them during the backward (data parallel over RCCL): a 248-block grid on 240 free CUs would take two rounds
+    static const int ncu_env = [] { const char* e = getenv("SCL_GEMM_CUS"); const int v = e ? atoi(e) : 256; return v >= 32 && v <= 256 ? v : 256; }();
+    if (!a_whole || !b_whole || !scl_gemm_w8_plan(k, at, bt, d, zdim, ncu_env, plan)) return false;
     return (d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan->tiles * zdim >= 128);
 }
 
