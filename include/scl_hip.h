@@ -128,6 +128,12 @@ int scl_gemm_uses_wide_tiles(const SclGemmDesc* desc);
  * clock} at kernel entry, after the prologue, after the K loop, after the epilogue (blocks 0 .. nblocks-1, nblocks <= 4096). */
 int scl_debug_gemm_stamps(unsigned long long* out, int nblocks);
 
+/* Split-K with the epilogue kept: run `desc` as a plain split-K GEMM into f32 slabs ([nslabs][M][N], slab stride `stride` elements:
+ * same A / B, C = slabs, ldc = N, splitk = nslabs, no epilogue flags, alpha as in desc), then this pass stores
+ * desc.C (and C2) = epilogue(sum_s slab_s) exactly as scl_gemm_bf16(desc) would have (alpha already applied by the partial GEMMs).
+ * For un-batched problems (nb1 = nb2 = 1) with few output tiles and a long K — the N = 1024 linears of a pack-sized train step. */
+int scl_gemm_splitk_finish(const SclGemmDesc* desc, const float* slabs, int nslabs, int64_t stride, void* stream);
+
 /* out[i] = sum_s slabs[s*stride + i]  (deterministic split-K combine). */
 int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream);
 

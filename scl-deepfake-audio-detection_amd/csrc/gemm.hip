@@ -698,7 +698,10 @@ bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long l
     // them during the backward (data parallel over RCCL): a 248-block grid on 240 free CUs would take two rounds
     static const int ncu_env = [] { const char* e = getenv("SCL_GEMM_CUS"); const int v = e ? atoi(e) : 256; return v >= 32 && v <= 256 ? v : 256; }();
     if (!a_whole || !b_whole || !scl_gemm_w8_plan(k, at, bt, d, zdim, ncu_env, plan)) return false;
-    return (d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan->tiles * zdim >= 128);
+    // row-major A with 128-159 wide tiles (qkv forward of a pack-sized step: 11 x 12 tiles): the 432 tiles of the 128x128 kernel win
+    // 24.4 vs 31.8 us; from 176 wide tiles on (fc1 forward, 11 x 16) the wide kernel does (32.5 vs 38.9) — tools/splitk_probe.py
+    const long long need = at ? 128 : 160;
+    return (d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan->tiles * zdim >= need);
 }
 
 }  // namespace
@@ -822,6 +825,93 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
 extern "C" int scl_debug_gemm_stamps(unsigned long long* out, int nblocks) {
     SCL_REQUIRE(out && nblocks > 0 && nblocks <= 4096, "gemm stamps: bad args");
     return scl_gemm_read_stamps(out, nblocks);
+}
+
+// ---- split-K finish: C = epilogue(sum of the f32 slabs) ------------------------------------------------------------------------------
+// A GEMM with few output tiles and a long reduction (the N = 1024 linears of a pack-sized step, M = 11 x 199 rows, K = 3072 / 4096:
+// 144 tiles of 128x128, one 4-wave block on 144 of the 256 CUs walking 48-64 K steps at HBM latency) runs faster as `nslabs` partial
+// GEMMs into f32 slabs followed by this pass, which applies the ORIGINAL descriptor's epilogue (bias, second output, activation,
+// residual / activation-gradient, dropout, bf16 or f32 store) to the sum — the same arithmetic, in the same order, as the in-kernel
+// epilogue applies to its accumulator.  One thread per 4 columns of a row.
+__global__ __launch_bounds__(256) void scl_gemm_finish_kernel(const GemmK d, const float* __restrict__ slabs, int nslabs, long long stride) {
+    const int ncg = (d.N + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)d.M * ncg) return;
+    const int row = (int)(idx / ncg), col = (int)(idx - (long long)row * ncg) * 4;
+    const int flags = d.flags;
+    const float* p = slabs + (long long)row * d.N + col;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = col + 4 <= d.N && !(d.N & 3) && !(stride & 3);
+    for (int s = 0; s < nslabs; ++s, p += stride) {
+        if (full) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+            for (int i = 0; i < 4; ++i) if (col + i < d.N) v[i] += p[i];
+        }
+    }
+    const unsigned q = udiv_magic((unsigned)row, d.c_magic, d.c_shift);
+    const long long off = (long long)q * d.c_rbstride + (long long)((unsigned)row - q * d.c_rpb) * d.ldc + col;
+    const float* bias = (flags & SCL_GEMM_HAS_BIAS) ? d.bias : nullptr;
+    if (full && d.vec_ok) {
+        const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
+        const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF, rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF, ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+        if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (flags & SCL_GEMM_HAS_C2) {
+            if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+        if (act) { v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]); }
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rmode) {
+            if (r_f32) {
+                const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.R) + off);
+                r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(d.R) + off);
+                r[0] = __uint_as_float(t.x << 16); r[1] = __uint_as_float(t.x & 0xFFFF0000u);
+                r[2] = __uint_as_float(t.y << 16); r[3] = __uint_as_float(t.y & 0xFFFF0000u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (rmode == 2) v[i] *= act_grad_f(ract, r[i]);
+            if (flags & SCL_GEMM_DROPOUT) v[i] *= dropout_scale(d.drop_seed, (uint64_t)(off + i), d.drop_p);
+            if (rmode == 1) v[i] += r[i];
+        }
+        if (c_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + off) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    } else {
+        const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
+        for (int i = 0; i < 4; ++i) epi_scalar(ea, v[i], off + i, col + i, bias);
+    }
+}
+
+extern "C" int scl_gemm_splitk_finish(const SclGemmDesc* dp, const float* slabs, int nslabs, int64_t stride, void* stream) {
+    SCL_REQUIRE(dp && slabs && nslabs >= 1 && stride >= 0, "gemm finish: bad args");
+    const SclGemmDesc& d = *dp;
+    SCL_REQUIRE(d.M > 0 && d.N > 0 && d.nb1 == 1 && d.nb2 == 1, "gemm finish: one un-batched [M, N] problem");
+    SCL_REQUIRE(d.C && d.c_rpb >= 1, "gemm finish: C null or c_rpb < 1");
+    const int rmode = (d.flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
+    SCL_REQUIRE(rmode == 0 || d.R, "gemm finish: RMODE set but R is null");
+    SCL_REQUIRE(!(d.flags & SCL_GEMM_HAS_C2) || d.C2, "gemm finish: HAS_C2 set but C2 is null");
+    SCL_REQUIRE(!(d.flags & SCL_GEMM_HAS_BIAS) || d.bias, "gemm finish: HAS_BIAS set but bias is null");
+    SCL_REQUIRE(((uintptr_t)slabs & 15) == 0, "gemm finish: slabs must be 16-byte aligned");
+    GemmK k;
+    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias;
+    k.c_bs1 = 0; k.c_bs2 = 0; k.c_rbstride = d.c_rbstride; k.c_split_stride = 0; k.bias_bs2 = 0;
+    k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
+    k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = 1; k.splitk = 1; k.flags = d.flags;
+    k.alpha = 1.0f; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed; k.group_m = 8; k.tile_m = 0; k.debug = 0;
+    auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p & (bytes - 1)) == 0; };
+    k.vec_ok = !(d.ldc & 3) && !(d.c_rbstride & 3) && al(d.C, (d.flags & SCL_GEMM_C_F32) ? 16 : 8) && al(d.C2, (d.flags & SCL_GEMM_C2_F32) ? 16 : 8) &&
+               al(d.R, (d.flags & SCL_GEMM_R_F32) ? 16 : 8) && al(d.bias, 16);
+    const long long n = (long long)d.M * ((d.N + 3) / 4);
+    hipLaunchKernelGGL(scl_gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k, slabs, nslabs, (long long)stride);
+    return scl_check_launch("scl_gemm_splitk_finish");
 }
 
 extern "C" int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream) {

@@ -1,5 +1,6 @@
 """Tensor-level wrappers over the C ABI (torch is used for device memory and the stream only)."""
 import ctypes
+import os
 
 import torch
 
@@ -96,6 +97,23 @@ class Op:
                             self.rpb, self.ld, self.cin, 0)
 
 
+_SPLITK_WS = {}      # per stream: f32 slabs of the automatic split-K path (old, smaller ones stay alive: recorded plans point into them)
+_AUTO_SPLITK = os.environ.get("SCL_GEMM_AUTO_SPLITK", "1") == "1"
+
+
+def _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, f32):
+    """Few output tiles and a long reduction (N = 1024 linears of a pack-sized step: 144 tiles of 128 x 128, K = 3072 / 4096): three
+    partial GEMMs + scl_gemm_splitk_finish beat the single launch 57 -> 37 us (tools/splitk_probe.py); shorter reductions and
+    problems that fill the CUs do not."""
+    if not _AUTO_SPLITK or splitk != 1 or nb1 != 1 or nb2 != 1 or a_t or f32 or K < 3072 or K % 64:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 170:
+        return 1
+    sk = min(K // 1024, 512 // tiles, 4)
+    return sk if sk >= 2 else 1
+
+
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
          c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False):
@@ -104,6 +122,18 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
                    nb2=nb2, splitk=splitk, ldc=ldc, c_rpb=c_rpb, c_rbstride=c_rbstride, c_bs1=c_bs1, c_bs2=c_bs2, c_offset=c_offset,
                    bias_bs2=bias_bs2, bias_offset=bias_offset, drop_p=drop_p, drop_seed=drop_seed, c_split_stride=c_split_stride,
                    no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8)
+    sk = _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, A.t.dtype == torch.float32)
+    if sk > 1 and not (force_w8 or force_p8 or force_big):
+        key = (C.device.index, torch.cuda.current_stream(C.device).cuda_stream)
+        ws = _SPLITK_WS.get(key)
+        if ws is None or ws[-1].numel() < sk * M * N:
+            ws = (ws or []) + [torch.empty(sk * M * N, dtype=torch.float32, device=C.device)]
+            _SPLITK_WS[key] = ws
+        slabs = ws[-1]
+        part = _gemm_desc(A, B, slabs, M, N, K, b_t=b_t, alpha=alpha, splitk=sk, c_split_stride=M * N, no_dma=no_dma, no_w8=True)
+        _call("scl_gemm_bf16", ctypes.byref(part), _stream(), keep=part)
+        _call("scl_gemm_splitk_finish", ctypes.byref(d), _ptr(slabs), sk, M * N, _stream(), keep=d)
+        return d
     _call("scl_gemm_bf16", ctypes.byref(d), _stream(), keep=d)
     return d
 

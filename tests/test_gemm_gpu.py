@@ -387,3 +387,46 @@ def test_f32_kernel_addresses_a_2d_convolution_in_place(dev):
     torch.cuda.synchronize()
     got = y.view(Bz, OH, OW, Co).permute(0, 3, 1, 2).double().cpu()
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("case", ["plain_bf16", "bias_resid_f32", "gelu_c2", "gelu_grad_mul", "ragged"])
+def test_auto_split_k_with_fused_finish_matches_the_single_launch(dev, case, monkeypatch):
+    """Pack-sized linears (144 output tiles, K = 3072 / 4096) go through ops.gemm's automatic split-K + scl_gemm_splitk_finish: the
+    epilogue of the original descriptor applied to the summed slabs.  Same values as the one-launch kernel up to the f32 summation
+    order (three partial sums instead of one chain): bf16 outputs within one bf16 step, f32 outputs within 2e-5 of the scale."""
+    from scl_amd import ops
+    from scl_amd.ops import Op
+    g = torch.Generator().manual_seed(11)
+    M, N, K = (2189, 1024, 4096) if case != "ragged" else (2189, 1000, 3072)
+    A = (0.05 * torch.randn(M, K, generator=g)).bfloat16().to(dev)
+    b_t = case in ("gelu_grad_mul", "ragged")
+    B = (0.05 * torch.randn(K, N, generator=g) if b_t else 0.05 * torch.randn(N, K, generator=g)).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    R32 = torch.randn(M, N, generator=g).to(dev)
+    Rbf = torch.randn(M, N, generator=g).bfloat16().to(dev)
+
+    def run(auto):
+        monkeypatch.setattr(ops, "_AUTO_SPLITK", auto)
+        kw, outs = dict(b_t=b_t), []
+        if case == "plain_bf16":
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        elif case == "bias_resid_f32":
+            C = torch.empty(M, N, device=dev); kw.update(bias=bias, R=R32, rmode=1)
+        elif case == "gelu_c2":
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev); c2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw.update(bias=bias, act=1, c2=c2); outs.append(c2)
+        elif case == "gelu_grad_mul":
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev); kw.update(R=Rbf, rmode=2, ract=1)
+        else:
+            C = torch.empty(M, N, device=dev); kw.update(bias=bias)
+        assert ops._auto_splitk(M, N, K, False, 1, 1, 1, False) == (3 if auto else 1)
+        ops.gemm(Op(A, K), Op(B, N if b_t else K), C, M, N, K, **kw)
+        torch.cuda.synchronize()
+        return [C.float().cpu()] + [o.float().cpu() for o in outs]
+
+    one, split = run(False), run(True)
+    for a, b in zip(one, split):
+        scale = a.abs().max().item()
+        tol = 2e-5 * scale if case in ("bias_resid_f32", "ragged") else scale * 2 ** -7
+        assert (a - b).abs().max().item() <= tol, (case, (a - b).abs().max().item(), scale)
+        assert ((a - b).abs() > 1e-6 * scale).float().mean().item() < 0.5
