@@ -318,6 +318,15 @@ int scl_i16_gain_overlay(const void* speech_i16, int64_t n, const void* noise_i1
 int scl_multiview_crop_f32(const float* src, const int64_t* off, const int* len, int V, int firstlen, int start, int out_len,
                            int repeat_pad, float* out, int64_t ldo, void* stream);
 
+/* ---- file reader: FLAC (csrc/flac.hip, host code) ----------------------------------------------------------------------------------
+ * Stands where the reference calls librosa.load / AudioSegment.from_file on ASVspoof's .flac utterances
+ * (datautils/asvspoof_2019_augall_3.py:97-100, audio_augmentor/background_noise.py:22-28): `data` is the whole file in host memory.
+ * scl_flac_info reads STREAMINFO; scl_flac_decode_i32 writes interleaved samples [total][channels] as sign-extended int32 (divide
+ * by 2^(bits-1) for librosa's float range), checks every frame's CRC-8 / CRC-16 and, with check_md5 != 0, the MD5 signature of the
+ * decoded audio.  total_samples == 0 in STREAMINFO (unknown length): decode with a capacity of the caller's choosing. */
+int scl_flac_info(const void* data, int64_t nbytes, int* sample_rate, int* channels, int* bits_per_sample, int64_t* total_samples);
+int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* out, int64_t capacity_samples, int64_t* decoded_samples, int check_md5);
+
 /* ---- conf-5 augmenters (csrc/speedpitch.hip) ----------------------------------------------------------------------------------
  * speed: datautils/audio_augmentor/speed.py:29-33 -> pydub 0.25.1 AudioSegment.speedup(speed_factor).  scl_i16_append_xfade is
  * AudioSegment.append(chunk, crossfade) applied in place to the running 16-bit output `out` (n1 frames, capacity >= n1 + tail_n):

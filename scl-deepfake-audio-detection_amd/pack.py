@@ -52,12 +52,33 @@ def _read_wav(path):
     return x, sr
 
 
+def _read_flac(path):
+    """FLAC through the library's own decoder (csrc/flac.hip: frame CRCs and the STREAMINFO MD5 are verified); channels are averaged
+    as librosa.load(mono=True) does."""
+    import ctypes
+    from . import lib as L
+    with open(path, "rb") as f:
+        raw = f.read()
+    lib = L.load()
+    buf = ctypes.create_string_buffer(raw, len(raw))
+    fs, ch, bits, total = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+    L.check(lib.scl_flac_info(buf, len(raw), ctypes.byref(fs), ctypes.byref(ch), ctypes.byref(bits), ctypes.byref(total)), "scl_flac_info(%s)" % path)
+    cap = total.value if total.value > 0 else len(raw) * 16         # unknown length: no FLAC stream expands 128-fold per byte
+    out = np.empty((cap, ch.value), dtype=np.int32)
+    got = ctypes.c_int64(0)
+    L.check(lib.scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got), 1), "scl_flac_decode_i32(%s)" % path)
+    x = out[: got.value].astype(np.float32) / np.float32(1 << (bits.value - 1))
+    return (x.mean(axis=1) if ch.value > 1 else x[:, 0]), fs.value
+
+
 def load_audio(path, sr=16000):
     """librosa.load(path, sr=sr, mono=True) stand-in for the formats this image can decode."""
     if _LOADER is not None:
         return np.asarray(_LOADER(path, sr), dtype=np.float32)
     if path.lower().endswith(".wav"):
         x, fs = _read_wav(path)
+    elif path.lower().endswith(".flac"):
+        x, fs = _read_flac(path)
     else:
         try:
             import soundfile as sf
@@ -74,17 +95,18 @@ def load_audio(path, sr=16000):
 
 
 def require_decoder_for(paths, what):
-    """Fail at start-up when the corpus holds formats this image cannot decode: WAV goes through the stdlib, everything else
-    (ASVspoof ships FLAC, MUSAN / RIR corpora WAV) needs `soundfile` — or a loader registered with set_audio_loader()."""
+    """Fail at start-up when the corpus holds formats this image cannot decode: WAV goes through the stdlib, FLAC (ASVspoof) through
+    the library's decoder, everything else (MP3 in some MUSAN mirrors) needs `soundfile` — or a loader registered with
+    set_audio_loader()."""
     if _LOADER is not None:
         return
-    other = [p for p in paths if not str(p).lower().endswith(".wav")]
+    other = [p for p in paths if not str(p).lower().endswith((".wav", ".flac"))]
     if not other:
         return
     try:
         import soundfile  # noqa: F401
     except ImportError as e:
-        raise RuntimeError("%s: %d files such as %s are not WAV and the `soundfile` package is not installed — install it or register "
+        raise RuntimeError("%s: %d files such as %s are neither WAV nor FLAC and the `soundfile` package is not installed — install it or register "
                            "a decoder with scl_amd.pack.set_audio_loader(fn)" % (what, len(other), other[0])) from e
 
 

@@ -177,7 +177,7 @@ def test_prefetcher_preserves_order_and_propagates_errors():
 def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
     from scl_amd import pack
     pack.set_audio_loader(None)
-    pack.require_decoder_for(["a.wav", "b.WAV"], "list")                  # WAV: stdlib
+    pack.require_decoder_for(["a.wav", "b.WAV", "LA_T_1000137.flac"], "list")     # WAV: stdlib; FLAC: the library's decoder
     try:
         import soundfile  # noqa: F401
         has_sf = True
@@ -186,7 +186,7 @@ def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
     if not has_sf:
         import pytest as _pt
         with _pt.raises(RuntimeError, match="soundfile"):
-            pack.require_decoder_for(["LA_T_1000137.flac"], "training / validation list")
+            pack.require_decoder_for(["music-fma-0001.mp3"], "noise corpus")
     pack.set_audio_loader(lambda p, sr: np.zeros(10, np.float32))
-    pack.require_decoder_for(["LA_T_1000137.flac"], "list")               # a registered loader decodes anything
+    pack.require_decoder_for(["music-fma-0001.mp3"], "list")               # a registered loader decodes anything
     pack.set_audio_loader(None)
