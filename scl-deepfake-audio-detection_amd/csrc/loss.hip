@@ -11,6 +11,7 @@
 // Three kernels: Gram partials over K-chunks, a single-workgroup loss + dL/dS kernel, and the
 // backward contraction dF = (dL/dS + dL/dS^T) F / (T' t).  The [T', bz, bz] temporary of the
 // reference's bmm is never materialised.
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -165,12 +166,38 @@ __global__ void nll_kernel(const float* __restrict__ logp, const int64_t* __rest
     }
 }
 
+// Gs[i][j] = c * (G[i][j] + G[j][i]),  c = coef * (*upstream): the A operand of the backward contraction when it runs as a GEMM
+__global__ __launch_bounds__(256) void supcon_gsym_kernel(const float* __restrict__ G, const float* __restrict__ upstream, float coef,
+                                                          float* __restrict__ Gs, int bz, int ld) {
+    const float c = coef * (upstream ? *upstream : 1.f);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < bz * ld; p += gridDim.x * 256) {
+        const int i = p / ld, j = p % ld;
+        Gs[p] = j < bz ? c * (G[i * bz + j] + G[j * bz + i]) : 0.f;
+    }
+}
+
+// Long feature rows (feats: K = T' x 128 = 25 472): both contractions are GEMMs with a tiny M — [bz, K] x [K, bz] split along K, and
+// [bz, bz] x [bz, K] — and run on the exact-fp32 matrix-core kernel (gemm_f32.hip) instead of the scalar kernels above, which put
+// 25 / 100 workgroups on the 256 CUs (130 / 220 us per call at bz = 64; the GEMMs: ~12 / ~8 us).  Short rows (emb: K = 128) stay.
+inline bool supcon_as_gemm(int bz, int64_t K, int64_t ldF, const void* F) {      // bz % 4: the backward's reduction runs over bz rows of F
+    return K >= 2048 && (K & 3) == 0 && (ldF & 3) == 0 && (bz & 3) == 0 && ((uintptr_t)F & 15) == 0;
+}
+constexpr int SUPCON_GEMM_SPLIT = 32;
+
+inline SclOperand f32_rows(const float* p, int64_t ld) {
+    SclOperand o;
+    memset(&o, 0, sizeof(o));
+    o.ptr = p; o.rpb = 0x7fffffff; o.ld = (int32_t)ld; o.cin = 0x7fffffff;
+    return o;
+}
+
 }  // namespace
 
 extern "C" int scl_supcon_nchunks(int64_t K) {
     int64_t n = (K + 1023) / 1024;
     if (n > 512) n = 512;
-    return (int)(n < 1 ? 1 : n);
+    if (n < SUPCON_GEMM_SPLIT) n = SUPCON_GEMM_SPLIT;      // the GEMM form writes this many slabs
+    return (int)n;
 }
 
 // F f32 [bz, K] (row stride ldF); labels int64 [bz]; ws: nchunks*bz*bz floats; G: bz*bz floats.
@@ -180,7 +207,19 @@ extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int
     SCL_REQUIRE(F && labels && ws && G && loss_out, "supcon_fwd: null pointer");
     SCL_REQUIRE(bz >= 1 && bz <= 128 && K >= 1 && Tprime >= 1 && temperature > 0.f, "supcon_fwd: need 1 <= bz <= 128");
     hipStream_t s = (hipStream_t)stream;
-    const int nch = scl_supcon_nchunks(K);
+    if (supcon_as_gemm(bz, K, ldF, F)) {
+        SclGemmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.A = f32_rows(F, ldF); d.B = f32_rows(F, ldF);
+        d.C = ws; d.ldc = bz; d.c_rpb = 0x7fffffff; d.M = bz; d.N = bz; d.K = (int32_t)K; d.nb1 = 1; d.nb2 = 1;
+        d.splitk = SUPCON_GEMM_SPLIT; d.c_split_stride = (int64_t)bz * bz; d.flags = SCL_GEMM_C_F32 | SCL_GEMM_AB_F32; d.alpha = 1.0f;
+        const int rc = scl_gemm_bf16(&d, stream);
+        if (rc != SCL_OK) return rc;
+        hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(256), (size_t)(bz * bz + bz) * sizeof(float), s, ws, SUPCON_GEMM_SPLIT, labels, bz,
+                           1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
+        return scl_check_launch("scl_supcon_fwd");
+    }
+    const int nch = (int)((K + 1023) / 1024 < 1 ? 1 : ((K + 1023) / 1024 > 512 ? 512 : (K + 1023) / 1024));
     int64_t kchunk = (K + nch - 1) / nch;
     kchunk = (kchunk + KC - 1) / KC * KC;
     const int nch_eff = (int)((K + kchunk - 1) / kchunk);
@@ -194,6 +233,29 @@ extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int
 extern "C" int scl_supcon_bwd(const float* F, const float* G, const float* upstream, float coef, int bz, int64_t K, int64_t ldF,
                               int Tprime, float temperature, float* dF, void* dF_bf16, int accumulate, void* stream) {
     SCL_REQUIRE(F && G && dF && bz >= 1 && bz <= 128 && K >= 1, "supcon_bwd: bad args");
+    if (supcon_as_gemm(bz, K, ldF, F) && ((uintptr_t)dF & 15) == 0 && (dF_bf16 == nullptr || ((uintptr_t)dF_bf16 & 7) == 0)) {
+        // dF[i][k] (+)= sum_j Gs[i][j] F[j][k]:  A = Gs [bz, bz4] (reduction padded to a multiple of 4 with zero columns),
+        // B = F read as [j rows][k contiguous] (transposed operand), C = dF f32 (+ R = dF when accumulating), C2 = the bf16 copy
+        static float* gs_buf = nullptr;
+        if (!gs_buf && hipMalloc(&gs_buf, 128 * 128 * sizeof(float)) != hipSuccess) return SCL_ELAUNCH;
+        const int bz4 = (bz + 3) & ~3;
+        hipLaunchKernelGGL(supcon_gsym_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, G, upstream, coef / ((float)Tprime * temperature),
+                           gs_buf, bz, bz4);
+        SclGemmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.A = f32_rows(gs_buf, bz4); d.B = f32_rows(F, ldF);
+        d.C = dF; d.ldc = (int32_t)ldF; d.c_rpb = 0x7fffffff; d.M = bz; d.N = (int32_t)K; d.K = bz4; d.nb1 = 1; d.nb2 = 1; d.splitk = 1;
+        d.flags = SCL_GEMM_C_F32 | SCL_GEMM_AB_F32 | SCL_GEMM_B_T; d.alpha = 1.0f;
+        if (accumulate) { d.R = dF; d.flags |= SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT); }
+        if (dF_bf16) {
+            // the epilogue's second output is the value BEFORE the residual add: only usable when nothing is accumulated
+            if (accumulate) { scl_set_error("supcon_bwd: bf16 copy with accumulate is not supported on the GEMM path"); return SCL_EUNSUPPORTED; }
+            d.C2 = dF_bf16; d.flags |= SCL_GEMM_HAS_C2;
+        }
+        const int rc = scl_gemm_bf16(&d, stream);
+        if (rc != SCL_OK) return rc;
+        return scl_check_launch("scl_supcon_bwd");
+    }
     hipLaunchKernelGGL(supcon_bwd_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), (size_t)bz * bz * sizeof(float), (hipStream_t)stream,
                        F, G, upstream, coef / ((float)Tprime * temperature), dF, (bf16_t*)dF_bf16, bz, K, ldF, accumulate);
     return scl_check_launch("scl_supcon_bwd");

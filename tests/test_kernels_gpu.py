@@ -262,7 +262,8 @@ def test_conv0_fwd_bwd(dev, C, L, B, saved):
 
 def test_supcon_and_nll_match_oracle(dev):
     from oracle import head as OH
-    for bz, T2, d, seed in ((4, 49, 128, 0), (11, 199, 128, 1), (64, 49, 128, 2), (11, 128, 1, 3), (32, 199, 128, 4), (100, 7, 16, 5)):
+    for bz, T2, d, seed in ((4, 49, 128, 0), (11, 199, 128, 1), (64, 49, 128, 2), (11, 128, 1, 3), (32, 199, 128, 4), (100, 7, 16, 5), (64, 199, 128, 6),
+                            (12, 199, 128, 7)):
         torch.manual_seed(seed)
         f = torch.randn(bz, 1, T2, d)
         lab = torch.tensor(([1] * ((5 * bz + 10) // 11) + [0] * bz)[:bz])
@@ -279,6 +280,13 @@ def test_supcon_and_nll_match_oracle(dev):
         up = torch.tensor([0.37], device=dev)
         ops.supcon_bwd(Fd, G, up, 1.0, bz, K, K, T2, 0.07, dF)
         assert rel(dF, fr.grad.view(bz, K)) < 2e-4, (bz, T2, d)
+        # accumulate onto an existing gradient, and the bf16 copy (both forms: scalar kernels for short / ragged rows, fp32 GEMMs else)
+        acc = torch.ones(bz, K, device=dev)
+        ops.supcon_bwd(Fd, G, up, 1.0, bz, K, K, T2, 0.07, acc, accumulate=True)
+        assert rel(acc - 1.0, fr.grad.view(bz, K)) < 1e-3, (bz, T2, d)
+        dF2 = torch.empty(bz, K, device=dev); dFb = torch.empty(bz, K, device=dev, dtype=torch.bfloat16)
+        ops.supcon_bwd(Fd, G, up, 1.0, bz, K, K, T2, 0.07, dF2, dF_bf16=dFb)
+        assert torch.equal(dF2, dF) and torch.equal(dFb, dF.to(torch.bfloat16)), (bz, T2, d)
     # single-member class -> NaN, as loss_metrics.py:202
     torch.manual_seed(9)
     f = torch.randn(4, 80).to(dev)
