@@ -219,6 +219,17 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
     for (int i = threadIdx.x; i < C * (k + 3); i += blockDim.x) part[blk * C * (k + 3) + i] = red[i];
 }
 
+// First level of the partial-sum tree: segment g adds rows g, g + S, g + 2S, ... into row g (in place: no other segment touches
+// those rows).  At batch 64 there are 832 partial rows of 6656 values; a single level walks them serially from 26 workgroups (250 us).
+__global__ void conv0_reduce_seg_kernel(float* __restrict__ part, int nparts, int n, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= n || g >= nparts) return;
+    float s = 0.f;
+    for (int p = g; p < nparts; p += S) s += part[(int64_t)p * n + i];
+    part[(int64_t)g * n + i] = s;
+}
+
 __global__ void conv0_reduce_kernel(const float* __restrict__ part, int nparts, int C, int k, float* __restrict__ dW,
                                     float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,7 +301,13 @@ extern "C" int scl_conv0_bwd(const float* x, const float* w, const float* bias, 
     if (k <= 10) { if (stats) CONV0_BWD(true, 10); else CONV0_BWD(false, 10); }
     else { if (stats) CONV0_BWD(true, MAXK); else CONV0_BWD(false, MAXK); }
 #undef CONV0_BWD
-    const int nparts = grid.x * grid.y, n = C * (k + 3);
+    int nparts = grid.x * grid.y;
+    const int n = C * (k + 3);
+    if (nparts > 64) {
+        const int S = 32;
+        hipLaunchKernelGGL(conv0_reduce_seg_kernel, dim3((n + 255) / 256, S), dim3(256), 0, s, part_ws, nparts, n, S);
+        nparts = S;
+    }
     hipLaunchKernelGGL(conv0_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part_ws, nparts, C, k, dW, db, dgamma, dbeta);
     return scl_check_launch("scl_conv0_bwd");
 }
