@@ -56,14 +56,14 @@ __global__ __launch_bounds__(256) void supcon_gram_kernel(const float* __restric
 }
 
 // single block: S = sum(parts) * scale; loss; G[i][j] = dloss/dS[i][j]
-__global__ __launch_bounds__(256) void supcon_loss_kernel(const float* __restrict__ part, int nparts, const int64_t* __restrict__ labels,
+__global__ __launch_bounds__(1024) void supcon_loss_kernel(const float* __restrict__ part, int nparts, const int64_t* __restrict__ labels,
                                                           int bz, float scale, float* __restrict__ loss_out, float* __restrict__ G,
                                                           float* __restrict__ S_out) {
     extern __shared__ float sm[];  // S [bz*bz], rowloss [bz]
     float* S = sm;
     float* rowloss = sm + bz * bz;
     const int npairs = bz * bz;
-    for (int p = threadIdx.x; p < npairs; p += 256) {
+    for (int p = threadIdx.x; p < npairs; p += blockDim.x) {
         float s = 0.f;
         for (int c = 0; c < nparts; ++c) s += part[(int64_t)c * npairs + p];
         S[p] = s * scale;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void supcon_loss_kernel(const float* __restric
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = wv; i < bz; i += 4) {
+    for (int i = wv; i < bz; i += (int)(blockDim.x >> 6)) {
         const int64_t yi = labels[i];
         float mx = -INFINITY;
         for (int j = lane; j < bz; j += 64) mx = fmaxf(mx, j == i ? 0.f : S[i * bz + j]);  // logits * self_mask
@@ -176,13 +176,15 @@ __global__ __launch_bounds__(256) void supcon_gsym_kernel(const float* __restric
     }
 }
 
-// Long feature rows (feats: K = T' x 128 = 25 472): both contractions are GEMMs with a tiny M — [bz, K] x [K, bz] split along K, and
-// [bz, bz] x [bz, K] — and run on the exact-fp32 matrix-core kernel (gemm_f32.hip) instead of the scalar kernels above, which put
-// 25 / 100 workgroups on the 256 CUs (130 / 220 us per call at bz = 64; the GEMMs: ~12 / ~8 us).  Short rows (emb: K = 128) stay.
+// Both contractions are GEMMs with a tiny M — [bz, K] x [K, bz] (split along K when the rows are long: feats, K = T' x 128 = 25 472)
+// and [bz, bz] x [bz, K] — and run on the exact-fp32 matrix-core kernel (gemm_f32.hip) instead of the scalar kernels above, which put
+// 25 / 100 workgroups on the 256 CUs for feats (130 / 220 us per call at bz = 64; the GEMMs: ~12 / ~8 us) and ONE for emb (K = 128:
+// 210 us in the backward).  The scalar kernels remain for batch sizes / row lengths that are not multiples of 4.
 inline bool supcon_as_gemm(int bz, int64_t K, int64_t ldF, const void* F) {      // bz % 4: the backward's reduction runs over bz rows of F
-    return K >= 2048 && (K & 3) == 0 && (ldF & 3) == 0 && (bz & 3) == 0 && ((uintptr_t)F & 15) == 0;
+    return K >= 64 && (K & 3) == 0 && (ldF & 3) == 0 && (bz & 3) == 0 && ((uintptr_t)F & 15) == 0;
 }
 constexpr int SUPCON_GEMM_SPLIT = 32;
+inline int supcon_split(int64_t K) { const int64_t s = K / 256; return (int)(s < 1 ? 1 : (s > SUPCON_GEMM_SPLIT ? SUPCON_GEMM_SPLIT : s)); }
 
 inline SclOperand f32_rows(const float* p, int64_t ld) {
     SclOperand o;
@@ -212,10 +214,11 @@ extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int
         memset(&d, 0, sizeof(d));
         d.A = f32_rows(F, ldF); d.B = f32_rows(F, ldF);
         d.C = ws; d.ldc = bz; d.c_rpb = 0x7fffffff; d.M = bz; d.N = bz; d.K = (int32_t)K; d.nb1 = 1; d.nb2 = 1;
-        d.splitk = SUPCON_GEMM_SPLIT; d.c_split_stride = (int64_t)bz * bz; d.flags = SCL_GEMM_C_F32 | SCL_GEMM_AB_F32; d.alpha = 1.0f;
+        const int sk = supcon_split(K);
+        d.splitk = sk; d.c_split_stride = sk > 1 ? (int64_t)bz * bz : 0; d.flags = SCL_GEMM_C_F32 | SCL_GEMM_AB_F32; d.alpha = 1.0f;
         const int rc = scl_gemm_bf16(&d, stream);
         if (rc != SCL_OK) return rc;
-        hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(256), (size_t)(bz * bz + bz) * sizeof(float), s, ws, SUPCON_GEMM_SPLIT, labels, bz,
+        hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(1024), (size_t)(bz * bz + bz) * sizeof(float), s, ws, sk, labels, bz,
                            1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
         return scl_check_launch("scl_supcon_fwd");
     }
@@ -224,7 +227,7 @@ extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int
     kchunk = (kchunk + KC - 1) / KC * KC;
     const int nch_eff = (int)((K + kchunk - 1) / kchunk);
     hipLaunchKernelGGL(supcon_gram_kernel, dim3(nch_eff), dim3(256), (size_t)bz * (KC + 1) * sizeof(float), s, F, ws, bz, K, ldF, kchunk);
-    hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(256), (size_t)(bz * bz + bz) * sizeof(float), s, ws, nch_eff, labels, bz,
+    hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(1024), (size_t)(bz * bz + bz) * sizeof(float), s, ws, nch_eff, labels, bz,
                        1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
     return scl_check_launch("scl_supcon_fwd");
 }

@@ -34,10 +34,11 @@ json.dump(out, open("gpurun_out/r2_pmc_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:700])
 PY
 for m in wav2vec2_aasist wav2vec2_resnet_nll; do
+python3 bench.py --no-cpu-baseline --model $m --batch 32 --rawboost 0 --steps 6 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/r2_bench_$m.json
 rm -rf gpurun_out/prof_$m
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -o bench -- python3 bench.py --no-cpu-baseline --model $m --batch 32 --rawboost 0 --steps 6 > gpurun_out/prof_$m.log 2>&1
 find gpurun_out/prof_$m -name "*kernel_stats.csv" -exec cp {} gpurun_out/r2_bench_${m}_kernel_stats.csv \;
-grep '^{"metric"' gpurun_out/prof_$m.log | tail -1 > gpurun_out/r2_bench_$m.json
+grep '^{"metric"' gpurun_out/prof_$m.log | tail -1 > gpurun_out/r2_bench_${m}_under_rocprof.json
 rm -rf gpurun_out/prof_$m
 done
 python3 - <<'PY'
