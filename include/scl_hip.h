@@ -279,6 +279,8 @@ int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const f
 /* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
 /* ------------------------------------------------------------------------------------------ */
+/* Buffers: ws = scl_supcon_nchunks(K) * bz * bz floats; G = 2 * bz * bz floats — [0, bz*bz) receives dL/dS from the forward and is
+ * read by the backward, [bz*bz, 2*bz*bz) is the backward's scratch (the symmetrised, scaled coefficient matrix of its GEMM form). */
 int scl_supcon_nchunks(int64_t K);
 int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int64_t K, int64_t ldF, int Tprime, float temperature,
                    float* ws, float* G, float* loss_out, float* S_out, void* stream);

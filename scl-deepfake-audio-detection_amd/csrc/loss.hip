@@ -239,9 +239,8 @@ extern "C" int scl_supcon_bwd(const float* F, const float* G, const float* upstr
     if (supcon_as_gemm(bz, K, ldF, F) && ((uintptr_t)dF & 15) == 0 && (dF_bf16 == nullptr || ((uintptr_t)dF_bf16 & 7) == 0)) {
         // dF[i][k] (+)= sum_j Gs[i][j] F[j][k]:  A = Gs [bz, bz4] (reduction padded to a multiple of 4 with zero columns),
         // B = F read as [j rows][k contiguous] (transposed operand), C = dF f32 (+ R = dF when accumulating), C2 = the bf16 copy
-        static float* gs_buf = nullptr;
-        if (!gs_buf && hipMalloc(&gs_buf, 128 * 128 * sizeof(float)) != hipSuccess) return SCL_ELAUNCH;
-        const int bz4 = (bz + 3) & ~3;
+        float* gs_buf = const_cast<float*>(G) + (size_t)bz * bz;       // the caller's G holds 2 * bz * bz floats: [bz*bz, 2*bz*bz) is scratch
+        const int bz4 = bz;                                             // bz % 4 == 0 on this path
         hipLaunchKernelGGL(supcon_gsym_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, G, upstream, coef / ((float)Tprime * temperature),
                            gs_buf, bz, bz4);
         SclGemmDesc d;

@@ -372,11 +372,13 @@ def supcon_nchunks(K):
 
 
 def supcon_fwd(F, labels, bz, K, ldF, Tprime, temperature, ws, G, loss_out, S_out=None):
+    assert G.numel() >= 2 * bz * bz and ws.numel() >= supcon_nchunks(K) * bz * bz, "supcon: G holds 2 bz^2 floats (dL/dS + backward scratch)"
     _call("scl_supcon_fwd", _p(F), _p(labels), bz, K, ldF, Tprime, temperature, _p(ws), _p(G), _p(loss_out), _p(S_out),
                                     _stream())
 
 
 def supcon_bwd(F, G, upstream, coef, bz, K, ldF, Tprime, temperature, dF, dF_bf16=None, accumulate=False):
+    assert G.numel() >= 2 * bz * bz, "supcon: G holds 2 bz^2 floats (dL/dS + backward scratch)"
     _call("scl_supcon_bwd", _p(F), _p(G), _p(upstream), coef, bz, K, ldF, Tprime, temperature, _p(dF), _p(dF_bf16),
                                     1 if accumulate else 0, _stream())
 

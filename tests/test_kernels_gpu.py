@@ -273,7 +273,7 @@ def test_supcon_and_nll_match_oracle(dev):
         K = T2 * d
         Fd = f.view(bz, K).to(dev).contiguous()
         ws = torch.empty(ops.supcon_nchunks(K) * bz * bz, device=dev)
-        G = torch.empty(bz * bz, device=dev); loss = torch.empty(1, device=dev)
+        G = torch.empty(2 * bz * bz, device=dev); loss = torch.empty(1, device=dev)
         ops.supcon_fwd(Fd, lab.to(dev), bz, K, K, T2, 0.07, ws, G, loss)
         assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (bz, T2, d)
         dF = torch.empty(bz, K, device=dev)
@@ -290,7 +290,7 @@ def test_supcon_and_nll_match_oracle(dev):
     # single-member class -> NaN, as loss_metrics.py:202
     torch.manual_seed(9)
     f = torch.randn(4, 80).to(dev)
-    ws = torch.empty(ops.supcon_nchunks(80) * 16, device=dev); G = torch.empty(16, device=dev); loss = torch.empty(1, device=dev)
+    ws = torch.empty(ops.supcon_nchunks(80) * 16, device=dev); G = torch.empty(32, device=dev); loss = torch.empty(1, device=dev)
     ops.supcon_fwd(f, torch.tensor([1, 0, 0, 0], device=dev), 4, 80, 80, 10, 0.07, ws, G, loss)
     assert torch.isnan(loss).item()
     # NLL term: CE on log-probs, mean, then / bz
