@@ -117,7 +117,7 @@ __device__ __forceinline__ bf16x8 w8_frag(const char* img, int gb, int ks, int l
 // a lane owns 8 consecutive columns of one row, 8 lanes own a row's 64 columns, so bias / residual loads and the C / C2 stores of
 // one wave-instruction cover 8 rows x 128 (bf16) or 256 (f32) contiguous bytes.  Arithmetic per element is the old epilogue's,
 // in the same order: results are bit-identical.
-__device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4][4], int nmt, char* wlds, int mbase, int nbase,
+__device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
                                                  int mlimit, long long cbase, const float* bias, int lane) {
     const int flags = d.flags;
     const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
@@ -143,7 +143,40 @@ __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4]
         bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
     }
     const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
+    // The R operand (activation-gradient input / residual) comes in through LDS-DMA, several rows at a time: loads and stores share
+    // the in-order vmcnt counter, so a wait for row i's R vector requested after row i-1's stores also waits for those stores'
+    // acknowledgement — one memory round trip per row (tools/epilogue_probe.py: reading R cost 52 us per launch where a second
+    // store costs 14).  Staged this way the queue is drained once per batch, and the loop stays rolled (the kernels are 44 KB of
+    // code: unrolling the epilogue to keep R in registers slowed every variant, R or not, by 20-36 us).  bf16 R: batches of four
+    // rows in the wave's 4 KiB above the transposition blocks.  f32 R (twice the bytes): rows 0-1 and 2-3 there, rows 4-7 in the
+    // first half of the wave's own transposition block, whose rows have been consumed by then.
+    const bool r_dma = rmode && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
+    __amdgpu_buffer_rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(r_dma ? d.R : d.C));
+    const char* rstage = wextra;
     for (int i = 0; i < 2 * nmt; ++i) {
+        const bool issue = r_dma && (r_f32 ? (i == 0 || i == 2 || i == 4) : (i & 3) == 0);
+        if (issue) {
+            const int nrow = r_f32 ? (i == 4 ? 4 : 2) : 4;
+            char* dst = (r_f32 && i == 4) ? wlds : wextra;
+            if (r_f32 && i == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of rows 0-31 have returned
+            for (int u = 0; u < nrow; ++u) {
+                const int row2 = mbase + 8 * (i + u) + rsub;
+                unsigned offb = OOB;
+                if (i + u < 2 * nmt && row2 < mlimit && colv) {
+                    const unsigned q2 = udiv_magic((unsigned)row2, d.c_magic, d.c_shift);
+                    const long long o2 = cbase + (long long)q2 * d.c_rbstride + (long long)((unsigned)row2 - q2 * d.c_rpb) * d.ldc + col;
+                    offb = (unsigned)(o2 << (r_f32 ? 2 : 1));
+                }
+                if (r_f32) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048), 16, offb, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048 + 1024), 16, offb == OOB ? OOB : offb + 16, 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 1024), 16, offb, 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rstage = dst - (r_f32 ? i * 2048 : i * 1024);      // row-batch i lives at rstage + i * (2048 | 1024)
+        }
         const int r = 8 * i + rsub;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c) ^ (r & 15)) << 4));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c + 1) ^ (r & 15)) << 4));
@@ -175,13 +208,14 @@ __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4]
             float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (rmode) {
                 if (r_f32) {
-                    const float* p = reinterpret_cast<const float*>(d.R) + off;
-                    const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + 4);
+                    const float* p = r_dma ? reinterpret_cast<const float*>(rstage + i * 2048 + lane * 16) : reinterpret_cast<const float*>(d.R) + off;
+                    const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + (r_dma ? 256 : 4));
                     rr[0] = t0.x; rr[1] = t0.y; rr[2] = t0.z; rr[3] = t0.w; rr[4] = t1.x; rr[5] = t1.y; rr[6] = t1.z; rr[7] = t1.w;
                 } else {
                     const bf16_t* p = reinterpret_cast<const bf16_t*>(d.R) + off;
                     uint2 t0, t1;
-                    if ((off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
+                    if (r_dma) { const uint4 t = *reinterpret_cast<const uint4*>(rstage + i * 1024 + lane * 16); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
+                    else if ((off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
                     else { t0 = *reinterpret_cast<const uint2*>(p); t1 = *reinterpret_cast<const uint2*>(p + 4); }
                     rr[0] = __uint_as_float(t0.x << 16); rr[1] = __uint_as_float(t0.x & 0xFFFF0000u);
                     rr[2] = __uint_as_float(t0.y << 16); rr[3] = __uint_as_float(t0.y & 0xFFFF0000u);
@@ -304,8 +338,9 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
         const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
         char* wlds = smem + wave * 16384;
-        w8_epilogue_pass(d, acc[0], 4, wlds, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
-        if (NH > 0) w8_epilogue_pass(d, acc[1], NH, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
+        w8_epilogue_pass(d, acc[0], 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        if (NH > 0) w8_epilogue_pass(d, acc[1], NH, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
@@ -433,15 +468,16 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
         const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
         char* wlds = smem + wave * 16384;
+        char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
         f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
-        w8_epilogue_pass(d, alo, 4, wlds, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        w8_epilogue_pass(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            w8_epilogue_pass(d, hi, RBW - 4, wlds, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+            w8_epilogue_pass(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         }
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
