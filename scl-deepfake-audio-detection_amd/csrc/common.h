@@ -26,12 +26,20 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 // |erf error| <= 1.5e-7 absolute — below fp32 round-off of the surrounding arithmetic — at ~12 VALU ops instead of
 // libm erff's ~45; GELU sits in the epilogue of every FC1 / conv-stack / pos-conv tile, where erff cost ~30 % of a tile.
 // The same exp(-x^2/2) serves the erf tail and the Gaussian pdf of the gradient.
+// Every fused multiply-add below is written out and contraction is switched off inside these functions: the scalar form (128x128
+// kernels, LayerNorm+GELU, element-wise edge paths) and the two-at-a-time packed form (wide GEMM epilogue: v_pk_fma_f32 /
+// v_pk_mul_f32, the reciprocal and the exponential stay scalar) perform the same operations in the same order whatever code surrounds
+// them, so the kernels that share a result agree to the last bit.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    e = __expf(-z * z);   // = exp(-x^2 / 2)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float half_tail = 0.5f * poly * e;          // = 0.5 * erfc(|x| / sqrt 2)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    e = __expf(-(z * z));   // = exp(-x^2 / 2)
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(t, p, 1.421413741f);
+    p = __builtin_fmaf(t, p, -0.284496736f);
+    p = __builtin_fmaf(t, p, 0.254829592f);
+    const float half_tail = (0.5f * (t * p)) * e;          // = 0.5 * erfc(|x| / sqrt 2)
     cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
 }
 __device__ __forceinline__ float gelu_f(float x) {
@@ -40,9 +48,39 @@ __device__ __forceinline__ float gelu_f(float x) {
     return x * cdf;
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
+#pragma clang fp contract(off)
     float cdf, e;
     gelu_parts(x, cdf, e);
-    return cdf + x * 0.39894228040143268f * e;
+    return __builtin_fmaf(x * 0.39894228040143268f, e, cdf);
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& e) {
+#pragma clang fp contract(off)
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 den = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 z2 = z * z;
+    e = f32x2{__expf(-z2[0]), __expf(-z2[1])};
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 half_tail = (0.5f * (t * p)) * e;
+    cdf = f32x2{x[0] >= 0.f ? 1.0f - half_tail[0] : half_tail[0], x[1] >= 0.f ? 1.0f - half_tail[1] : half_tail[1]};
+}
+__device__ __forceinline__ void gelu2(float& a, float& b) {
+    f32x2 cdf, e;
+    gelu_parts2(f32x2{a, b}, cdf, e);
+    a = a * cdf[0]; b = b * cdf[1];      // outside the packed part, as gelu_f: a following "+ residual" contracts the same way
+}
+__device__ __forceinline__ void gelu_grad2(float& a, float& b) {      // a, b := gelu'(a), gelu'(b)
+#pragma clang fp contract(off)
+    f32x2 cdf, e;
+    const f32x2 x = {a, b};
+    gelu_parts2(x, cdf, e);
+    const f32x2 y = __builtin_elementwise_fma(x * 0.39894228040143268f, e, cdf);
+    a = y[0]; b = y[1];
 }
 // activation ids shared with SCL_GEMM_ACT_SHIFT: 0 none, 1 gelu, 2 relu, 3 leaky_relu(0.01)
 __device__ __forceinline__ float act_f(int id, float x) {
