@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
     for _ in range(3):                         # step 2 and 3 replay the recorded plan (with its bucket callbacks)
         _step(m, opt, x.to(dev), y.to(dev), sync)
     torch.cuda.synchronize()
-    q.put((rank, m.P.flat[: m.P.n_train].cpu(), len(sync.bounds)))
+    q.put((rank, m.P.flat[: m.P.n_train].cpu().numpy(), len(sync.bounds)))      # by value: the worker may exit before the parent reads
     dist.destroy_process_group()
 
 
@@ -58,7 +58,7 @@ def test_two_rank_step_equals_single_process_mean_gradient_step(dev):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (w, nb)) for r, w, nb in (q.get(timeout=300) for _ in range(world)))
+    res = dict((r, (torch.from_numpy(w), nb)) for r, w, nb in (q.get(timeout=300) for _ in range(world)))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -118,7 +118,7 @@ def _worker_aasist(rank, world, port, q):
         opt.step()
         torch.cuda.synchronize()
         final_ok = final_ok and launched >= 1 and len(snaps) == len(sync.bounds)
-    q.put((rank, m.P.flat[: m.P.n_train].cpu(), final_ok, m.state_dict()["first_bn1.running_mean"].cpu()))
+    q.put((rank, m.P.flat[: m.P.n_train].cpu().numpy(), final_ok, m.state_dict()["first_bn1.running_mean"].cpu().numpy()))
     dist.destroy_process_group()
 
 
@@ -133,7 +133,7 @@ def test_two_rank_aasist_step_equals_mean_gradient_step(dev):
     procs = [ctx.Process(target=_worker_aasist, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (w, ok, bn)) for r, w, ok, bn in (q.get(timeout=600) for _ in range(world)))
+    res = dict((r, (torch.from_numpy(w), ok, torch.from_numpy(bn))) for r, w, ok, bn in (q.get(timeout=600) for _ in range(world)))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -188,7 +188,7 @@ def _rccl_worker(port, q, wire):
         res.append(m.P.flat[: m.P.n_train].cpu())
         if use_sync:
             rep = sync.report()
-    q.put((res[0], res[1], rep, dist.get_backend()))
+    q.put((res[0].numpy(), res[1].numpy(), rep, dist.get_backend()))
     dist.destroy_process_group()
 
 
@@ -201,6 +201,7 @@ def test_gradsync_choreography_on_rccl_with_one_rank(dev, wire):
     p.start()
     try:
         plain, synced, rep, backend = q.get(timeout=240)
+        plain, synced = torch.from_numpy(plain), torch.from_numpy(synced)
     finally:
         p.join(timeout=30)
         if p.is_alive():
