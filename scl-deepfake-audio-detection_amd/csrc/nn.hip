@@ -9,7 +9,14 @@
 
 namespace {
 
-constexpr int BN_SLAB = 128;          // rows per statistics slab (a multiple of 256 / C for every legal C keeps a thread on one channel)
+constexpr int BN_SLAB = 128;          // smallest statistics slab, in rows (a multiple of 256 / C for every legal C keeps a thread on one channel)
+// rows per slab: 128 for small maps, else the multiple of 128 that leaves ~512 slabs — the finishing kernels walk the slab partials
+// with 16 lanes per channel (2112 slabs of a [32, 66, 128] map took them 24 us each, 19 + 19 times a ResNet step)
+static inline int bn_slab_rows(int N) {
+    if (N <= BN_SLAB * 512) return BN_SLAB;
+    const int r = (N + 511) / 512;
+    return (r + BN_SLAB - 1) / BN_SLAB * BN_SLAB;
+}
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 
@@ -28,10 +35,10 @@ __device__ __forceinline__ float nn_act_grad_from_y(int act, float y) {
 // partial (sum a, sum a*b) per slab and channel; a = f(row, c), b = g(row, c).  Thread t owns channel (t % C) when C <= 256 (C divides
 // 256), channels t and t + 256 when C == 512: consecutive threads read consecutive addresses.
 template <class F>
-__device__ __forceinline__ void slab_reduce(int N, int C, double* part, F f) {
+__device__ __forceinline__ void slab_reduce(int N, int C, double* part, int slab_rows, F f) {
     __shared__ double red[2][256];
     const int slab = blockIdx.x, t = threadIdx.x;
-    const long long e0 = (long long)slab * BN_SLAB * C, e1 = min((long long)(slab + 1) * BN_SLAB, (long long)N) * C;
+    const long long e0 = (long long)slab * slab_rows * C, e1 = min((long long)(slab + 1) * slab_rows, (long long)N) * C;
     const int nacc = C > 256 ? C / 256 : 1;
     for (int a = 0; a < nacc; ++a) {
         double s0 = 0.0, s1 = 0.0;      // fp64 from the first add: a scalar gradient such as first_bn.weight cancels 1e4 : 1
@@ -61,8 +68,8 @@ __device__ __forceinline__ void slab_reduce(int N, int C, double* part, F f) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, double* __restrict__ part) {
-    slab_reduce(N, C, part, [&](long long e, int, float& u, float& v) { const float a = x[e]; u = a; v = a * a; });
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, double* __restrict__ part, int slab_rows) {
+    slab_reduce(N, C, part, slab_rows, [&](long long e, int, float& u, float& v) { const float a = x[e]; u = a; v = a * a; });
 }
 
 // mean / rstd from the slab partials (training) or from the running statistics (eval); training also updates the running
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // backward, pass 1: per slab and channel (sum dz, sum dz * xhat) with dz = dy * act'(y)
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C, int act,
-                                                           double* __restrict__ part) {
-    slab_reduce(N, C, part, [&](long long e, int c, float& u, float& v) {
+                                                           double* __restrict__ part, int slab_rows) {
+    slab_reduce(N, C, part, slab_rows, [&](long long e, int c, float& u, float& v) {
         const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
         u = dz; v = dz * (x[e] - mean[c]) * rstd[c];
     });
@@ -265,7 +272,7 @@ bool bn_channels_ok(int C) { return C >= 1 && (C == 512 || (C <= 256 && 256 % C 
 
 }  // namespace
 
-extern "C" int scl_bn_nslabs(int N) { return (N + BN_SLAB - 1) / BN_SLAB; }
+extern "C" int scl_bn_nslabs(int N) { const int r = bn_slab_rows(N); return (N + r - 1) / r; }
 
 extern "C" int scl_bn_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                           long long* num_batches_tracked, int training, float momentum, float eps, int act, float* part, float* mean,
@@ -276,7 +283,7 @@ extern "C" int scl_bn_fwd(const float* x, int N, int C, const float* gamma, cons
     SCL_REQUIRE(act >= 0 && act <= 2, "bn_fwd: act");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = scl_bn_nslabs(N);
-    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, s, x, N, C, (double*)part);
+    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, s, x, N, C, (double*)part, bn_slab_rows(N));
     hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, N, C, eps, momentum, training, running_mean, running_var,
                        num_batches_tracked, mean, rstd);
     const RowMap map = {m_W > 0 ? m_W : 1, m_HW > 0 ? m_HW : 1, m_bs, m_rs, m_cs, m_base};
@@ -291,7 +298,7 @@ extern "C" int scl_bn_bwd(const float* dy, const float* y, const float* x, const
     SCL_REQUIRE(act == 0 || y, "bn_bwd: the activation gradient needs the forward output y");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = scl_bn_nslabs(N);
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, (double*)part);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, (double*)part, bn_slab_rows(N));
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, C, dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, dy, y, x, mean, rstd, gamma, sums, (long long)N * C, N, C,
                        act, training, dx);
