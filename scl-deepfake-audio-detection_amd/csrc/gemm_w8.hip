@@ -150,7 +150,7 @@ __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4]
     // code: unrolling the epilogue to keep R in registers slowed every variant, R or not, by 20-36 us).  bf16 R: batches of four
     // rows in the wave's 4 KiB above the transposition blocks.  f32 R (twice the bytes): rows 0-1 and 2-3 there, rows 4-7 in the
     // first half of the wave's own transposition block, whose rows have been consumed by then.
-    const bool r_dma = rmode && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
+    const bool r_dma = rmode && d.vec_ok && !(d.debug & 2) && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
     __amdgpu_buffer_rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(r_dma ? d.R : d.C));
     const char* rstage = wextra;
     for (int i = 0; i < 2 * nmt; ++i) {
@@ -601,6 +601,12 @@ int scl_gemm_read_stamps(unsigned long long* out, int nblocks) {
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s) {
     k.tile_m = plan.tile_m;
     k.debug = 0;
+    {   // the epilogue stages R through buffer loads with 32-bit byte offsets: fall back to plain loads for an R extent >= 4 GiB
+        const long long nb1 = zdim / ((long long)k.nb2 * k.splitk);
+        const long long rows = k.M - 1, rpb = (long long)k.c_rpb;
+        const long long maxoff = (nb1 - 1) * k.c_bs1 + ((long long)k.nb2 - 1) * k.c_bs2 + (rows / rpb) * k.c_rbstride + (rows % rpb) * k.ldc + k.N;
+        if (maxoff * ((k.flags & SCL_GEMM_R_F32) ? 4 : 2) >= 0xFFFFFF00ll) k.debug |= 2;
+    }
     const dim3 grid((unsigned)plan.tiles, 1, (unsigned)zdim);
     // 1: single barrier per K step, 0: two-barrier ping-pong.  A/B on MI355X (profiles/r2_gemm_ab.txt): equal within 3 % on the forward
     // and dgrad shapes (single barrier ahead), the ping-pong 2-9 % ahead when both operands are transposed (wgrads: twice the LDS
