@@ -49,6 +49,9 @@ int scl_stream_wait_stream(void* waiter, void* signaler);
 #define SCL_KID_AUG  1   /* the RawBoost chain: scl_fir_multi_f32, scl_clip_stats_f32, scl_isd_scatter_f32, scl_clip_affine_f32 */
 #define SCL_KID_MAX  8
 int scl_prof_enable(int kid, int on);
+/* create n_pairs event pairs ahead of time: the first profiled step would otherwise pay hipEventCreate for every launch inside the
+ * timed region (bench.py: 335 launches, ~30 ms) */
+int scl_prof_reserve(int kid, int n_pairs);
 int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops);
 
 /* ------------------------------------------------------------------------------------------ */

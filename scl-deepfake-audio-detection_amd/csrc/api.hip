@@ -64,6 +64,18 @@ extern "C" int scl_prof_enable(int kid, int on) {
     return SCL_OK;
 }
 
+extern "C" int scl_prof_reserve(int kid, int n_pairs) {
+    SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX && n_pairs >= 0 && n_pairs <= 65536, "prof: bad reserve (%d, %d)", kid, n_pairs);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    while ((int)st.pool.size() < n_pairs) {
+        ProfPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return SCL_ELAUNCH;
+        st.pool.push_back(p);
+    }
+    return SCL_OK;
+}
+
 extern "C" int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops) {
     SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX, "prof: bad kernel id %d", kid);
     std::lock_guard<std::mutex> lk(g_prof_mu);

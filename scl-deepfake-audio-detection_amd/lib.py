@@ -67,6 +67,7 @@ def _protos():
         "scl_version": ([], _i32),
         "scl_last_error": ([], ctypes.c_char_p),
         "scl_prof_enable": ([_i32, _i32], _i32),
+        "scl_prof_reserve": ([_i32, _i32], _i32),
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),

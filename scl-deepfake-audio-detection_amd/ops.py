@@ -209,6 +209,10 @@ def prof_enable(kid, on):
     _call("scl_prof_enable", kid, 1 if on else 0)
 
 
+def prof_reserve(kid, n_pairs):
+    _call("scl_prof_reserve", kid, n_pairs)
+
+
 def prof_read(kid):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     _call("scl_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
