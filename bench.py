@@ -41,8 +41,8 @@ FLOP_PER_UTT_STEP_64000 = 444e9  # 74.0 GMAC forward x 2 x 3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (configs[2]: 64; configs[1]: 32)")
     ap.add_argument("--samples", type=int, default=64000)
     ap.add_argument("--rawboost", type=int, default=5, help="RawBoost algo applied on the GPU inside the step (configs[2]: 5; 0 = off)")
