@@ -7,7 +7,7 @@ python3 bench.py > gpurun_out/bench_default.log 2>&1
 grep '^{"metric"' gpurun_out/bench_default.log | tail -1 > gpurun_out/r2_bench_default.json
 python3 bench.py --batch 32 --rawboost 0 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/r2_bench_b32_norawboost.json
 rm -rf gpurun_out/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_final_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 > gpurun_out/prof_final_bench.log 2>&1
 grep '^{"metric"' gpurun_out/prof_final_bench.log | tail -1 > gpurun_out/r2_bench_under_rocprof.json
 find gpurun_out/prof_final -name "*kernel_stats.csv" -exec cp {} gpurun_out/r2_bench_default_kernel_stats.csv \;
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
@@ -36,7 +36,7 @@ PY
 for m in wav2vec2_aasist wav2vec2_resnet_nll; do
 python3 bench.py --no-cpu-baseline --model $m --batch 32 --rawboost 0 --steps 6 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/r2_bench_$m.json
 rm -rf gpurun_out/prof_$m
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -o bench -- python3 bench.py --no-cpu-baseline --model $m --batch 32 --rawboost 0 --steps 6 > gpurun_out/prof_$m.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -o bench -- python3 bench.py --no-cpu-baseline --model $m --batch 32 --rawboost 0 --steps 6 --warmup 2 > gpurun_out/prof_$m.log 2>&1
 find gpurun_out/prof_$m -name "*kernel_stats.csv" -exec cp {} gpurun_out/r2_bench_${m}_kernel_stats.csv \;
 grep '^{"metric"' gpurun_out/prof_$m.log | tail -1 > gpurun_out/r2_bench_${m}_under_rocprof.json
 rm -rf gpurun_out/prof_$m
