@@ -34,7 +34,10 @@ ProfState g_prof[SCL_KID_MAX];
 std::mutex g_prof_mu;
 }  // namespace
 
-SclProfScope::SclProfScope(int kid_, hipStream_t s_, double flops) : kid(kid_), s(s_), slot(nullptr) {
+thread_local SclProfScope* scl_prof_active = nullptr;
+
+SclProfScope::SclProfScope(int kid_, hipStream_t s_, double flops, bool dispatch_)
+    : kid(kid_), s(s_), slot(nullptr), ea(nullptr), eb(nullptr), dispatch(dispatch_), taken(false) {
     if (kid < 0 || kid >= SCL_KID_MAX || !g_prof[kid].on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfState& st = g_prof[kid];
@@ -44,14 +47,18 @@ SclProfScope::SclProfScope(int kid_, hipStream_t s_, double flops) : kid(kid_), 
     st.used.push_back(p);
     st.flops += flops;
     slot = (void*)(uintptr_t)st.used.size();  // index + 1
-    hipEventRecord(p.a, s);
+    ea = p.a; eb = p.b;
+    if (dispatch) scl_prof_active = this;      // the launch inside the scope takes the two events itself
+    else hipEventRecord(p.a, s);
 }
 SclProfScope::~SclProfScope() {
+    if (dispatch && scl_prof_active == this) scl_prof_active = nullptr;
     if (!slot) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfState& st = g_prof[kid];
-    const size_t idx = (size_t)(uintptr_t)slot - 1;
-    if (idx < st.used.size()) hipEventRecord(st.used[idx].b, s);
+    if (dispatch) {
+        if (!taken) { hipEventRecord(ea, s); hipEventRecord(eb, s); }      // no launch went through SCL_LAUNCH: an empty interval
+        return;
+    }
+    hipEventRecord(eb, s);
 }
 
 extern "C" int scl_version(void) { return 100; }

@@ -1,6 +1,7 @@
 // common.h — shared device helpers for the gfx950 kernels (wave = 64 lanes, CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/scl_hip.h"
@@ -134,9 +135,25 @@ int  scl_check_launch(const char* what);
 
 struct SclProfScope {  // brackets a launch with two events when profiling of `kid` is on
     int kid; hipStream_t s; void* slot;
-    SclProfScope(int kid, hipStream_t s, double flops);
+    hipEvent_t ea, eb;      // dispatch mode: handed to the ONE kernel launch of the scope (SCL_LAUNCH) as its start / stop events
+    bool dispatch, taken;
+    SclProfScope(int kid, hipStream_t s, double flops, bool dispatch = false);
     ~SclProfScope();
 };
+// The scope a launch on this thread belongs to (dispatch mode only).  The kernel's own dispatch packet then carries the two time
+// stamps (hipExtLaunchKernelGGL) instead of two hipEventRecord barrier packets around it, which cost ~20 us of queue bubble each
+// — 13 ms over the 330 GEMM launches of bench.py's profiled step.
+extern thread_local SclProfScope* scl_prof_active;
+#define SCL_LAUNCH(kern, grid, block, lds, stream, ...)                                                                     \
+    do {                                                                                                                    \
+        SclProfScope* ps_ = scl_prof_active;                                                                                \
+        if (ps_ && ps_->slot && !ps_->taken) {                                                                              \
+            ps_->taken = true;                                                                                              \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ps_->ea, ps_->eb, 0, __VA_ARGS__);                        \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                \
+        }                                                                                                                   \
+    } while (0)
 
 #define SCL_REQUIRE(cond, ...)                     \
     do {                                           \

@@ -752,13 +752,13 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;
     if (f32ab) {
-        SclProfScope prof(SCL_KID_GEMM_F32, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
+        SclProfScope prof(SCL_KID_GEMM_F32, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2, true);
         const int rc = scl_gemm_f32_launch(d, k, s);
         if (rc != SCL_OK) return rc;
         return scl_check_launch("scl_gemm_bf16(f32 operands)");
     }
     {
-        SclProfScope prof(SCL_KID_GEMM, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2);
+        SclProfScope prof(SCL_KID_GEMM, s, 2.0 * d.M * d.N * (double)d.K * d.nb1 * d.nb2, true);
         // LDS-DMA staging cannot mask a partially valid 16-byte vector: use it only when none can occur
         const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
         const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
@@ -789,10 +789,10 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
                 p8_attr_set = true;
             }
             dim3 pgrid((unsigned)(p8_tiles / zdim), 1, (unsigned)zdim), pblock(512);
-            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<false, false>), pgrid, pblock, P8_LDS, s, k);
-            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<false, true>), pgrid, pblock, P8_LDS, s, k);
-            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_p8_kernel<true, false>), pgrid, pblock, P8_LDS, s, k);
-            else hipLaunchKernelGGL((scl_gemm_p8_kernel<true, true>), pgrid, pblock, P8_LDS, s, k);
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_p8_kernel<false, false>), pgrid, pblock, P8_LDS, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_p8_kernel<false, true>), pgrid, pblock, P8_LDS, s, k);
+            else if (at && !bt) SCL_LAUNCH((scl_gemm_p8_kernel<true, false>), pgrid, pblock, P8_LDS, s, k);
+            else SCL_LAUNCH((scl_gemm_p8_kernel<true, true>), pgrid, pblock, P8_LDS, s, k);
         } else if (big) {
             static bool attr_set = false;
             if (!attr_set) {
@@ -803,20 +803,20 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
                 attr_set = true;
             }
             dim3 bgrid(((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN), 1, (unsigned)zdim), bblock(512);
-            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_big_kernel<false, false>), bgrid, bblock, BIG_LDS, s, k);
-            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_big_kernel<false, true>), bgrid, bblock, BIG_LDS, s, k);
-            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_big_kernel<true, false>), bgrid, bblock, BIG_LDS, s, k);
-            else hipLaunchKernelGGL((scl_gemm_big_kernel<true, true>), bgrid, bblock, BIG_LDS, s, k);
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_big_kernel<false, false>), bgrid, bblock, BIG_LDS, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_big_kernel<false, true>), bgrid, bblock, BIG_LDS, s, k);
+            else if (at && !bt) SCL_LAUNCH((scl_gemm_big_kernel<true, false>), bgrid, bblock, BIG_LDS, s, k);
+            else SCL_LAUNCH((scl_gemm_big_kernel<true, true>), bgrid, bblock, BIG_LDS, s, k);
         } else if (dma) {
-            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);
-            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<false, true>), grid, block, lds, s, k);
-            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_dma_kernel<true, false>), grid, block, lds, s, k);
-            else hipLaunchKernelGGL((scl_gemm_dma_kernel<true, true>), grid, block, lds, s, k);
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_dma_kernel<false, true>), grid, block, lds, s, k);
+            else if (at && !bt) SCL_LAUNCH((scl_gemm_dma_kernel<true, false>), grid, block, lds, s, k);
+            else SCL_LAUNCH((scl_gemm_dma_kernel<true, true>), grid, block, lds, s, k);
         } else {
-            if (!at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<false, false>), grid, block, lds, s, k);
-            else if (!at && bt) hipLaunchKernelGGL((scl_gemm_kernel<false, true>), grid, block, lds, s, k);
-            else if (at && !bt) hipLaunchKernelGGL((scl_gemm_kernel<true, false>), grid, block, lds, s, k);
-            else hipLaunchKernelGGL((scl_gemm_kernel<true, true>), grid, block, lds, s, k);
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_kernel<false, false>), grid, block, lds, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_kernel<false, true>), grid, block, lds, s, k);
+            else if (at && !bt) SCL_LAUNCH((scl_gemm_kernel<true, false>), grid, block, lds, s, k);
+            else SCL_LAUNCH((scl_gemm_kernel<true, true>), grid, block, lds, s, k);
         }
     }
     return scl_check_launch("scl_gemm_bf16");

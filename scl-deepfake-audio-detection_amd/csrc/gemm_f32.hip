@@ -213,10 +213,10 @@ void f32_launch(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     const dim3 block(256);
-    if (!at && !bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, false, false>), grid, block, lds, s, k);
-    else if (!at && bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, false, true>), grid, block, lds, s, k);
-    else if (at && !bt) hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, true, false>), grid, block, lds, s, k);
-    else hipLaunchKernelGGL((scl_gemm_f32_kernel<TM, true, true>), grid, block, lds, s, k);
+    if (!at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, false>), grid, block, lds, s, k);
+    else if (!at && bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, true>), grid, block, lds, s, k);
+    else if (at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, false>), grid, block, lds, s, k);
+    else SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, true>), grid, block, lds, s, k);
 }
 
 }  // namespace

@@ -553,16 +553,16 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
     }
     const dim3 block(512);
     if (mode == 1) {
-        if (!at && !bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-        else if (!at && bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
-        else if (at && !bt) hipLaunchKernelGGL((scl_gemm_w8s_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-        else hipLaunchKernelGGL((scl_gemm_w8s_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+        if (!at && !bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else if (!at && bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else if (at && !bt) SCL_LAUNCH((scl_gemm_w8s_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else SCL_LAUNCH((scl_gemm_w8s_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
         return;
     }
-    if (!at && !bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-    else if (!at && bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
-    else if (at && !bt) hipLaunchKernelGGL((scl_gemm_w8_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-    else hipLaunchKernelGGL((scl_gemm_w8_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+    if (!at && !bt) SCL_LAUNCH((scl_gemm_w8_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+    else if (!at && bt) SCL_LAUNCH((scl_gemm_w8_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+    else if (at && !bt) SCL_LAUNCH((scl_gemm_w8_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+    else SCL_LAUNCH((scl_gemm_w8_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
 }
 
 }  // namespace
