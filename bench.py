@@ -95,6 +95,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # The wide GEMMs launch 248 one-per-CU blocks (all of a CU's LDS each), which leaves 8 of the 256 CUs to the gradient
+        # exchange that overlaps the backward: RCCL is asked for at most 8 channels (one persistent block each) unless the
+        # environment says otherwise — with more, its blocks take CUs the next GEMM launch counts on (a second round).
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         # "nccl" is RCCL on ROCm.  SCL_BENCH_BACKEND=gloo + SCL_BENCH_ONE_DEVICE=1 rehearse the N > 1 code path on a one-GPU box
         dist.init_process_group(os.environ.get("SCL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -227,7 +231,7 @@ def main():
     if sync is not None:
         # self-diagnosing multi-GPU line: ranks, buckets, when each all-reduce was issued relative to the end of the backward and
         # how long the optimizer waited for the last one (the exposed part of the exchange)
-        res["rccl"] = dict(sync.report() or {}, rccl_ranks=world, backend=torch.distributed.get_backend(), gemm_cus=os.environ.get("SCL_GEMM_CUS", "256"),
+        res["rccl"] = dict(sync.report() or {}, rccl_ranks=world, backend=torch.distributed.get_backend(), gemm_cus=os.environ.get("SCL_GEMM_CUS", "256"), nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"),
                            grad_bytes_per_step=(g_hi - g_lo) * (2 if sync.wire == "bf16" else 4))
     if world == 1 and not args.no_cpu_baseline and args.model == "wav2vec2_linear_nll":
         res["cpu_baseline"] = cpu_baseline(args)

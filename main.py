@@ -219,6 +219,7 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")      # 248 one-per-CU GEMM blocks + 8 RCCL channels = the 256 CUs (see bench.py)
         torch.distributed.init_process_group("nccl")
     os.makedirs("out", exist_ok=True)
     torch.manual_seed(args.seed)
