@@ -50,14 +50,25 @@ def parse():
                     help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet are extra workloads")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
+
+
+def gemm_source_sha():
+    """Fingerprint of the GEMM kernel sources: a committed PMC pass is quoted only for the sources it was taken with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "scl-deepfake-audio-detection_amd", "csrc", "gemm*"))):
+        if f.endswith((".hip", ".h")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(args):
     """Oracle CPU path (the restatement pinned to the reference) on a bounded sample: `cpu_batch` utterances of the same
     length — RawBoost per clip with the reference's own call sequence (one clip after the other, as a DataLoader worker
-    does), then one warm-up-free train step."""
+    does), then one DISCARDED train step (thread pool, allocator and oneDNN primitive caches warm) and one timed train step."""
     import numpy as np
     from oracle import head as OH
     from oracle import rawboost as RB
@@ -74,11 +85,14 @@ def cpu_baseline(args):
         xa = np.stack([RB.process_rawboost_feature(x[i].numpy(), 16000, RB.RawBoostArgs(), args.rawboost) for i in range(B)])
         x = torch.from_numpy(xa.astype(np.float32))
         t_aug = time.time() - t0
+    OH.train_step(ssl, head, cfg, x, y)          # discarded
+    t1 = time.time()
     OH.train_step(ssl, head, cfg, x, y)
-    dt = time.time() - t0
+    t_step = time.time() - t1
+    dt = t_aug + t_step
     return {"value": B / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d x %d-sample clips: oracle RawBoost algo %d per clip on 1 core (%.2f s) + 1 train step (fwd+loss+bwd+AdamW, fp32 "
-                      "torch CPU oracle, %d threads), %.1f s in all" % (B, args.samples, args.rawboost, t_aug, torch.get_num_threads(), dt)}
+            "sample": "%d x %d-sample clips: oracle RawBoost algo %d per clip on 1 core (%.2f s) + the second of 2 train steps (fwd+loss+bwd+AdamW, "
+                      "fp32 torch CPU oracle, %d threads; %.1f s), the first discarded" % (B, args.samples, args.rawboost, t_aug, torch.get_num_threads(), t_step)}
 
 
 def main():
@@ -95,10 +109,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # The wide GEMMs launch 248 one-per-CU blocks (all of a CU's LDS each), which leaves 8 of the 256 CUs to the gradient
-        # exchange that overlaps the backward: RCCL is asked for at most 8 channels (one persistent block each) unless the
-        # environment says otherwise — with more, its blocks take CUs the next GEMM launch counts on (a second round).
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+        # SCL_RCCL_CHANNELS=<n> caps RCCL's persistent blocks (NCCL_MAX_NCHANNELS) so that they and the one-per-CU GEMM blocks share the
+        # 256 CUs (pair it with SCL_GEMM_CUS=256-n); opt-in: no multi-GPU A/B backs a default, and few channels can cap xGMI bandwidth
+        if os.environ.get("SCL_RCCL_CHANNELS"):
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ["SCL_RCCL_CHANNELS"])
         # "nccl" is RCCL on ROCm.  SCL_BENCH_BACKEND=gloo + SCL_BENCH_ONE_DEVICE=1 rehearse the N > 1 code path on a one-GPU box
         dist.init_process_group(os.environ.get("SCL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -191,12 +205,14 @@ def main():
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # HBM traffic per GEMM launch cannot be read live (PMC needs rocprofv3): take it from the committed counter pass of this
-    # same command (profiles/r2_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), else null
+    # same command (profiles/r3_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
+    # while the GEMM sources are the ones that pass was taken with (its "gemm_src_sha"), else null
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")) as f:
             pmc = json.load(f)
-        if B == pmc.get("batch", 32) and L == 64000 and not args.tiny and args.model == "wav2vec2_linear_nll":
+        if (B == pmc.get("batch", 32) and L == 64000 and not args.tiny and args.model == "wav2vec2_linear_nll"
+                and pmc.get("gemm_src_sha") == gemm_source_sha()):
             traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
     except (OSError, KeyError, ValueError):
         traffic = None

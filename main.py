@@ -154,7 +154,7 @@ def produce_prediction_file(dataset, model, device, save_path, batch_size=10):
     print("Scores saved to {}".format(save_path))
 
 
-def produce_emb_file(dataset, model, device, save_path, batch_size=10):
+def produce_emb_file(dataset, model, device, save_path, batch_size=10, scores_name="scores.txt"):
     """<save_path>/<utt>.npy embeddings + scores.txt (reference main.py:120-159)."""
     model.is_train = True
     os.makedirs(save_path, exist_ok=True)
@@ -163,7 +163,7 @@ def produce_emb_file(dataset, model, device, save_path, batch_size=10):
         out, _, emb = res
         for f, e in zip(ids, emb):
             np.save(os.path.join(save_path, f.split("/")[-1].split(".")[0]), e.cpu().numpy())
-        with open(os.path.join(save_path, "scores.txt"), "a+") as fh:
+        with open(os.path.join(save_path, scores_name), "a+") as fh:
             for f, cm in zip(ids, out.cpu().numpy().tolist()):
                 fh.write("{} {} {}\n".format(f, cm[0], cm[1]))
     _score_loop(dataset, model, device, batch_size, emit)
@@ -176,6 +176,9 @@ def merge_rank_outputs(path, world, n_items):
     for r in range(world):
         with open("%s.rank%d" % (path, r)) as fh:
             shards.append(fh.read().splitlines())
+        want = len(range(r, n_items, world))
+        if len(shards[r]) != want:      # a shard of an aborted run that was appended to, or a rank that died: never merge it silently
+            raise RuntimeError("%s.rank%d holds %d lines, expected %d" % (path, r, len(shards[r]), want))
     with open(path, "a+") as out:
         for i in range(n_items):
             out.write(shards[i % world][i // world] + "\n")
@@ -219,7 +222,8 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")      # 248 one-per-CU GEMM blocks + 8 RCCL channels = the 256 CUs (see bench.py)
+        if os.environ.get("SCL_RCCL_CHANNELS"):      # opt-in cap on RCCL's persistent blocks (no multi-GPU A/B backs a default)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ["SCL_RCCL_CHANNELS"])
         torch.distributed.init_process_group("nccl")
     os.makedirs("out", exist_ok=True)
     torch.manual_seed(args.seed)
@@ -275,18 +279,23 @@ def main(argv=None):
         final_output = args.eval_output
         if world > 1:
             eval_set = Subset(eval_set, list(range(rank, len(eval_set), world)))
-            if not args.emb:          # per-rank score shards, merged below in protocol order (embeddings are one file per utterance)
-                args.eval_output = "%s.rank%d" % (final_output, rank)
+            # per-rank score shards, merged below in protocol order (embeddings are one file per utterance; their scores.txt is a shard too)
+            shard = "%s.rank%d" % (os.path.join(final_output, "scores.txt") if args.emb else final_output, rank)
+            if os.path.exists(shard):       # left behind by an aborted run: the writers append
+                os.remove(shard)
+            if not args.emb:
+                args.eval_output = shard
         if args.predict:
             produce_prediction_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
         elif args.emb:
-            produce_emb_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
+            produce_emb_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size,
+                             scores_name="scores.txt.rank%d" % rank if world > 1 else "scores.txt")
         else:
             produce_evaluation_file(eval_set, model, device, args.eval_output, batch_size=args.batch_size)
-        if world > 1 and not args.emb:
+        if world > 1:
             torch.distributed.barrier()
             if rank == 0:
-                merge_rank_outputs(final_output, world, len(file_eval))
+                merge_rank_outputs(os.path.join(final_output, "scores.txt") if args.emb else final_output, world, len(file_eval))
         return 0
 
     repeat = args.padding_type == "repeat"

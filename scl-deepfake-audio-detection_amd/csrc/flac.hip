@@ -241,6 +241,7 @@ bool decode_subframe(Bits& br, int32_t* s, int blocksize, int bps) {
 }
 
 // one frame starting at byte `pos`; appends blocksize x channels interleaved samples to out[written...]
+constexpr int FLAC_ENOSPC = -100;      // internal: the frame is sound but does not fit the caller's buffer
 int decode_frame(const uint8_t* p, size_t n, size_t* pos, const StreamInfo& si, std::vector<int32_t>& ch, int32_t* out, int64_t capacity,
                  int64_t* written, int* frame_bps) {
     Bits br(p + *pos, n - *pos);
@@ -271,7 +272,7 @@ int decode_frame(const uint8_t* p, size_t n, size_t* pos, const StreamInfo& si, 
     br.align();
     const size_t hdr_len = br.byte_pos();
     const uint32_t c8 = br.read(8);
-    if (br.bad || crc8(p + *pos, hdr_len) != c8) return SCL_EINVAL;
+    if (br.bad || *pos + hdr_len + 1 > n || crc8(p + *pos, hdr_len) != c8) return SCL_EINVAL;      // header (+ its CRC byte) inside the buffer
     int nch, mode = 0;                            // mode 1 left/side, 2 side/right, 3 mid/side
     if (ch_code < 8) nch = ch_code + 1; else if (ch_code <= 10) { nch = 2; mode = ch_code - 7; } else return SCL_EINVAL;
     if (nch != si.channels) return SCL_EINVAL;
@@ -293,7 +294,7 @@ int decode_frame(const uint8_t* p, size_t n, size_t* pos, const StreamInfo& si, 
         const int32_t mid = (int32_t)(((uint32_t)a[i] << 1) | (uint32_t)(side & 1));
         a[i] = (mid + side) >> 1; b[i] = (mid - side) >> 1;
     }
-    if (*written + blocksize > capacity) return SCL_EINVAL;
+    if (*written + blocksize > capacity) return FLAC_ENOSPC;
     for (int c = 0; c < nch; ++c) {
         const int32_t* src = ch.data() + (size_t)c * blocksize;
         int32_t* dst = out + *written * nch + c;
@@ -329,9 +330,12 @@ extern "C" int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* ou
     while (pos + 2 <= n && (si.total == 0 || written < si.total)) {
         if (!(p[pos] == 0xFF && (p[pos + 1] & 0xFE) == 0xF8)) break;      // trailing bytes that are not a frame (e.g. an ID3v1 tag)
         const int rc = decode_frame(p, n, &pos, si, ch, out, capacity_samples, &written, &bps);
+        if (rc == FLAC_ENOSPC) {      // told apart from a corrupt frame: a caller that could not size the output (STREAMINFO total = 0) grows it and retries
+            scl_set_error("flac_decode: output too small (%lld samples per channel hold the stream only up to byte %zu)", (long long)capacity_samples, pos);
+            return SCL_EINVAL;
+        }
         if (rc != SCL_OK) {
-            scl_set_error("flac_decode: corrupt frame at byte %zu (sample %lld): sync / CRC / reserved-field check failed, or the output is too small",
-                          pos, (long long)written);
+            scl_set_error("flac_decode: corrupt frame at byte %zu (sample %lld): sync / CRC / reserved-field check failed", pos, (long long)written);
             return rc;
         }
     }

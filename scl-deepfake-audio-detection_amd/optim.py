@@ -24,11 +24,12 @@ class _StepOverlap:
 
     def __init__(self, opt, seg_elems=16 * 1024 * 1024):
         self.opt = opt
-        n = opt.P.n_train
+        # the trainable range only: under flag_fix_ssl the frozen encoder gets neither weight decay nor Adam updates from a
+        # gradient slice nothing writes (torch.optim.AdamW skips parameters whose .grad is None)
+        lo0, hi = opt.model.trainable_range() if hasattr(opt.model, "trainable_range") else (0, opt.P.n_train)
         self.bounds = []
-        hi = n
-        while hi > 0:
-            lo = max(0, hi - seg_elems)
+        while hi > lo0:
+            lo = max(lo0, hi - seg_elems)
             self.bounds.append((lo, hi))
             hi = lo
         self.side = torch.cuda.Stream(device=opt.P.device)

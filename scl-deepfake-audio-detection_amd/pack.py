@@ -63,10 +63,18 @@ def _read_flac(path):
     buf = ctypes.create_string_buffer(raw, len(raw))
     fs, ch, bits, total = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
     L.check(lib.scl_flac_info(buf, len(raw), ctypes.byref(fs), ctypes.byref(ch), ctypes.byref(bits), ctypes.byref(total)), "scl_flac_info(%s)" % path)
-    cap = total.value if total.value > 0 else len(raw) * 16         # unknown length: no FLAC stream expands 128-fold per byte
-    out = np.empty((cap, ch.value), dtype=np.int32)
+    # STREAMINFO without a length (streamed encoders): a CONSTANT / silence frame expands without bound per byte, so the output
+    # grows until the decoder stops reporting "too small" (it writes nothing past the capacity it is given)
+    cap = total.value if total.value > 0 else max(len(raw) * 16, 1 << 16)
     got = ctypes.c_int64(0)
-    L.check(lib.scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got), 1), "scl_flac_decode_i32(%s)" % path)
+    while True:
+        out = np.empty((cap, ch.value), dtype=np.int32)
+        rc = lib.scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got), 1)
+        if rc != 0 and total.value <= 0 and cap < (1 << 31) and b"output too small" in (lib.scl_last_error() or b""):
+            cap *= 8
+            continue
+        L.check(rc, "scl_flac_decode_i32(%s)" % path)
+        break
     x = out[: got.value].astype(np.float32) / np.float32(1 << (bits.value - 1))
     return (x.mean(axis=1) if ch.value > 1 else x[:, 0]), fs.value
 
@@ -75,9 +83,11 @@ def load_audio(path, sr=16000):
     """librosa.load(path, sr=sr, mono=True) stand-in for the formats this image can decode."""
     if _LOADER is not None:
         return np.asarray(_LOADER(path, sr), dtype=np.float32)
-    if path.lower().endswith(".wav"):
+    with open(path, "rb") as f:          # by content, not by name: the offline augmentation cache keeps the source file's name
+        magic = f.read(4)                # (augall_3:285-291 writes out_format='wav' bytes under it)
+    if magic == b"RIFF":
         x, fs = _read_wav(path)
-    elif path.lower().endswith(".flac"):
+    elif magic == b"fLaC":
         x, fs = _read_flac(path)
     else:
         try:
@@ -234,12 +244,9 @@ def _offline_cached(method, x, args, sr, audio_path, make, int16_values=False):
         y = y / 32768.0                   # the reference re-loads the file it just wrote with librosa.load (augall_3:288-291)
     else:
         pcm = np.clip(np.round(y.detach().cpu().numpy() * 32767.0), -32768, 32767).astype("<i2")
-    if aug_path.lower().endswith(".wav"):
-        with wave.open(aug_path, "wb") as w:
-            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
-    else:
-        import soundfile as sf
-        sf.write(aug_path, pcm, sr, subtype="PCM_16")
+    # PCM16 WAV bytes whatever the extension, as the reference's export(out_format='wav') does; load_audio() sniffs RIFF / fLaC
+    with wave.open(aug_path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
     return y
 
 

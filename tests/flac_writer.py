@@ -134,7 +134,7 @@ def _subframe(w, s, bps, kind, **kw):
         _residual(w, np.array(res, dtype=np.int64), n, order, kw.get("porder", 0), kw.get("rice2", False), kw.get("escape_parts", ()))
 
 
-def write_flac(x, sample_rate=16000, bps=16, blocksize=4096, plan=None, stereo_mode="independent", md5=True, id3=False):
+def write_flac(x, sample_rate=16000, bps=16, blocksize=4096, plan=None, stereo_mode="independent", md5=True, id3=False, unknown_total=False):
     """x: int array [n] or [n, channels].  plan(frame_index, channel) -> (kind, kwargs) picks the subframe coding."""
     x = np.asarray(x, dtype=np.int64)
     if x.ndim == 1:
@@ -188,7 +188,7 @@ def write_flac(x, sample_rate=16000, bps=16, blocksize=4096, plan=None, stereo_m
     digest = hashlib.md5(raw).digest() if md5 else b"\0" * 16
     si = BitWriter()
     si.put(blocksize, 16); si.put(blocksize, 16); si.put(0, 24); si.put(0, 24)
-    si.put(sample_rate, 20); si.put(nch - 1, 3); si.put(bps - 1, 5); si.put(n, 36)
+    si.put(sample_rate, 20); si.put(nch - 1, 3); si.put(bps - 1, 5); si.put(0 if unknown_total else n, 36)      # 0: a streamed encoder that never went back to fill it in
     head = b"fLaC" + bytes([0x00]) + (34).to_bytes(3, "big") + si.tobytes() + digest
     pad = bytes([0x81]) + (8).to_bytes(3, "big") + b"\0" * 8         # a PADDING block, flagged last
     tag = (b"ID3\x04\x00\x00" + bytes([0, 0, 0, 10]) + b"\0" * 10) if id3 else b""

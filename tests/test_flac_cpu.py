@@ -96,3 +96,50 @@ def test_load_audio_reads_flac_like_librosa(tmp_path):
     open(p2, "wb").write(write_flac(st, 48000, 16, 4096, stereo_mode="mid_side"))
     y2 = pack.load_audio(p2, 16000)                         # mono mix-down + 3:1 resampling
     assert abs(len(y2) - 16000 // 3) <= 1 and np.isfinite(y2).all()
+
+
+def test_truncation_inside_a_frame_header_is_an_error_not_an_overread():
+    x = speechlike(9000, 6)
+    raw = write_flac(x, 16000, 16, 4096)
+    first = raw.index(b"\xff\xf8", 4 + 4 + 34)                # sync code of frame 0
+    for cut in range(first + 2, first + 7):                   # every cut inside the header (before / at its CRC-8 byte)
+        tail = raw[:cut]
+        lib = L.load()
+        buf = ctypes.create_string_buffer(tail, len(tail))      # exact-size buffer: an over-read would leave it
+        out = np.empty((9000, 1), dtype=np.int32)
+        got = ctypes.c_int64(0)
+        assert lib.scl_flac_decode_i32(buf, len(tail), out.ctypes.data_as(ctypes.c_void_p), 9000, ctypes.byref(got), 0) != 0
+
+
+def test_stream_of_unknown_length_with_constant_frames_is_read_by_growing_the_output(tmp_path):
+    from scl_amd import pack
+    pack.set_audio_loader(None)
+    x = np.zeros(40 * 4096, dtype=np.int64)                    # digital silence: ~11 bytes per 4096-sample CONSTANT frame,
+    x[:4096] = speechlike(4096, 7)                            # far beyond any fixed samples-per-byte bound
+    raw = write_flac(x, 16000, 16, 4096, plan=lambda f, c: ("fixed", dict(order=2, porder=2)) if f == 0 else ("constant", {}), unknown_total=True)
+    assert len(raw) * 16 < len(x)
+    p = str(tmp_path / "streamed.flac")
+    open(p, "wb").write(raw)
+    y = pack.load_audio(p, 16000)
+    assert np.array_equal(y, (x / 32768.0).astype(np.float32))
+    buf = ctypes.create_string_buffer(raw, len(raw))
+    out = np.empty((4096, 1), dtype=np.int32)
+    got = ctypes.c_int64(0)
+    assert L.load().scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), 4096, ctypes.byref(got), 0) != 0
+    assert b"output too small" in L.load().scl_last_error()
+
+
+def test_offline_cache_keeps_the_source_name_but_holds_wav_bytes(tmp_path):
+    """online_aug: false on the .flac corpus (augall_3:285-291 exports out_format='wav' under the utterance's own name)."""
+    import types
+    import torch
+    from scl_amd import pack
+    pack.set_audio_loader(None)
+    args = types.SimpleNamespace(aug_dir=str(tmp_path), device="cpu")
+    y = torch.tensor([0.0, 1000.0, -32768.0, 32767.0, 12.0])
+    got = pack._offline_cached("reverb", None, args, 16000, "/corpus/LA_T_1.flac", lambda: y.clone(), int16_values=True)
+    cached = os.path.join(str(tmp_path), "reverb", "LA_T_1.flac")
+    assert open(cached, "rb").read(4) == b"RIFF"
+    assert torch.equal(got, y / 32768.0)
+    again = pack._offline_cached("reverb", None, args, 16000, "/corpus/LA_T_1.flac", lambda: 1 / 0, int16_values=True)   # a hit: make() not called
+    assert np.array_equal(np.asarray(again.cpu()), (y / 32768.0).numpy())
