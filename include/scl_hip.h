@@ -233,6 +233,12 @@ int scl_posconv_weight_bwd(const float* dwf, const float* v, const float* g, con
 int scl_meanpool_fwd(const void* h, float* emb, int B, int T, int C, void* stream);
 int scl_meanpool_bwd(const float* demb, const void* pre, void* dpre, int B, int T, int C, int ract, float drop_p,
                      uint32_t seed, void* stream);
+/* the same two with f32 frame-level activations: the training path keeps the 128-wide frame-level head (BackEnd.m_frame_level,
+ * model/wav2vec2_linear_nll.py:60-93) in f32 — its backward spreads ONE row per utterance over all T frames, and a bf16
+ * rounding of that row would be systematic over the T-row sums of the weight gradients instead of averaging out */
+int scl_meanpool_fwd_f32(const float* h, float* emb, int B, int T, int C, void* stream);
+int scl_meanpool_bwd_f32(const float* demb, const float* pre, float* dpre, int B, int T, int C, int ract, float drop_p,
+                         uint32_t seed, void* stream);
 int scl_utt_head_fwd(const float* emb, const float* W, const float* bias, float* logp, int B, int C, int NC, void* stream);
 int scl_utt_head_bwd(const float* dlogp, const float* logp, const float* emb, const float* W, const float* demb_in,
                      float* demb, float* dW, float* db, float* ws, int B, int C, int NC, void* stream);

@@ -1,10 +1,13 @@
 """ORACLE (test infrastructure).  pydub 0.25.1 / CPython audioop integer semantics and the two
 augmenters built on them.  Pinning: `reverb` and `librosa_to_int16` reproduce, bit for bit, vectors produced by the REFERENCE's
 own ReverbAugmentor.transform / librosa_to_pydub / pydub_to_librosa (tests/golden/audio_int16.npz, oracle/gen_golden.py::
-gen_audio_int16 — pydub.AudioSegment stood in by a bare sample container).  `rms_int` / `dbfs` / `apply_gain` / `overlay` /
-`background_noise` restate pydub's own arithmetic (AudioSegment.dBFS, apply_gain -> audioop.mul, overlay -> audioop.add), which
-cannot be executed here: PARITY UNPINNED w.r.t. pydub for those (restated from its published semantics).
-Anchored on the reference's call sites:
+gen_audio_int16 — pydub.AudioSegment stood in by a bare sample container).  `rms_int` / `apply_gain` / `overlay` are pinned to
+CPython 3.10's own `audioop.rms` / `audioop.mul` / `audioop.add` — the C code pydub 0.25.1 calls for them — executed in the build
+container on random, saturating, silent and extreme inputs, and `background_noise` to the chain of background_noise.py:40-56
+built from those real primitives (tests/golden/audioop.npz, gen_golden.py::gen_audioop; tests/test_oracle_golden.py).  What
+stays restated from pydub's published source because pydub itself is absent: that dBFS is 20 * log(rms / 32768, 10), that
+apply_gain passes 10 ** (dB / 20) to audioop.mul, and that overlay() adds from position 0 over min(len) samples (SURVEY.md
+Appendix B).  Anchored on the reference's call sites:
 
   datautils/audio_augmentor/utils.py:20-30      librosa_to_pydub / pydub_to_librosa
   datautils/audio_augmentor/reverb.py:33-44     ReverbAugmentor.transform
@@ -31,11 +34,12 @@ def rms_int(samples):
 
 
 def dbfs(samples):
-    """pydub AudioSegment.dBFS = 20*log10(rms / 32768); -inf when rms == 0."""
+    """pydub AudioSegment.dBFS = ratio_to_db(rms / max_possible_amplitude) = 20 * log(rms / 32768, 10) (pydub/utils.py spells the
+    base-10 logarithm as math.log(x, 10)); -inf when rms == 0."""
     r = rms_int(samples)
     if r == 0:
         return -float("inf")
-    return 20.0 * math.log10(r / 32768.0)
+    return 20 * math.log(r / 32768.0, 10)
 
 
 def apply_gain(samples, gain_db):

@@ -4,9 +4,13 @@ this image and from /root/reference:
   speed   datautils/audio_augmentor/speed.py:29-33   -> pydub 0.25.1 (00_envsetup.sh:48) AudioSegment.speedup(speed_factor)
   pitch   datautils/audio_augmentor/pitch.py:31-38   -> librosa 0.10.0 (00_envsetup.sh:45) effects.pitch_shift(data, sr, n_steps)
 
-PARITY UNPINNED: neither package can be imported here, so nothing below is checked against an execution of the reference; both
-are restatements of the packages' published algorithms, anchored on the reference's call sites above and on its converters
-(utils.py:20-30, pinned in oracle/audio_int16.py).
+PARITY PARTLY PINNED: neither package can be imported here.  The speed path's ARITHMETIC is pinned: pydub does it in CPython's
+`audioop` (mul / add), which is in this container's standard library — tests/golden/audioop.npz holds the whole speedup()
+sequence below executed with the real audioop.mul / audioop.add in place of `_mul` / `_add` (factors below and above 1, a
+speech-like and a full-scale clip; oracle/gen_golden.py::gen_audioop, tests/test_oracle_golden.py).  What remains a restatement
+of pydub's published source is the sequence itself (slicing, fade steps, looped overlay, append).  The pitch path (librosa)
+stays UNPINNED.  Both are anchored on the reference's call sites above and on its converters (utils.py:20-30, pinned in
+oracle/audio_int16.py).
 
 `Seg` restates the part of pydub.AudioSegment that speedup() touches, for mono 16-bit audio, statement by statement: millisecond
 slicing (`__getitem__`, `_parse_position`, rounded `len`), `fade` (one gain step per millisecond above 100 ms, per frame below),

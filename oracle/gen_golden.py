@@ -339,15 +339,26 @@ def gen_w2v_hf():
     out = {"x": x.numpy(), "hf_last_hidden": ho.last_hidden_state.numpy(),
            "hf_extract_features": ho.extract_features.numpy(), "seed": np.array(11)}
     np.savez_compressed(os.path.join(OUT, "w2v_tiny_hf.npz"), **out)
-    if os.environ.get("SCL_GOLDEN_FULL") == "1":  # in-container only: XLS-R-300M shape, 1 x 16000
-        cfg = W.W2VConfig()
-        sd = W.init_state(cfg, seed=12)
-        hf = hf_model(cfg)
-        hf.load_state_dict({k: v for k, v in W.to_hf_state(sd, cfg).items() if k in hf.state_dict()}, strict=False)
-        x = 0.1 * torch.randn(1, 16000, generator=g)
-        with torch.no_grad():
-            e = (W.forward(sd, cfg, x) - hf(x).last_hidden_state).abs().max().item()
-        print("full-size wav2vec2 vs HF max abs err: %.3e" % e)
+    # XLS-R-300M shape (24 x 1024, 16 heads of 64, ffn 4096, pos-conv k = 128 in 16 groups — the shapes the fused attention and
+    # positional-convolution kernels specialise on), 1 x 16000 samples, seeded random weights: a strided fingerprint of what
+    # transformers.Wav2Vec2Model returns (final output, conv features, a few hidden states)
+    cfg = W.W2VConfig()
+    sd = W.init_state(cfg, seed=12)
+    hf = hf_model(cfg)
+    hf.load_state_dict({k: v for k, v in W.to_hf_state(sd, cfg).items() if k in hf.state_dict()}, strict=False)
+    x = 0.1 * torch.randn(1, 16000, generator=torch.Generator().manual_seed(4321))
+    with torch.no_grad():
+        ho = hf(x, output_hidden_states=True)
+        e = (W.forward(sd, cfg, x) - ho.last_hidden_state).abs().max().item()
+    print("full-size wav2vec2 vs HF max abs err: %.3e (|out| max %.3f)" % (e, ho.last_hidden_state.abs().max().item()))
+    assert e < 2e-4
+    fp = {"x": x.numpy(), "seed": np.array(12), "last_hidden": ho.last_hidden_state[:, ::8, ::32].numpy(),
+          "last_hidden_absmax": np.array(ho.last_hidden_state.abs().max().item()),
+          "extract_features": ho.extract_features[:, ::8, ::16].numpy()}
+    for li in (0, 1, 12, 24):      # hidden_states[0] = after the positional convolution, [n] = after layer n (pre final LayerNorm)
+        fp["hidden%d" % li] = ho.hidden_states[li][:, ::8, ::32].numpy()
+    np.savez_compressed(os.path.join(OUT, "w2v_xlsr_hf.npz"), **fp)
+    print("w2v_xlsr_hf.npz", {k: v.shape for k, v in fp.items()})
 
 
 def gen_eer():
@@ -534,6 +545,57 @@ def gen_audio_int16():
     print("audio_int16.npz", len(out), "arrays")
 
 
+def gen_audioop():
+    """A8 + the speed augmenter: pydub (absent) does its integer arithmetic in CPython's `audioop` (rms / mul / add), which IS in
+    this container's standard library.  Vectors from the real module: the three primitives on random / saturating / silent /
+    extreme inputs, the MUSAN-overlay chain of background_noise.py:40-56 built from them, and pydub's speedup() sequence
+    (oracle.audio_speed_pitch.Seg) with its two arithmetic hooks swapped for the real audioop.mul / audioop.add."""
+    import audioop
+    import math
+    from oracle import audio_speed_pitch as SP
+    b = lambda a: np.asarray(a, dtype="<i2").tobytes()
+    u = lambda raw: np.frombuffer(raw, dtype="<i2").copy()
+    rs = np.random.RandomState(20261003)
+    L = 16000
+    t = np.arange(L)
+    speech = np.round(5000 * np.sin(2 * np.pi * t / 61.0) * np.sin(2 * np.pi * t / 2300.0) + 300 * rs.randn(L)).astype(np.int16)
+    inputs = {"speech": speech, "loud": rs.randint(-32768, 32768, L).astype(np.int16), "silent": np.zeros(L, np.int16),
+              "tiny": rs.randint(-2, 3, 4001).astype(np.int16), "extremes": np.tile(np.array([-32768, 32767, -1, 0, 1, -32767], np.int16), 500),
+              "one": np.array([-7], np.int16)}
+    factors = np.array([0.0, 1e-6, 0.5, 0.999, 1.0, 1.7, 3.3, 10 ** (-7.3 / 20), 10 ** (9.1 / 20), 10 ** (-120 / 20), 100.0, -0.75], np.float64)
+    out = {"factors": factors}
+    for name, x in inputs.items():
+        out["in:" + name] = x
+        out["rms:" + name] = np.array(audioop.rms(b(x), 2), np.int64)
+        out["mul:" + name] = np.stack([u(audioop.mul(b(x[:4000]), 2, float(f))) for f in factors])      # on the first 4000 samples
+        other = np.roll(inputs["loud"], 17)[: len(x)] if len(x) <= L else None
+        out["add:" + name] = u(audioop.add(b(x), b(other), 2))
+    out["rms:empty"] = np.array(audioop.rms(b"", 2), np.int64)
+    # background_noise.py:40-56 from the real primitives (dBFS as pydub.utils.ratio_to_db: 20 * log(rms / 32768, 10))
+    for tag, sp, noise, snr in (("bn0", speech, (inputs["loud"] // 9).astype(np.int16), 7), ("bn1", (speech // 3).astype(np.int16), inputs["loud"][:9000], 15),
+                                ("bn2", inputs["loud"], np.concatenate([speech, speech])[:24000], 5)):
+        db = lambda x: 20 * math.log(audioop.rms(b(x), 2) / 32768.0, 10)
+        gain = snr * db(noise) / db(sp)
+        g = u(audioop.mul(b(sp), 2, 10 ** (gain / 20.0)))
+        n = min(len(g), len(noise))
+        res = g.copy()
+        res[:n] = u(audioop.add(b(g[:n]), b(noise[:n]), 2))
+        out[tag + ":speech"], out[tag + ":noise"], out[tag + ":snr"], out[tag + ":gain"], out[tag + ":out"] = sp, noise, np.array(snr), np.array(gain), res
+    # pydub speedup() with audioop doing the arithmetic
+    keep = SP._mul, SP._add
+    SP._mul = lambda frames, factor: u(audioop.mul(b(frames), 2, float(factor)))
+    SP._add = lambda a, c: u(audioop.add(b(a), b(c), 2))
+    try:
+        for i, (src, fac) in enumerate((("speech", 0.9), ("speech", 0.9713), ("speech", 1.0461), ("speech", 1.1), ("loud", 0.93), ("loud", 1.08))):
+            x = inputs[src][:12000] if src == "loud" else inputs[src]
+            out["speed%d:in" % i], out["speed%d:factor" % i] = x, np.array(fac)
+            out["speed%d:out" % i] = SP.speedup(SP.Seg(x, 16000), fac).f
+    finally:
+        SP._mul, SP._add = keep
+    np.savez_compressed(os.path.join(OUT, "audioop.npz"), **out)
+    print("audioop.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
@@ -542,6 +604,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop)):
         if want(name):
             fn()

@@ -296,7 +296,7 @@ def to_int16(x):
 
 def _dbfs(sumsq, n):
     rms = math.isqrt(int(sumsq) // int(n)) if n else 0
-    return -float("inf") if rms == 0 else 20.0 * math.log10(rms / 32768.0)
+    return -float("inf") if rms == 0 else 20 * math.log(rms / 32768.0, 10)      # pydub.utils.ratio_to_db spells log10 this way
 
 
 def background_noise(x, noise_i16, snr_db):

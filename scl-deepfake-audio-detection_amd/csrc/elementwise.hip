@@ -223,14 +223,19 @@ __global__ void posconv_wbwd_apply_kernel(const float* __restrict__ dwf, const f
 // emb[b][c] = mean_t h[b][t][c]   (h bf16 [B,T,C])
 // 512 threads = 4 frame groups x 128 channel lanes: group g adds frames g, g + 4, ...; the four partial sums are combined in a
 // fixed order through LDS (one thread per channel walking all T frames left the launch at 49 us for 64 utterances)
-__global__ __launch_bounds__(512) void meanpool_fwd_kernel(const bf16_t* __restrict__ h, float* __restrict__ emb, int T, int C) {
+__device__ __forceinline__ float ld_act(const bf16_t* p, int64_t i) { return bf2f(p[i]); }
+__device__ __forceinline__ float ld_act(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ void st_act(bf16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+__device__ __forceinline__ void st_act(float* p, int64_t i, float v) { p[i] = v; }
+template <typename TA>
+__global__ __launch_bounds__(512) void meanpool_fwd_kernel(const TA* __restrict__ h, float* __restrict__ emb, int T, int C) {
     __shared__ float red[4][128];
     const int b = blockIdx.x, g = threadIdx.x >> 7, l = threadIdx.x & 127;
     for (int c0 = 0; c0 < C; c0 += 128) {
         const int c = c0 + l;
         float s = 0.f;
         if (c < C)
-            for (int t = g; t < T; t += 4) s += bf2f(h[((int64_t)b * T + t) * C + c]);
+            for (int t = g; t < T; t += 4) s += ld_act(h, ((int64_t)b * T + t) * C + c);
         red[g][l] = s;
         __syncthreads();
         if (g == 0 && c < C) emb[(int64_t)b * C + c] = (((red[0][l] + red[1][l]) + red[2][l]) + red[3][l]) / (float)T;
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(512) void meanpool_fwd_kernel(const bf16_t* __restr
     }
 }
 // d_pre[b][t][c] = d_emb[b][c] / T * dropmask(seed, idx) * act'(pre[b][t][c])
-__global__ void meanpool_bwd_kernel(const float* __restrict__ demb, const bf16_t* __restrict__ pre, bf16_t* __restrict__ dpre,
+template <typename TA>
+__global__ void meanpool_bwd_kernel(const float* __restrict__ demb, const TA* __restrict__ pre, TA* __restrict__ dpre,
                                     int B, int T, int C, int ract, float drop_p, uint32_t seed) {
     const int64_t n = (int64_t)B * T * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -246,8 +252,8 @@ __global__ void meanpool_bwd_kernel(const float* __restrict__ demb, const bf16_t
         const int b = (int)(i / ((int64_t)T * C));
         float v = demb[(int64_t)b * C + c] / (float)T;
         if (drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)i, drop_p);
-        v *= act_grad_f(ract, bf2f(pre[i]));
-        dpre[i] = f2bf(v);
+        v *= act_grad_f(ract, ld_act(pre, i));
+        st_act(dpre, i, v);
     }
 }
 // logits = emb W^T + b ; logp = log_softmax(logits)   (num classes NC <= 8, C <= 1024); one wave per item
@@ -393,14 +399,25 @@ extern "C" int scl_posconv_weight_bwd(const float* dwf, const float* v, const fl
 
 extern "C" int scl_meanpool_fwd(const void* h, float* emb, int B, int T, int C, void* stream) {
     SCL_REQUIRE(h && emb && B > 0 && T > 0 && C > 0, "meanpool_fwd: bad args");
-    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)h, emb, T, C);
+    hipLaunchKernelGGL(meanpool_fwd_kernel<bf16_t>, dim3(B), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)h, emb, T, C);
     return scl_check_launch("scl_meanpool_fwd");
+}
+extern "C" int scl_meanpool_fwd_f32(const float* h, float* emb, int B, int T, int C, void* stream) {
+    SCL_REQUIRE(h && emb && B > 0 && T > 0 && C > 0, "meanpool_fwd_f32: bad args");
+    hipLaunchKernelGGL(meanpool_fwd_kernel<float>, dim3(B), dim3(512), 0, (hipStream_t)stream, h, emb, T, C);
+    return scl_check_launch("scl_meanpool_fwd_f32");
 }
 extern "C" int scl_meanpool_bwd(const float* demb, const void* pre, void* dpre, int B, int T, int C, int ract, float drop_p,
                                 uint32_t seed, void* stream) {
     SCL_REQUIRE(demb && pre && dpre && B > 0 && T > 0 && C > 0, "meanpool_bwd: bad args");
-    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for((int64_t)B * T * C)), dim3(256), 0, (hipStream_t)stream, demb, (const bf16_t*)pre, (bf16_t*)dpre, B, T, C, ract, drop_p, seed);
+    hipLaunchKernelGGL(meanpool_bwd_kernel<bf16_t>, dim3(grid_for((int64_t)B * T * C)), dim3(256), 0, (hipStream_t)stream, demb, (const bf16_t*)pre, (bf16_t*)dpre, B, T, C, ract, drop_p, seed);
     return scl_check_launch("scl_meanpool_bwd");
+}
+extern "C" int scl_meanpool_bwd_f32(const float* demb, const float* pre, float* dpre, int B, int T, int C, int ract, float drop_p,
+                                    uint32_t seed, void* stream) {
+    SCL_REQUIRE(demb && pre && dpre && B > 0 && T > 0 && C > 0, "meanpool_bwd_f32: bad args");
+    hipLaunchKernelGGL(meanpool_bwd_kernel<float>, dim3(grid_for((int64_t)B * T * C)), dim3(256), 0, (hipStream_t)stream, demb, pre, dpre, B, T, C, ract, drop_p, seed);
+    return scl_check_launch("scl_meanpool_bwd_f32");
 }
 extern "C" int scl_utt_head_fwd(const float* emb, const float* W, const float* bias, float* logp, int B, int C, int NC, void* stream) {
     SCL_REQUIRE(emb && W && bias && logp && B > 0 && C > 0 && NC >= 1 && NC <= 8, "utt_head_fwd: bad args");

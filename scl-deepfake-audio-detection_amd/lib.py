@@ -104,6 +104,8 @@ def _protos():
         "scl_posconv_weight_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_meanpool_fwd": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_meanpool_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _vp], _i32),
+        "scl_meanpool_fwd_f32": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_meanpool_bwd_f32": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _vp], _i32),
         "scl_utt_head_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_utt_head_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
         # attention.hip

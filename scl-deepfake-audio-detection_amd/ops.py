@@ -322,11 +322,12 @@ def posconv_weight_bwd(dwf, v, g, norm, sdot_ws, dv, dg, E, Cg, K):
 
 
 def meanpool_fwd(h, emb, B, T, C):
-    _call("scl_meanpool_fwd", _p(h), _p(emb), B, T, C, _stream())
+    _call("scl_meanpool_fwd_f32" if _isf32(h) else "scl_meanpool_fwd", _p(h), _p(emb), B, T, C, _stream())
 
 
 def meanpool_bwd(demb, pre, dpre, B, T, C, ract, drop_p=0.0, seed=0):
-    return _call("scl_meanpool_bwd", _p(demb), _p(pre), _p(dpre), B, T, C, ract, drop_p, seed, _stream())
+    assert pre.dtype == dpre.dtype
+    return _call("scl_meanpool_bwd_f32" if _isf32(pre) else "scl_meanpool_bwd", _p(demb), _p(pre), _p(dpre), B, T, C, ract, drop_p, seed, _stream())
 
 
 def utt_head_fwd(emb, W, bias, logp, B, C, NC):

@@ -368,10 +368,9 @@ def test_full_size_train_step_matches_oracle_at_baseline_shape(dev):
         got, ref = m.P.g(name).float().cpu().flatten(), ref_grads[name].flatten()
         e, c = rl2(got, ref), cosine(got, ref)
         print("grad %-70s rel-L2 %.2e cos %.6f" % (name, e, c))
-        # the frame-level head linears back-propagate the broadcast mean-pool gradient (identical rows x LeakyReLU masks) through bf16
-        # operands: their rounding is systematic over the T rows instead of averaging out (measured 8e-2 / 0.9969)
-        lim_e, lim_c = (1.2e-1, 0.995) if name.startswith("backend.m_frame_level") else (6e-2, 0.998)
-        if not (e < lim_e and c > lim_c):
+        # one bound for every tensor: the frame-level head linears, whose backward spreads one mean-pool row over all T frames, run
+        # in f32 on the exact-fp32 GEMM (bf16 operands there measured 8e-2 / 0.9969: a rounding that is systematic over the T rows)
+        if not (e < 6e-2 and c > 0.998):
             bad.append((name, e, c))
     assert not bad, bad
 

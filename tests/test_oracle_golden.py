@@ -1,5 +1,6 @@
 """Pins the oracle (oracle/*.py) to vectors produced by the reference's own Python
 (oracle/gen_golden.py, run in the build container) — CPU only."""
+import math
 import os
 
 import numpy as np
@@ -7,6 +8,7 @@ import pytest
 import torch
 
 from oracle import audio_int16 as AI
+from oracle import audio_speed_pitch as SP
 from oracle import eer as OE
 from oracle import head as OH
 from oracle import multiview as OM
@@ -130,6 +132,27 @@ def test_wav2vec2_restatement_matches_transformers():
     assert abs(n_train - 315.4e6) < 0.3e6
 
 
+def test_wav2vec2_restatement_matches_transformers_at_xlsr_300m_shape():
+    """The shapes the fused attention / positional-convolution kernels specialise on (head dim 64, 16 groups, k = 128, 24 layers):
+    tests/golden/w2v_xlsr_hf.npz is a strided fingerprint of transformers.Wav2Vec2Model's output for 1 x 16000 samples with the
+    oracle's seeded weights copied in (oracle/gen_golden.py::gen_w2v_hf, build container)."""
+    g = load("w2v_xlsr_hf.npz")
+    cfg = W.W2VConfig()
+    sd = W.init_state(cfg, seed=int(g["seed"]))
+    with torch.no_grad():
+        y, inter = W.forward(sd, cfg, torch.from_numpy(g["x"]), return_all=True)
+    assert y.shape == (1, 49, 1024) and abs(y.abs().max().item() - float(g["last_hidden_absmax"])) < 1e-4
+    np.testing.assert_allclose(y[:, ::8, ::32].numpy(), g["last_hidden"], atol=1e-4)
+    ln = torch.nn.functional.layer_norm(inter["conv"][-1], (cfg.conv_dim,), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)
+    np.testing.assert_allclose(ln[:, ::8, ::16].numpy(), g["extract_features"], atol=2e-5)
+    # hidden_states[0] = after the positional convolution, [n] = after layer n; HF's last entry is already layer-normed
+    np.testing.assert_allclose(inter["pos"][:, ::8, ::32].numpy(), g["hidden0"], atol=1e-4)
+    for n in (1, 12):
+        ref = g["hidden%d" % n]
+        np.testing.assert_allclose(inter["layers"][n - 1][:, ::8, ::32].numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+    np.testing.assert_allclose(g["hidden24"], g["last_hidden"], atol=0)
+
+
 def test_train_step_matches_reference_train_epoch_iteration():
     g = load("train_step.npz")
     cfg = W.W2VConfig.tiny()
@@ -186,3 +209,44 @@ def test_reverb_and_int16_conversion_match_the_reference_run():
     assert AI.librosa_to_int16(g["conv:in"]).tolist() == g["conv:out"].tolist()
     for name in ("short", "clip16000", "long_rir"):
         assert np.array_equal(AI.reverb(g[name + ":speech"], g[name + ":rir"]), g[name + ":out"]), name
+
+
+def test_int16_oracle_matches_cpython_audioop():
+    """tests/golden/audioop.npz holds outputs of CPython 3.10's own audioop.rms / mul / add (the C code pydub 0.25.1 calls from
+    AudioSegment.rms / apply_gain / overlay) on random, saturating, silent and extreme inputs, and of the MUSAN-overlay chain of
+    background_noise.py:40-56 built from them (oracle/gen_golden.py::gen_audioop, build container).  The restatement must agree
+    bit for bit."""
+    g = np.load(os.path.join(G, "audioop.npz"))
+    names = [k[3:] for k in g.files if k.startswith("in:")]
+    assert len(names) >= 6
+    assert AI.rms_int(np.zeros(0, np.int16)) == int(g["rms:empty"]) == 0
+    for name in names:
+        x = g["in:" + name]
+        assert AI.rms_int(x) == int(g["rms:" + name]), name
+        for f, want in zip(g["factors"], g["mul:" + name]):
+            got = SP._mul(x[:4000], f)
+            assert np.array_equal(got, want), (name, f)
+            db = 20 * math.log(f, 10) if f > 0 else None
+            if db is not None and 10.0 ** (db / 20.0) == f:          # apply_gain goes through dB: where the round trip is exact
+                assert np.array_equal(AI.apply_gain(x[:4000], db), want), (name, f)
+        other = np.roll(g["in:loud"], 17)[: len(x)]
+        assert np.array_equal(AI.overlay(x, other), g["add:" + name]), name
+        assert np.array_equal(SP._add(x, other), g["add:" + name]), name
+    for tag in ("bn0", "bn1", "bn2"):
+        out, gain = AI.background_noise(g[tag + ":speech"].astype(np.float64) / 32768.0, g[tag + ":noise"], int(g[tag + ":snr"]))
+        assert gain == float(g[tag + ":gain"]), tag
+        assert np.array_equal(out, g[tag + ":out"]), tag
+
+
+def test_speed_oracle_matches_the_sequence_run_on_cpython_audioop():
+    """pydub's speedup() sequence (slicing, fades, looped overlay, append) with the real audioop.mul / audioop.add doing the
+    arithmetic (gen_golden.py::gen_audioop) against the same sequence on the restated primitives: factors below 1 (negative
+    cross-fade) and above 1, a speech-like and a full-scale clip."""
+    g = np.load(os.path.join(G, "audioop.npz"))
+    n = 0
+    while "speed%d:in" % n in g.files:
+        x, fac = g["speed%d:in" % n], float(g["speed%d:factor" % n])
+        got = SP.speedup(SP.Seg(x, 16000), fac).f
+        assert np.array_equal(got, g["speed%d:out" % n]), (n, fac)
+        n += 1
+    assert n >= 6
