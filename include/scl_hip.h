@@ -91,6 +91,8 @@ typedef struct SclOperand {
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
 #define SCL_GEMM_NO_W8    0x01000000  /* never the wide-tile (<=208/256 x 256, runtime row pitch) ping-pong kernel of gemm_w8.hip */
 #define SCL_GEMM_FORCE_W8 0x02000000  /* pick it whenever it can address the operands (testing / A-B comparison) */
+#define SCL_GEMM_FORCE_X2 0x08000000  /* pick the two-blocks-per-CU 208 x 128 kernel of gemm_x2.hip whenever it can address the operands */
+#define SCL_GEMM_NO_X2    0x10000000  /* never that kernel (testing / A-B comparison) */
 #define SCL_GEMM_AB_F32   0x40000000  /* A and B are f32 (strides in f32 elements, multiples of 4): exact-fp32 MFMA kernel (gemm_f32.hip) */
 #define SCL_GEMM_STAMPS   0x20000000  /* diagnostic: the wide kernels record per-block time stamps (scl_debug_gemm_stamps) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
@@ -115,6 +117,12 @@ typedef struct SclGemmDesc {
     float    drop_p;
     uint32_t drop_seed;
     int32_t  _pad;
+    /* optional, wide-tile kernels only (scl_gemm_colsum_rows() > 0): every tile also writes the column sums of the f32 values it
+     * stores to C into colsum_part[(tile_row * 4 + s) * N + col], s = 0..3 (two wave rows x two row passes); the caller sums the
+     * scl_gemm_colsum_rows() partial rows in a fixed order (scl_colreduce_f32).  The bias gradient of a Linear is the column sum of
+     * its output gradient (autograd of F.linear, main.py:79): produced here by the GEMM that writes that gradient, instead of a
+     * second pass over it. */
+    float*   colsum_part;
 } SclGemmDesc;
 
 /* C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] ), fp32 accumulate on MFMA.
@@ -126,6 +134,9 @@ int scl_gemm_bf16(const SclGemmDesc* desc, void* stream);
 /* 0 when scl_gemm_bf16 would run this descriptor on the 128x128 tiles, 1 / 2 for the wide (<= 208 / 256 rows x 256 columns) tiles of
  * gemm_w8.hip — lets the caller size split-K for the tile that will actually be used (pointers are not dereferenced). */
 int scl_gemm_uses_wide_tiles(const SclGemmDesc* desc);
+/* number of partial rows a launch of this descriptor writes to colsum_part (tile rows x 4), or 0 when it would not run on a kernel
+ * that can (then colsum_part must be null: scl_gemm_bf16 refuses it). */
+int scl_gemm_colsum_rows(const SclGemmDesc* desc);
 
 /* diagnostic: copy the per-block stamps of the last SCL_GEMM_STAMPS launch: 8 x u64 per block = {realtime (100 MHz), shader
  * clock} at kernel entry, after the prologue, after the K loop, after the epilogue (blocks 0 .. nblocks-1, nblocks <= 4096). */
@@ -252,8 +263,10 @@ int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, 
  * lse: f32 [B, H, T] row log-sum-exp of the scaled scores.  fwd: T <= 256; bwd: T <= 224 (LDS budget).
  * Replaces F.multi_head_attention_forward inside fairseq's TransformerSentenceEncoderLayer (model/xlsr.py:41) and its backward. */
 int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream);
-int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int B, int T, int H, int D,
-                 float scale, void* stream);
+/* bias_part (optional, f32 [B, 3*H*64]): per-utterance column sums of dqkv, from the f32 accumulators — summed over B (scl_colreduce_f32)
+ * they are the q/k/v bias gradients, which otherwise cost a pass over dqkv. */
+int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, float* bias_part, int B, int T,
+                 int H, int D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* feature-extractor layer 0 (Conv1d(1,C,10,5) + LayerNorm + GELU), fused fwd / bwd            */

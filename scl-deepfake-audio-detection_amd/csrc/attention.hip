@@ -164,21 +164,23 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows(Kt, t, ks, lane), qf[ks], s[t], 0, 0, 0);
+                if (t == NT - 1) {      // only the last key tile can hold keys >= T (the softmax below is VALU-bound: no per-element test elsewhere)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
-                    m = fmaxf(m, s[t][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
                 }
+                m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             }
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float l = 0.f;
+        const float msl = -m * sl2;
 #pragma unroll
         for (int t = 0; t < ATT_NTMAX; ++t) {
             if (t < NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[t][r] = exp2f((s[t][r] - m) * sl2); l += s[t][r]; }
+                for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, msl)); l += s[t][r]; }      // = exp(scale * (s - m))
             }
         }
         l += __shfl_xor(l, 16, 64);
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
         for (int u = 0; u < ATT_NTMAX / 2; ++u) {
             if (u < NT2) {
                 const int ta = 2 * u, tb = 2 * u + 1;
+                // the un-normalised exponentials (<= 1) are the B operand; 1 / l multiplies the 16 outputs instead of the 4 NT probabilities
                 float pb[4] = {0.f, 0.f, 0.f, 0.f};
-                if (tb < NT) { pb[0] = s[tb][0] * inv; pb[1] = s[tb][1] * inv; pb[2] = s[tb][2] * inv; pb[3] = s[tb][3] * inv; }
+                if (tb < NT) { pb[0] = s[tb][0]; pb[1] = s[tb][1]; pb[2] = s[tb][2]; pb[3] = s[tb][3]; }
                 u32x4a pk;
-                pk[0] = pack_bf2(s[ta][0] * inv, s[ta][1] * inv); pk[1] = pack_bf2(s[ta][2] * inv, s[ta][3] * inv);
+                pk[0] = pack_bf2(s[ta][0], s[ta][1]); pk[1] = pack_bf2(s[ta][2], s[ta][3]);
                 pk[2] = pack_bf2(pb[0], pb[1]); pk[3] = pack_bf2(pb[2], pb[3]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
             bf16_t* dst = ctx + ((int64_t)b * T + q) * E + h * ATT_D + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3]));
+                *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
         }
     }
 }
@@ -253,7 +256,7 @@ __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [
 
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                           bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+                                                           bf16_t* __restrict__ dqkv, float* __restrict__ bias_part, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 dqsum = f32x4{0.f, 0.f, 0.f, 0.f};      // bias_part: column sums of this wave's dQ tiles over the query steps
 
     // staging roles: threads 0..255 carry Q, threads 256..511 carry dO + O (for delta) + LSE; one step ahead in registers
     const int half = threadIdx.x >> 8, st = threadIdx.x & 255;
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             if (q < T)
                 *reinterpret_cast<uint2*>(dqkv + ((int64_t)b * T + q) * 3 * E + h * ATT_D + 16 * dt + 4 * g) =
                     make_uint2(pack_bf2(dq[0] * scale, dq[1] * scale), pack_bf2(dq[2] * scale, dq[3] * scale));
+            dqsum += dq;      // rows q >= T hold zeros (their P is masked to 0)
         }
     }
     // ---- dK, dV of this wave's keys: lane owns key 16(2w+j)+lc, d = 16dt + 4g + 0..3
@@ -431,6 +436,49 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             }
         }
     }
+    if (bias_part == nullptr) return;
+    // ---- column sums of this (utterance, head)'s dQ / dK / dV block -> bias_part[b][3E]: the q/k/v bias gradient is the column sum
+    // of dqkv (autograd of F.linear), summed here from the f32 accumulators instead of by a pass over the 78 MB tensor.
+    // Fixed order: butterfly over the 16 key / query lanes, then waves in index order => deterministic.
+    __syncthreads();                       // the dS image is free
+    float* red = reinterpret_cast<float*>(dSs);      // [8 waves][16 (dq) + 64 (dk) + 64 (dv)] f32 = 4.5 KiB
+    {
+        float v[4] = {dqsum[0] * scale, dqsum[1] * scale, dqsum[2] * scale, dqsum[3] * scale};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] += __shfl_xor(v[r], 1, 64); v[r] += __shfl_xor(v[r], 2, 64); v[r] += __shfl_xor(v[r], 4, 64); v[r] += __shfl_xor(v[r], 8, 64);
+        }
+        if (lc == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 144 + 4 * g + r] = v[r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float kk[4], vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {      // keys >= T and tiles this wave does not own hold zeros
+                kk[r] = (dKt[dt][0][r] + dKt[dt][1][r]) * scale;
+                vv[r] = dVt[dt][0][r] + dVt[dt][1][r];
+                kk[r] += __shfl_xor(kk[r], 1, 64); kk[r] += __shfl_xor(kk[r], 2, 64); kk[r] += __shfl_xor(kk[r], 4, 64); kk[r] += __shfl_xor(kk[r], 8, 64);
+                vv[r] += __shfl_xor(vv[r], 1, 64); vv[r] += __shfl_xor(vv[r], 2, 64); vv[r] += __shfl_xor(vv[r], 4, 64); vv[r] += __shfl_xor(vv[r], 8, 64);
+            }
+            if (lc == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { red[wave * 144 + 16 + 16 * dt + 4 * g + r] = kk[r]; red[wave * 144 + 80 + 16 * dt + 4 * g + r] = vv[r]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int which = threadIdx.x >> 6, d = threadIdx.x & 63;      // 0: q, 1: k, 2: v
+        float t = 0.f;
+        if (which == 0) t = red[(2 * (d >> 4)) * 144 + (d & 15)] + red[(2 * (d >> 4) + 1) * 144 + (d & 15)];      // the two query tiles of d-tile d >> 4
+        else {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[w * 144 + 16 + 64 * (which - 1) + d];
+        }
+        bias_part[(int64_t)b * 3 * E + which * E + h * ATT_D + d] = t;
+    }
 }
 
 }  // namespace
@@ -444,8 +492,8 @@ extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T
     return scl_check_launch("scl_attn_fwd");
 }
 
-extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int B, int T, int H, int D,
-                            float scale, void* stream) {
+extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, float* bias_part, int B, int T,
+                            int H, int D, float scale, void* stream) {
     SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0, "attn_bwd: bad args");
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 224, "attn_bwd: fused path needs head dim 64 and T <= 224 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
@@ -456,6 +504,6 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd8_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, H, scale);
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale);
     return scl_check_launch("scl_attn_bwd");
 }

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             if (c < C) {
                 float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = gelu_f((y[ch][i] - mean) * rstd * gamma[c + i] + beta[c + i]);
+                for (int i = 0; i < 8; ++i) o[i] = (y[ch][i] - mean) * rstd * gamma[c + i] + beta[c + i];
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // two elements per packed-f32 instruction, same bits as gelu_f
                 const int64_t off = ((int64_t)b * T0 + t0 + r) * C + c;
                 if (ZF32) {
                     float* z = reinterpret_cast<float*>(zv);
@@ -171,11 +173,16 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
         }
         float s1 = 0.f, s2 = 0.f;
         if (act) {
+            float gg[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gg[i] = ((y[i] - mean) * rstd) * gamma[c + i] + beta[c + i];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) gelu_grad2(gg[i], gg[i + 1]);      // packed-f32 form, same bits as gelu_grad_f
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float h = (y[i] - mean) * rstd;
                 const float gmi = gamma[c + i];
-                const float dyn = dzv[i] * gelu_grad_f(h * gmi + beta[c + i]);
+                const float dyn = dzv[i] * gg[i];
                 aw[i][KT + 1] += dyn * h;  // dgamma
                 aw[i][KT + 2] += dyn;      // dbeta
                 const float dh = dyn * gmi;

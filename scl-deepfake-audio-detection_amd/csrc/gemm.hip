@@ -704,14 +704,43 @@ bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long l
     return (d.flags & SCL_GEMM_FORCE_W8) || (w8_env && d.N >= 192 && plan->tiles * zdim >= need);
 }
 
+// 208 x 128 tiles, two 4-wave workgroups per CU (gemm_x2.hip): the epilogue of one tile runs under the K loop of the other.
+// SCL_GEMM_X2: 0 never, 1 automatic (below), 2 whenever the operands can be addressed.
+bool gemm_pick_x2(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, W8Plan* plan) {
+    static const int x2_env = [] { const char* e = getenv("SCL_GEMM_X2"); return e ? atoi(e) : 0; }();
+    if (d.flags & (SCL_GEMM_NO_X2 | SCL_GEMM_FORCE_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG | SCL_GEMM_NO_DMA)) return false;
+    if (!(d.flags & SCL_GEMM_FORCE_X2) && x2_env == 0) return false;
+    const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
+    const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
+    static const int ncu_env = [] { const char* e = getenv("SCL_GEMM_CUS"); const int v = e ? atoi(e) : 256; return v >= 32 && v <= 256 ? v : 256; }();
+    if (!a_whole || !b_whole || !scl_gemm_x2_plan(k, at, bt, d, zdim, ncu_env, plan)) return false;
+    if ((d.flags & SCL_GEMM_FORCE_X2) || x2_env == 2) return true;
+    // automatic: forward / data-gradient shapes (A K-contiguous) that fill at least the 256 CUs once
+    return !at && d.N >= 128 && plan->tiles * zdim >= 248;
+}
+
 }  // namespace
 
 extern "C" int scl_gemm_uses_wide_tiles(const SclGemmDesc* dp) {
     if (!dp || dp->M <= 0 || dp->N <= 0 || dp->K <= 0 || dp->nb1 < 1 || dp->nb2 < 1 || dp->splitk < 1) return 0;
     GemmK k; W8Plan plan;
     const bool at = dp->flags & SCL_GEMM_A_T, bt = dp->flags & SCL_GEMM_B_T;
-    return gemm_pick_w8(k, at, bt, *dp, (long long)dp->nb1 * dp->nb2 * dp->splitk, &plan) ? 1 + plan.variant : 0;
+    const long long zdim = (long long)dp->nb1 * dp->nb2 * dp->splitk;
+    if (gemm_pick_x2(k, at, bt, *dp, zdim, &plan)) return 3;
+    return gemm_pick_w8(k, at, bt, *dp, zdim, &plan) ? 1 + plan.variant : 0;
 }
+
+// partial rows of the fused column sums (SclGemmDesc.colsum_part): wide tiles of gemm_w8.hip only, one un-batched problem, whole 8-column
+// vectors in every row
+static int gemm_colsum_rows(const SclGemmDesc& d) {
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nb1 != 1 || d.nb2 != 1 || d.splitk != 1 || (d.N & 7) || (d.ldc & 7) || (d.flags & SCL_GEMM_AB_F32)) return 0;
+    GemmK k; W8Plan plan;
+    const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
+    const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0), b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
+    if (!a_whole || !b_whole || (d.flags & SCL_GEMM_NO_DMA) || gemm_pick_x2(k, at, bt, d, 1, &plan) || !gemm_pick_w8(k, at, bt, d, 1, &plan)) return 0;
+    return plan.tiles_m * 4;
+}
+extern "C" int scl_gemm_colsum_rows(const SclGemmDesc* dp) { return dp ? gemm_colsum_rows(*dp) : 0; }
 
 extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     SCL_REQUIRE(dp, "gemm: null desc");
@@ -736,7 +765,9 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
     SCL_REQUIRE(zdim <= 65535, "gemm: batch*splitk too large (%lld)", zdim);
-    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias;
+    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias; k.colsum = d.colsum_part;
+    SCL_REQUIRE(!d.colsum_part || (gemm_colsum_rows(d) > 0 && ((uintptr_t)d.colsum_part & 15) == 0),
+                "gemm: colsum_part needs a launch on the wide tiles (scl_gemm_colsum_rows() > 0) and a 16-byte aligned buffer");
     k.c_bs1 = d.c_bs1; k.c_bs2 = d.c_bs2; k.c_rbstride = d.c_rbstride; k.c_split_stride = d.c_split_stride; k.bias_bs2 = d.bias_bs2;
     k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
@@ -776,8 +807,11 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         // wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the
         // problem fills at least half a round of them and the operands advance linearly along K
         W8Plan plan;
-        const bool w8 = dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
-        if (w8) {
+        const bool x2 = dma && gemm_pick_x2(k, at, bt, d, zdim, &plan);
+        const bool w8 = !x2 && dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
+        if (x2) {
+            scl_gemm_x2_launch(k, at, bt, plan, zdim, s);
+        } else if (w8) {
             scl_gemm_w8_launch(k, at, bt, plan, zdim, s);
         } else if (p8) {
             static bool p8_attr_set = false;
@@ -901,7 +935,7 @@ extern "C" int scl_gemm_splitk_finish(const SclGemmDesc* dp, const float* slabs,
     SCL_REQUIRE(!(d.flags & SCL_GEMM_HAS_BIAS) || d.bias, "gemm finish: HAS_BIAS set but bias is null");
     SCL_REQUIRE(((uintptr_t)slabs & 15) == 0, "gemm finish: slabs must be 16-byte aligned");
     GemmK k;
-    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias;
+    k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias; k.colsum = nullptr;
     k.c_bs1 = 0; k.c_bs2 = 0; k.c_rbstride = d.c_rbstride; k.c_split_stride = 0; k.bias_bs2 = 0;
     k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = 1; k.splitk = 1; k.flags = d.flags;

@@ -18,7 +18,7 @@ struct OpK {             // device-side operand description (bytes, 32-bit)
 };
 struct GemmK {
     OpK A, B;
-    void* C; void* C2; const void* R; const float* bias;
+    void* C; void* C2; const void* R; const float* bias; float* colsum;
     long long c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2;  // elements
     unsigned c_rpb, c_magic, c_shift;
     int ldc, M, N, K, nb2, splitk, flags, vec_ok, group_m, tile_m, debug;
@@ -228,5 +228,9 @@ struct W8Plan { int variant, tiles_m, tile_m; long long tiles, cost; };
 bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan);
 int scl_gemm_read_stamps(unsigned long long* out, int nblocks);
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s);
+
+// gemm_x2.hip (host side): 208 x 128 tiles, two 4-wave workgroups per CU (plan->variant = 2)
+bool scl_gemm_x2_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan);
+int scl_gemm_x2_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s);
 
 }  // namespace sclg

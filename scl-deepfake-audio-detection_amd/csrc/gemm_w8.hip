@@ -28,6 +28,7 @@
 //   * The epilogue goes through LDS (w8_epilogue_pass): whole 128-B lines per store instead of 16 x 32-byte fragments.
 //   * Accumulation order per output element is k ascending, as in the 128x128 kernels: results are bit-identical to theirs.
 #include "gemm_common.h"
+#include "gemm_w8_epi.h"
 
 using namespace sclg;
 
@@ -106,156 +107,6 @@ template <bool T>
 __device__ __forceinline__ bf16x8 w8_frag(const char* img, int gb, int ks, int lane) {   // gb: 16-row (column) block 0..15 of the image
     if (T) return frag_t_raw(img + (gb >> 3) * TILE_BYTES, gb & 7, ks, lane);
     return frag_k(img, gb, ks, lane);
-}
-
-// ---- epilogue through LDS: whole 128-B lines per store ----------------------------------------------------------------
-// The MFMA leaves a lane with 4 consecutive columns of 16 different rows, so a direct store touches 16 cache lines with 32
-// (bf16: 16) bytes each; with one 8-wave block per CU nothing overlaps the epilogue and those stores (plus the residual loads of
-// the same shape) took 16-27 us of a 45-55 us block (stamps, profiles/r2_gemm_stamps.txt).  Here each wave parks up to 64 rows x
-// 64 columns of f32 accumulators in a private 16-KiB LDS block ([row][256 B], 16-byte chunks XOR-swizzled with row & 15: the
-// ds_write_b128 of a 16-lane group and the two ds_read_b128 per lane are bank-conflict free) and reads them back row-contiguous:
-// a lane owns 8 consecutive columns of one row, 8 lanes own a row's 64 columns, so bias / residual loads and the C / C2 stores of
-// one wave-instruction cover 8 rows x 128 (bf16) or 256 (f32) contiguous bytes.  Arithmetic per element is the old epilogue's,
-// in the same order: results are bit-identical.
-__device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
-                                                 int mlimit, long long cbase, const float* bias, int lane) {
-    const int flags = d.flags;
-    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
-    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
-    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
-    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
-    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
-    const int g = lane >> 4, lc = lane & 15;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        if (mt < nmt) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(wlds + (mt * 16 + lc) * 256 + (((nt * 4 + g) ^ lc) << 4)) = acc[mt][nt];
-        }
-    }
-    const int c = lane & 7, rsub = lane >> 3;
-    const int col = nbase + 8 * c;
-    const bool colv = d.vec_ok && col + 8 <= d.N;
-    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has_bias && colv) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-    }
-    const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
-    // The R operand (activation-gradient input / residual) comes in through LDS-DMA, several rows at a time: loads and stores share
-    // the in-order vmcnt counter, so a wait for row i's R vector requested after row i-1's stores also waits for those stores'
-    // acknowledgement — one memory round trip per row (tools/epilogue_probe.py: reading R cost 52 us per launch where a second
-    // store costs 14).  Staged this way the queue is drained once per batch, and the loop stays rolled (the kernels are 44 KB of
-    // code: unrolling the epilogue to keep R in registers slowed every variant, R or not, by 20-36 us).  bf16 R: batches of four
-    // rows in the wave's 4 KiB above the transposition blocks.  f32 R (twice the bytes): rows 0-1 and 2-3 there, rows 4-7 in the
-    // first half of the wave's own transposition block, whose rows have been consumed by then.
-    const bool r_dma = rmode && d.vec_ok && !(d.debug & 2) && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
-    __amdgpu_buffer_rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(r_dma ? d.R : d.C));
-    const char* rstage = wextra;
-    for (int i = 0; i < 2 * nmt; ++i) {
-        const bool issue = r_dma && (r_f32 ? (i == 0 || i == 2 || i == 4) : (i & 3) == 0);
-        if (issue) {
-            const int nrow = r_f32 ? (i == 4 ? 4 : 2) : 4;
-            char* dst = (r_f32 && i == 4) ? wlds : wextra;
-            if (r_f32 && i == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of rows 0-31 have returned
-            for (int u = 0; u < nrow; ++u) {
-                const int row2 = mbase + 8 * (i + u) + rsub;
-                unsigned offb = OOB;
-                if (i + u < 2 * nmt && row2 < mlimit && colv) {
-                    const unsigned q2 = udiv_magic((unsigned)row2, d.c_magic, d.c_shift);
-                    const long long o2 = cbase + (long long)q2 * d.c_rbstride + (long long)((unsigned)row2 - q2 * d.c_rpb) * d.ldc + col;
-                    offb = (unsigned)(o2 << (r_f32 ? 2 : 1));
-                }
-                if (r_f32) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048), 16, offb, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048 + 1024), 16, offb == OOB ? OOB : offb + 16, 0, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 1024), 16, offb, 0, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            rstage = dst - (r_f32 ? i * 2048 : i * 1024);      // row-batch i lives at rstage + i * (2048 | 1024)
-        }
-        const int r = 8 * i + rsub;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c) ^ (r & 15)) << 4));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c + 1) ^ (r & 15)) << 4));
-        const int row = mbase + r;
-        if (row >= mlimit) continue;
-        const unsigned q = udiv_magic((unsigned)row, d.c_magic, d.c_shift);
-        const long long off = cbase + (long long)q * d.c_rbstride + (long long)((unsigned)row - q * d.c_rpb) * d.ldc + col;
-        float v[8] = {d.alpha * lo[0], d.alpha * lo[1], d.alpha * lo[2], d.alpha * lo[3], d.alpha * hi[0], d.alpha * hi[1], d.alpha * hi[2], d.alpha * hi[3]};
-        if (colv) {
-            if (has_bias) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += bb[j];
-            }
-            if (has_c2) {
-                if (c2_f32) {
-                    float* p = reinterpret_cast<float*>(d.C2) + off;
-                    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
-                    bf16_t* p = reinterpret_cast<bf16_t*>(d.C2) + off;
-                    if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                    else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
-                }
-            }
-            if (act == 1) {
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) gelu2(v[j], v[j + 1]);
-            } else if (act) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = act_f(act, v[j]);
-            }
-            float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (rmode) {
-                if (r_f32) {
-                    const float* p = r_dma ? reinterpret_cast<const float*>(rstage + i * 2048 + lane * 16) : reinterpret_cast<const float*>(d.R) + off;
-                    const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + (r_dma ? 256 : 4));
-                    rr[0] = t0.x; rr[1] = t0.y; rr[2] = t0.z; rr[3] = t0.w; rr[4] = t1.x; rr[5] = t1.y; rr[6] = t1.z; rr[7] = t1.w;
-                } else {
-                    const bf16_t* p = reinterpret_cast<const bf16_t*>(d.R) + off;
-                    uint2 t0, t1;
-                    if (r_dma) { const uint4 t = *reinterpret_cast<const uint4*>(rstage + i * 1024 + lane * 16); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
-                    else if ((off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
-                    else { t0 = *reinterpret_cast<const uint2*>(p); t1 = *reinterpret_cast<const uint2*>(p + 4); }
-                    rr[0] = __uint_as_float(t0.x << 16); rr[1] = __uint_as_float(t0.x & 0xFFFF0000u);
-                    rr[2] = __uint_as_float(t0.y << 16); rr[3] = __uint_as_float(t0.y & 0xFFFF0000u);
-                    rr[4] = __uint_as_float(t1.x << 16); rr[5] = __uint_as_float(t1.x & 0xFFFF0000u);
-                    rr[6] = __uint_as_float(t1.y << 16); rr[7] = __uint_as_float(t1.y & 0xFFFF0000u);
-                }
-            }
-            if (rmode == 2 && ract == 1) {
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) { gelu_grad2(rr[j], rr[j + 1]); v[j] *= rr[j]; v[j + 1] *= rr[j + 1]; }
-            } else if (rmode == 2) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= act_grad_f(ract, rr[j]);
-            }
-            if (drop) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(d.drop_seed, (uint64_t)(off + j), d.drop_p);
-            }
-            if (rmode == 1) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rr[j];
-            }
-            if (c_f32) {
-                float* p = reinterpret_cast<float*>(d.C) + off;
-                *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-                bf16_t* p = reinterpret_cast<bf16_t*>(d.C) + off;
-                if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
-            }
-        } else {
-            // column-edge tile / unaligned C: element-wise path
-#pragma unroll
-            for (int j = 0; j < 8; ++j) epi_scalar(ea, v[j], off + j, col + j, bias);
-        }
-    }
 }
 
 // one phase: [the caller's LDS reads / DMA issues]  wait reads -> barrier -> MFMA burst -> barrier.  The LDS reads are retired
@@ -345,8 +196,10 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
         char* wlds = smem + wave * 16384;
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
-        w8_epilogue_pass(d, acc[0], 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
-        if (NH > 0) w8_epilogue_pass(d, acc[1], NH, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        // optional column sums of the stored values: partial row (tile row * 4 + wave row * 2 + pass)
+        float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
+        w8_epilogue_pass(d, acc[0], 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        w8_epilogue_pass(d, acc[1], NH, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
@@ -476,14 +329,15 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
         char* wlds = smem + wave * 16384;
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
         f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
-        w8_epilogue_pass(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
+        w8_epilogue_pass(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            w8_epilogue_pass(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+            w8_epilogue_pass(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
         }
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,

@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
             load8<true>(gamma, c, g);
             load8<true>(beta, c, b);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float t = (v[ch][i] - mean) * rstd * g[i] + b[i];
-                o[i] = act == 1 ? gelu_f(t) : t;
+            for (int i = 0; i < 8; ++i) o[i] = (v[ch][i] - mean) * rstd * g[i] + b[i];
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // packed-f32 form, same bits as gelu_f
             }
             if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
             if (y_f32) store8_f32(y_f32, (int64_t)row * ldy + c, o);
@@ -135,11 +136,13 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                 if (act == 1) {
                     float b[8];
                     load8<true>(beta, c, b);
+                    float gg[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float h = (xv[i] - mean) * rstd;
-                        dyv[ch][i] *= gelu_grad_f(h * g[i] + b[i]);
-                    }
+                    for (int i = 0; i < 8; ++i) gg[i] = ((xv[i] - mean) * rstd) * g[i] + b[i];
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) gelu_grad2(gg[i], gg[i + 1]);      // packed-f32 form, same bits as gelu_grad_f
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dyv[ch][i] *= gg[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {

@@ -20,6 +20,9 @@ from . import ops
 from .lib import ACT_GELU, FLAT
 from .ops import Op
 
+# fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
+FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
+
 
 class W2VConfig:
     def __init__(self, conv_dim=512, conv_kernels=(10, 3, 3, 3, 3, 2, 2), conv_strides=(5, 2, 2, 2, 2, 2, 2), embed=1024,
@@ -205,6 +208,8 @@ class Encoder:
         d["ln_part"] = f32(nln * 3 * max(C, E))
         ncs = max(ops.colsum_nparts(B * (max(Ts[1:] + [T + K]) + 4)), 1) + 1      # conv bias sums run over the zero-padded dyp rows
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
+        d["qkv_bias_part"] = f32(B * 3 * E)
+        d["cs_fused"] = f32(4 * (M // 200 + 2) * Fd)      # per-tile column sums written by the fc2 data-gradient GEMM (main stream only)
         d["conv0_ws"] = f32(ops.conv0_bwd_nparts(B, L, cfg.conv_kernels[0], cfg.conv_strides[0]) * C * (cfg.conv_kernels[0] + 3))
         d["conv0_stats"] = f32(B * Ts[0] * 2)   # per-frame (mean, rstd) of layer 0's LayerNorm
         d["slab"] = None  # split-K slabs, sized on first use
@@ -434,9 +439,17 @@ class Encoder:
             # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
             with self._side():
                 self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
-            ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU)
+            # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
+            fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU)
+            nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
+            if nrows * Fd > d["cs_fused"].numel():
+                nrows = 0
+            ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
+            if nrows:
+                ops.colreduce(d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd)
             with self._side():
-                self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
+                if not nrows:
+                    self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
                 self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
@@ -451,7 +464,10 @@ class Encoder:
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
             qkv, dqkv = d["qkv"][n], d["dqkv"]
             if d["fused_attn"]:
-                ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5)
+                ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5,
+                             bias_part=d["qkv_bias_part"] if FUSED_BIAS_GRAD else None)
+                if FUSED_BIAS_GRAD:       # q/k/v bias gradients: per-utterance column sums out of attn_bwd's accumulators, summed over B
+                    ops.colreduce(d["qkv_bias_part"], self._qkv_view(pn, "bias"), B, 3 * E)
             else:
                 Pn = d["P"][n]
                 bq = dict(nb1=B, nb2=H)
@@ -469,7 +485,8 @@ class Encoder:
                 ops.gemm(dS, Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=0), dqkv, T, D, T, a_t=True, b_t=True, alpha=sc, ldc=3 * E,
                          c_bs1=T * 3 * E, c_bs2=D, c_offset=E, **bq)                                   # dK = s dS^T Q
             with self._side():
-                ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
+                if not (FUSED_BIAS_GRAD and d["fused_attn"]):
+                    ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
                 self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             # dx (= d x1) is the gradient of out_proj's output: out_proj.bias.grad rides on this LayerNorm backward

@@ -35,7 +35,7 @@ class SclGemmDesc(ctypes.Structure):
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("nb1", ctypes.c_int32), ("nb2", ctypes.c_int32), ("splitk", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
-                ("drop_seed", ctypes.c_uint32), ("_pad", ctypes.c_int32)]
+                ("drop_seed", ctypes.c_uint32), ("_pad", ctypes.c_int32), ("colsum_part", ctypes.c_void_p)]
 
 
 # flags (include/scl_hip.h)
@@ -48,6 +48,8 @@ GEMM_NO_P8 = 0x00400000
 GEMM_FORCE_P8 = 0x00800000
 GEMM_NO_W8 = 0x01000000
 GEMM_FORCE_W8 = 0x02000000
+GEMM_FORCE_X2 = 0x08000000
+GEMM_NO_X2 = 0x10000000
 GEMM_AB_F32 = 0x40000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
@@ -73,6 +75,7 @@ def _protos():
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
         "scl_debug_gemm_stamps": ([_vp, _i32], _i32),
         "scl_gemm_uses_wide_tiles": ([P(SclGemmDesc)], _i32),
+        "scl_gemm_colsum_rows": ([P(SclGemmDesc)], _i32),
         # nn.hip
         "scl_bn_nslabs": ([_i32], _i32),
         "scl_bn_fwd": ([_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64,
@@ -112,7 +115,7 @@ def _protos():
         "scl_softmax_fwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_attn_fwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
-        "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         # conv0.hip
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_conv0_fwd_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),

@@ -29,6 +29,8 @@ N_CLASS = 2
 # scoring (model.eval() under torch.no_grad(): main.py --eval / --predict / --emb, the validation pass) runs fp32 end to end unless
 # SCL_SCORE_FP32=0 asks for the bf16-operand training kernels (about 8x faster forward, scores to ~1e-2)
 SCORE_FP32 = os.environ.get("SCL_SCORE_FP32", "1") != "0"
+# the 128-wide frame-level head in f32 on the exact-fp32 GEMM (SCL_HEAD_F32=0: bf16 operands, the A/B switch of tests / probes)
+HEAD_F32 = os.environ.get("SCL_HEAD_F32", "1") != "0"
 DROP_P = 0.5  # BackEnd(128, 128, 2, 0.5, False): torch.nn.Dropout(0.5) after each frame-level layer
 
 
@@ -175,8 +177,9 @@ class Model(nn.Module):
             # the frame-level head (three 128 x 128 linears) runs in f32 on the exact-fp32 GEMM with the fp32 master weights, forward and
             # backward: 3.8 GFLOP per step at batch 64, and its gradients then meet the same bound as every other tensor (the
             # mean-pool backward hands every frame of an utterance the SAME row — rounded to bf16 its error is systematic over T)
-            self._hbufs[key] = dict(r0=f32(M * HEAD_DIM + 1024), pre=[f32(M * HEAD_DIM) for _ in range(3)],
-                                    h=[f32(M * HEAD_DIM + 1024) for _ in range(3)], dpre=[f32(M * HEAD_DIM + 1024) for _ in range(3)],
+            hd = f32 if HEAD_F32 else bf
+            self._hbufs[key] = dict(r0=hd(M * HEAD_DIM + 1024), pre=[hd(M * HEAD_DIM) for _ in range(3)],
+                                    h=[hd(M * HEAD_DIM + 1024) for _ in range(3)], dpre=[hd(M * HEAD_DIM + 1024) for _ in range(3)],
                                     dfe=f32(M * HEAD_DIM), dfe_bf=bf(M * HEAD_DIM + 1024), denc=bf(M * self.cfg.embed),
                                     demb=f32(B * HEAD_DIM), ws=f32(B * N_CLASS + 16),
                                     cs=f32(ops.colsum_nparts(M) * max(HEAD_DIM, 8)), dW=f32(HEAD_DIM * max(HEAD_DIM, self.cfg.embed)))
@@ -228,7 +231,7 @@ class Model(nn.Module):
         W = lambda name, ld: Op(P.bf16, ld, offset=P.off(name))
         # feats = LL(x) (pre-ReLU tensor is what SupCon sees, linear_nll:127-129), r0 = relu(feats)
         ops.gemm(Op(enc_out, E), W("LL.weight", E), hb["r0"], M, HEAD_DIM, E, bias=P.f32("LL.bias"), act=ACT_RELU, c2=feats)
-        Wf = lambda name, ld: Op(P.flat, ld, offset=P.off(name))
+        Wf = (lambda name, ld: Op(P.flat, ld, offset=P.off(name))) if HEAD_F32 else W
         prev, drop_descs = hb["r0"], []
         for j, idx in enumerate((0, 3, 6)):
             dsc = ops.gemm(Op(prev, HEAD_DIM), Wf("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), hb["h"][j], M, HEAD_DIM, HEAD_DIM,
@@ -282,7 +285,8 @@ class Model(nn.Module):
             ops.colsum_reduce(dpre, hb["cs"], P.g("backend.m_frame_level.%d.bias" % idx), M, HEAD_DIM)
             self.encoder._wgrad(sv["ectx"]["d"], Op(dpre, HEAD_DIM), Op(inp, HEAD_DIM), P.g("backend.m_frame_level.%d.weight" % idx),
                                 HEAD_DIM, HEAD_DIM, M)
-            wj = Op(P.flat, HEAD_DIM, offset=P.off("backend.m_frame_level.%d.weight" % idx))      # fp32 master weights, exact-fp32 GEMM
+            # fp32 master weights on the exact-fp32 GEMM (bf16 working copy when SCL_HEAD_F32=0)
+            wj = Op(P.flat if HEAD_F32 else P.bf16, HEAD_DIM, offset=P.off("backend.m_frame_level.%d.weight" % idx))
             if j > 0:
                 drop_descs.append(ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dpre"][j - 1], M, HEAD_DIM, HEAD_DIM, b_t=True, R=hb["pre"][j - 1],
                                            rmode=2, ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=seeds[j - 1]))

@@ -116,14 +116,15 @@ def _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, f32):
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False):
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
     d = _gemm_desc(A, B, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=act, c2=c2, R=R, rmode=rmode, ract=ract, alpha=alpha, nb1=nb1,
                    nb2=nb2, splitk=splitk, ldc=ldc, c_rpb=c_rpb, c_rbstride=c_rbstride, c_bs1=c_bs1, c_bs2=c_bs2, c_offset=c_offset,
                    bias_bs2=bias_bs2, bias_offset=bias_offset, drop_p=drop_p, drop_seed=drop_seed, c_split_stride=c_split_stride,
-                   no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8)
+                   no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8,
+                   force_x2=force_x2, no_x2=no_x2, colsum_part=colsum_part)
     sk = _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, A.t.dtype == torch.float32)
-    if sk > 1 and not (force_w8 or force_p8 or force_big):
+    if sk > 1 and not (force_w8 or force_p8 or force_big or force_x2):
         key = (C.device.index, torch.cuda.current_stream(C.device).cuda_stream)
         ws = _SPLITK_WS.get(key)
         if ws is None or ws[-1].numel() < sk * M * N:
@@ -138,6 +139,13 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
     return d
 
 
+def gemm_colsum_rows(A, B, C, M, N, K, **kw):
+    """Partial rows [rows, N] f32 a gemm(..., colsum_part=...) with the same arguments writes (sum them with colreduce); 0 when the
+    call would not run on the wide tiles, which alone produce the fused column sums."""
+    d = _gemm_desc(A, B, C, M, N, K, **kw)
+    return L.load().scl_gemm_colsum_rows(ctypes.byref(d))
+
+
 def gemm_wide_kind(A, B, C, M, N, K, **kw):
     """0 if scl_gemm_bf16 would use the 128x128 tiles for this call, 1 / 2 for the wide tiles (gemm_w8.hip); same arguments as gemm()."""
     d = _gemm_desc(A, B, C, M, N, K, **kw)
@@ -147,7 +155,7 @@ def gemm_wide_kind(A, B, C, M, N, K, **kw):
 def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
                alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
                c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False,
-               force_p8=False, force_big=False, no_w8=False, force_w8=False):
+               force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None):
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
     flags = 0
@@ -179,6 +187,9 @@ def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=N
         d.bias = _ptr(bias, bias_offset)
     if drop_p > 0.0:
         flags |= L.GEMM_DROPOUT
+    if colsum_part is not None:
+        assert colsum_part.dtype == torch.float32
+        d.colsum_part = _ptr(colsum_part)
     if no_dma:
         flags |= L.GEMM_NO_DMA
     if no_big:
@@ -193,6 +204,10 @@ def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=N
         flags |= L.GEMM_NO_W8
     if force_w8:
         flags |= L.GEMM_FORCE_W8
+    if force_x2:
+        flags |= L.GEMM_FORCE_X2
+    if no_x2:
+        flags |= L.GEMM_NO_X2
     flags |= (act << L.ACT_SHIFT) | (rmode << L.RMODE_SHIFT) | (ract << L.RACT_SHIFT)
     d.c_bs1, d.c_bs2, d.c_rbstride, d.c_split_stride, d.bias_bs2 = c_bs1, c_bs2, c_rbstride, c_split_stride, bias_bs2
     d.c_rpb, d.ldc = c_rpb, (N if ldc is None else ldc)
@@ -351,8 +366,9 @@ def attn_fwd(qkv, ctx, lse, B, T, H, D, scale):
     _call("scl_attn_fwd", _p(qkv), _p(ctx), _p(lse), B, T, H, D, scale, _stream())
 
 
-def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale):
-    _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, T, H, D, scale, _stream())
+def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale, bias_part=None):
+    """bias_part: optional f32 [B, 3*H*D] — per-utterance column sums of dqkv (colreduce over B gives the q/k/v bias gradients)."""
+    _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(bias_part), B, T, H, D, scale, _stream())
 
 
 def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5, stats=None):

@@ -31,7 +31,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from scl_amd import lib
     assert ctypes.sizeof(lib.SclOperand) == 56
-    assert ctypes.sizeof(lib.SclGemmDesc) == 2 * 56 + 4 * 8 + 5 * 8 + 8 * 4 + 4 * 4 + 8  # pointers, strides, ints, floats/seed/pad
+    assert ctypes.sizeof(lib.SclGemmDesc) == 2 * 56 + 4 * 8 + 5 * 8 + 8 * 4 + 4 * 4 + 8 + 8  # pointers, strides, ints, floats/seed/pad, colsum_part
+    assert lib.SclGemmDesc.colsum_part.offset == ctypes.sizeof(lib.SclGemmDesc) - 8
     assert lib.SclGemmDesc.C.offset == 112 and lib.SclGemmDesc.flags.offset == 112 + 32 + 40 + 32
 
 

@@ -297,6 +297,105 @@ def test_wide_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk)
     _close(got, ref if splitk > 1 else torch.relu(ref), 8e-3, "w8 a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(12736, 1024, 1024, 1), (5128, 1288, 96, 1), (2184, 3072, 1024, 1), (1024, 4096, 12736, 4),
+                                          (520, 776, 4128, 3), (200, 256, 32, 1), (1000, 200, 544, 1), (208, 128, 64, 1)])
+def test_two_blocks_per_cu_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
+    """gemm_x2.hip (208 x 128 tiles, 4-wave workgroups, two per CU, K step 32, rings of three stages): same K order per output
+    element as the 128 x 128 kernels => bit-identical, on ragged M / N edges, K that is a multiple of 32 but not of 64, fewer K steps
+    than ring stages, uneven split-K slabs; operands are followed by NaN, so a fetch that is not range-checked shows."""
+    A = _rand((M, K), dev, 71, 0.3); B = _rand((N, K), dev, 72, 0.3)
+    def nanpad(mat):
+        buf = torch.full((mat.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=dev)
+        buf[:mat.numel()] = mat.reshape(-1)
+        return buf
+    opA = ops.Op(nanpad(A.t().contiguous()), M) if a_t else ops.Op(nanpad(A), K)
+    opB = ops.Op(nanpad(B.t().contiguous()), N) if b_t else ops.Op(nanpad(B), K)
+    outs = []
+    for kw in (dict(no_p8=True, no_big=True, no_w8=True, no_x2=True), dict(force_x2=True), dict(force_x2=True), dict(force_x2=True)):
+        if splitk > 1:
+            C = torch.full((splitk, M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N, **kw)
+        else:
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, act=2, **kw)
+        outs.append(C)
+    d = ops._gemm_desc(opA, opB, outs[-1], M, N, K, a_t=a_t, b_t=b_t, splitk=splitk, c_split_stride=M * N if splitk > 1 else 0, force_x2=True)
+    assert ops.L.load().scl_gemm_uses_wide_tiles(ops.ctypes.byref(d)) == 3
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    ref = A.float() @ B.float().t()
+    got = outs[1].sum(0) if splitk > 1 else outs[1]
+    _close(got, ref if splitk > 1 else torch.relu(ref), 8e-3, "x2 a_t=%s b_t=%s" % (a_t, b_t))
+
+
+def test_two_blocks_per_cu_kernel_epilogues_and_conv_rows(dev):
+    """Every fused epilogue of the encoder (bias + GELU + second output; x gelu'(R); f32 residual; dropout) and the utterance-batched
+    overlapping rows of a conv layer through gemm_x2.hip against the 128 x 128 kernel, bit for bit."""
+    M, N, K = 3 * 199 + 57, 1024, 512
+    A = _rand((M, K), dev, 81, 0.3); W = _rand((N, K), dev, 82, 0.05); Wt = W.t().contiguous()
+    bias = torch.randn(N, device=dev); Rb = _rand((M, N), dev, 83, 1.0); Rf = torch.randn(M, N, device=dev)
+    cases = [
+        (dict(bias=bias, act=1), torch.bfloat16, True),                      # fc1 forward: GELU + pre-activation copy
+        (dict(R=Rb, rmode=2, ract=1), torch.bfloat16, False),                # fc2 data gradient
+        (dict(bias=bias, R=Rf, rmode=1), torch.float32, False),              # out-proj / fc2 forward: f32 residual stream
+        (dict(bias=bias, act=3, drop_p=0.5, drop_seed=1234), torch.bfloat16, True),
+    ]
+    for kw, cdt, c2 in cases:
+        for b_t, opB in ((False, ops.Op(W, K)), (True, ops.Op(Wt, N))):
+            outs = []
+            for sel in (dict(no_w8=True, no_p8=True, no_big=True, no_x2=True), dict(force_x2=True)):
+                C = torch.full((M, N), float("nan"), dtype=cdt, device=dev)
+                C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev) if c2 else None
+                ops.gemm(ops.Op(A, K), opB, C, M, N, K, b_t=b_t, c2=C2, **kw, **sel)
+                outs.append((C, C2))
+            assert torch.equal(outs[0][0], outs[1][0]), kw.keys()
+            if c2:
+                assert torch.equal(outs[0][1], outs[1][1]), kw.keys()
+    Bz, Tin, C_, k, s = 6, 1601, 512, 3, 2
+    Tout = (Tin - k) // s + 1
+    z = _rand((Bz * Tin * C_ + 65536,), dev, 61, 0.3); wk = _rand((C_, k * C_), dev, 62, 0.05)
+    cb = torch.randn(C_, device=dev)
+    outs = []
+    for sel in (dict(no_w8=True, no_p8=True, no_big=True, no_x2=True), dict(force_x2=True)):
+        y = torch.full((Bz * Tout, C_), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(ops.Op(z, s * C_, rpb=Tout, rbstride=Tin * C_), ops.Op(wk, k * C_), y, Bz * Tout, C_, k * C_, bias=cb, **sel)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,b_t", [(12736, 4096, 1024, True), (1000, 520, 256, False), (3 * 206 + 5, 1024, 512, True)])
+def test_wide_tile_epilogue_column_sums(dev, M, N, K, b_t):
+    """SclGemmDesc.colsum_part: the wide tiles also write per-tile column sums of the f32 values they store (the bias gradient of the
+    Linear whose output gradient this GEMM produces).  Against the column sum of an f32-output run of the same GEMM (1e-5 of the
+    column's absolute sum: only the summation order differs), with the x gelu'(R) epilogue of the fc2 data gradient and a row count
+    that leaves the last tile ragged; the bf16 output itself must not change, and a launch that cannot honour the request refuses."""
+    A = _rand((M, K), dev, 91, 0.3); W = _rand((N, K), dev, 92, 0.05)
+    opB = ops.Op(W.t().contiguous(), N) if b_t else ops.Op(W, K)
+    R = _rand((M, N), dev, 93, 1.0)
+    kw = dict(b_t=b_t, R=R, rmode=2, ract=1, force_w8=M < 12000)      # the small cases would otherwise go to the 128 x 128 tiles
+    C0 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.Op(A, K), opB, C0, M, N, K, **kw)
+    rows = ops.gemm_colsum_rows(ops.Op(A, K), opB, C0, M, N, K, **kw)
+    assert rows > 0 and rows % 4 == 0
+    part = torch.full((rows, N), float("nan"), device=dev)
+    C1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.Op(A, K), opB, C1, M, N, K, colsum_part=part, **kw)
+    assert torch.equal(C0, C1)
+    Cf = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(A, K), opB, Cf, M, N, K, **kw)
+    out = torch.empty(N, device=dev)
+    ops.colreduce(part, out, rows, N)
+    assert torch.isfinite(part).all()
+    ref = Cf.double().sum(0)
+    scale = Cf.double().abs().sum(0)
+    assert ((out.double() - ref).abs() / scale).max().item() < 1e-5
+    assert (out - part.sum(0)).abs().max().item() <= 1e-4 * scale.max().item()
+    from scl_amd.lib import SclError
+    with pytest.raises(SclError):          # 128 x 128 tiles cannot: refused, not silently ignored
+        ops.gemm(ops.Op(A, K), opB, C1, M, N, K, colsum_part=part, no_w8=True, **kw)
+
+
 def test_wide_tile_kernel_conv_and_grouped_addressing(dev):
     """Operands the wide kernel must address exactly as the 128x128 kernels do: utterance-batched overlapping rows (conv layer as a
     GEMM: rpb / rbstride / ld < K), a strided utterance-batched output (c_rpb / c_rbstride / ldc, the phase-split transposed

@@ -343,3 +343,15 @@ def test_fused_attention_fwd_bwd(dev, B, T, H):
         assert rel(got, gr) < 2.5e-2, ("qkv"[i], rel(got, gr))
         cos = torch.nn.functional.cosine_similarity(got.flatten().cpu(), gr.flatten().cpu(), dim=0).item()
         assert cos > 0.999, ("qkv"[i], cos)
+    # the same launch with the fused bias-gradient sums: dqkv unchanged bit for bit, bias_part[b] = column sums of utterance b's
+    # dqkv rows (from the f32 accumulators: compared with the sum of the bf16-rounded rows at the rounding of T addends)
+    dq2 = torch.full_like(dqkv, float("nan"))
+    part = torch.full((B, 3 * E), float("nan"), device=dev)
+    ops.attn_bwd(qkv, ctx, dctx, lse, dq2, B, T, H, D, scale, bias_part=part)
+    assert torch.equal(dq2, dqkv)
+    ref_cs = dqkv.float().reshape(B, T, 3 * E).sum(1)
+    bound = 2.0 ** -8 * dqkv.float().abs().reshape(B, T, 3 * E).sum(1) + 1e-6
+    assert ((part - ref_cs).abs() <= bound).all()
+    exact = torch.stack([(q.grad * 1.0).permute(0, 2, 1, 3).reshape(B, T, E), k.grad.permute(0, 2, 1, 3).reshape(B, T, E),
+                         v.grad.permute(0, 2, 1, 3).reshape(B, T, E)], dim=2).reshape(B, T, 3 * E).sum(1)
+    assert rel(part, exact) < 2.5e-2

@@ -342,6 +342,50 @@ FULL_SIZE_GRADS = [
 ]
 
 
+def head_only_reference(m, B, L, y, head_sd):
+    """The oracle's head + losses (torch fp32 autograd, CPU) run on the encoder output the GPU step itself produced, with LL.weight at
+    the bf16 rounding the GPU's LL GEMM multiplies by: what the hand-written head backward must reproduce when nothing upstream differs.
+    Returns (gradients of the head tensors, gradient w.r.t. the encoder output [B*T, E])."""
+    d = m.encoder.bufs(B, L)
+    T, E = d["T"], m.cfg.embed
+    enc = d["out"][: B * T * E].float().cpu().view(B, T, E).clone().requires_grad_(True)
+    sd = {k: v.clone().float() for k, v in head_sd.items()}
+    sd["LL.weight"] = sd["LL.weight"].to(torch.bfloat16).float()
+    for v in sd.values():
+        v.requires_grad_(True)
+    out, feats, emb = OH.head_forward(sd, enc)
+    sum(OH.model_loss(out, feats, emb, y).values()).backward()
+    return {k: v.grad for k, v in sd.items()}, enc.grad.reshape(B * T, E)
+
+
+HEAD_TENSORS = ["backend.m_frame_level.0.weight", "backend.m_frame_level.0.bias", "backend.m_frame_level.3.weight", "backend.m_frame_level.3.bias",
+                "backend.m_frame_level.6.weight", "backend.m_frame_level.6.bias", "backend.m_utt_level.weight", "backend.m_utt_level.bias"]
+
+
+def test_head_backward_is_exact_given_the_encoder_output(dev):
+    """The frame-level head (three 128 x 128 linears + LeakyReLU + mean pool + utterance linear + losses) runs in f32 on the exact-fp32
+    GEMM: fed the SAME encoder output, its parameter gradients agree with torch's fp32 autograd to 1e-4 rel-L2 (LL, whose GEMMs take
+    bf16 operands, and the gradient handed to the encoder: 1e-2).  What is left between the whole step and the fp32 oracle in these
+    tensors (tests below) therefore comes from upstream: a bf16-perturbed pre-activation that changes sign flips its LeakyReLU slope."""
+    cfg = W.W2VConfig.tiny()
+    ssl, head = W.init_state(cfg, seed=91), OH.init_head(cfg.embed, seed=92)
+    m = build(dev, ssl, head)
+    m.eval()
+    B, L = 6, 12000
+    x = 0.1 * torch.randn(B, L, generator=torch.Generator().manual_seed(8))
+    y = torch.tensor([1, 1, 1, 0, 0, 0])
+    out, feats, emb = m(x.to(dev))
+    sum(m.loss(out, feats, emb, y.to(dev), CONF).values()).backward()
+    torch.cuda.synchronize()
+    ref, denc = head_only_reference(m, B, L, y, head)
+    for name in HEAD_TENSORS:
+        assert rl2(m.P.g(name), ref[name]) < 1e-4, (name, rl2(m.P.g(name), ref[name]))
+    assert rl2(m.P.g("LL.weight"), ref["LL.weight"]) < 1e-2 and rl2(m.P.g("LL.bias"), ref["LL.bias"]) < 1e-4
+    T = m.encoder.bufs(B, L)["T"]
+    got = m._head_bufs(B, T)["denc"][: B * T * cfg.embed].float().cpu().view(B * T, cfg.embed)
+    assert rl2(got, denc) < 1e-2
+
+
 def test_full_size_train_step_matches_oracle_at_baseline_shape(dev):
     """BASELINE shape: XLS-R-300M encoder (24 x 1024 x 16 heads x 4096), 4 x 64000-sample clips (T = 199), dropout off — forward
     outputs, the three loss terms (north_star bar: 1e-2 relative at bf16) and 24 gradient tensors covering every GEMM layout
@@ -357,6 +401,8 @@ def test_full_size_train_step_matches_oracle_at_baseline_shape(dev):
         p.grad = None
     total.backward()
     torch.cuda.synchronize()
+    href, denc = head_only_reference(m, 4, 64000, y, head)      # before train_step: its AdamW update moves `head` in place
+    head0 = {k: v.clone() for k, v in head.items()}
     ref_losses, ref_grads, (ro, rf, re), _ = OH.train_step(ssl, head, ocfg, x, y)
     print("4 x 64000 rel-L2: out %.2e feats %.2e emb %.2e" % (rl2(out, ro), rl2(feats, rf), rl2(emb, re)))
     assert rl2(out, ro) < 1e-2 and rl2(feats, rf) < 1e-2 and rl2(emb, re) < 1e-2
@@ -368,11 +414,28 @@ def test_full_size_train_step_matches_oracle_at_baseline_shape(dev):
         got, ref = m.P.g(name).float().cpu().flatten(), ref_grads[name].flatten()
         e, c = rl2(got, ref), cosine(got, ref)
         print("grad %-70s rel-L2 %.2e cos %.6f" % (name, e, c))
-        # one bound for every tensor: the frame-level head linears, whose backward spreads one mean-pool row over all T frames, run
-        # in f32 on the exact-fp32 GEMM (bf16 operands there measured 8e-2 / 0.9969: a rounding that is systematic over the T rows)
-        if not (e < 6e-2 and c > 0.998):
+        # the frame-level head tensors sit behind three LeakyReLUs: where the bf16 encoder moves a pre-activation across zero the slope
+        # jumps 1 <-> 0.01, a sparse O(1) error in d(pre) that no head precision removes (f32 head 7.1e-2, bf16 head 8.1e-2 here);
+        # the head itself is exact — checked right below on the GPU's own encoder output
+        lim_e, lim_c = (1.0e-1, 0.995) if name.startswith("backend.m_frame_level") else (6e-2, 0.998)
+        if not (e < lim_e and c > lim_c):
             bad.append((name, e, c))
     assert not bad, bad
+    for name in HEAD_TENSORS:
+        e = rl2(m.P.g(name), href[name])
+        print("head-only %-40s rel-L2 %.2e" % (name, e))
+        assert e < 1e-4, (name, e)
+    assert rl2(m.P.g("LL.weight"), href["LL.weight"]) < 1e-2
+    flips = 0.0   # fraction of frame-level pre-activations whose sign differs between the step and the fp32 oracle's forward
+    with torch.no_grad():
+        h_g = torch.relu(feats.float().cpu()); h_o = torch.relu(rf)
+        for idx in (0, 3, 6):
+            w, b_ = head0["backend.m_frame_level.%d.weight" % idx], head0["backend.m_frame_level.%d.bias" % idx]
+            pg, po = torch.nn.functional.linear(h_g, w, b_), torch.nn.functional.linear(h_o, w, b_)
+            flips = max(flips, ((pg > 0) != (po > 0)).float().mean().item())
+            h_g, h_o = torch.nn.functional.leaky_relu(pg, 0.01), torch.nn.functional.leaky_relu(po, 0.01)
+    print("LeakyReLU slope flips vs the fp32 oracle: %.3f %% of the pre-activations of the worst layer" % (100 * flips))
+    assert 0.0 < flips < 0.02
 
 
 def test_batch_64_auto_selected_tiles_agree_with_the_validated_small_batch(dev):
