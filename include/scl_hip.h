@@ -195,7 +195,11 @@ int scl_layernorm_bwd_nparts(int M);
 int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* dres, float* dx_f32, void* dx_bf16,
                       float* part, int M, int C, int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, int out_rpb,
-                      int64_t out_rbstride, int64_t out_off, void* stream);
+                      int64_t out_rbstride, int64_t out_off, uint32_t din_seed, float din_p, uint32_t dout_seed, float dout_p, void* stream);
+/* din / dout (p = 0: off): the encoder's element dropout on the output of out_proj / fc2 (fairseq dropout1 / dropout3, p = cfg.dropout,
+ * model/xlsr.py:33-41 runs the encoder in train mode).  din: the column sums of dres (sum_dres == 1) are taken of dres x keep-mask(din_seed,
+ * row * C + col) — the bias gradient of the linear whose dropped output fed the residual.  dout: the bf16 output is multiplied by
+ * keep-mask(dout_seed, row * C + col) — it is the dY operand of the next linear's gradient GEMMs; the f32 output stays unmasked. */
 /* out_rpb > 0: bf16 output row r goes to element (r / out_rpb) * out_rbstride + (r % out_rpb) * lddx + out_off (per-utterance
  * zero padding kept by the caller) */
 /* sum_dres == 1: `part` rows are [dgamma | dbeta | colsum(dres)] (3*C floats per slab instead of 2*C; sum_dres == 2: third row =
@@ -241,6 +245,9 @@ int scl_posconv_weight_pack(const float* v, const float* g, float* norm, void* w
 int scl_posconv_weight_bwd(const float* dwf, const float* v, const float* g, const float* norm, float* sdot_ws,
                            float* dv, float* dg, int E, int Cg, int K, void* stream);
 /* tail of the linear head: mean over frames, m_utt_level, log_softmax (model/wav2vec2_linear_nll.py:88-93,134) */
+/* y = x * keep-mask(seed, i) / (1 - p), to f32 and / or bf16 (in place allowed): fairseq TransformerEncoder.extract_features'
+ * F.dropout(x, p = cfg.dropout) after the positional-conv residual add, its backward, and the backward of dropout_input */
+int scl_dropout_f32(const float* x, float* y_f32, void* y_bf16, int64_t n, uint32_t seed, float p, void* stream);
 int scl_meanpool_fwd(const void* h, float* emb, int B, int T, int C, void* stream);
 int scl_meanpool_bwd(const float* demb, const void* pre, void* dpre, int B, int T, int C, int ract, float drop_p,
                      uint32_t seed, void* stream);
@@ -261,12 +268,15 @@ int scl_softmax_fwd(const float* S, void* P, int64_t R, int T, int ldS, int Tp, 
 int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, int lddP, int Tp, void* stream);
 /* Fused attention for head dim 64 (scores stay on chip).  qkv / dqkv: bf16 [B, T, 3, H, 64]; ctx / dctx: bf16 [B, T, H*64];
  * lse: f32 [B, H, T] row log-sum-exp of the scaled scores.  fwd: T <= 256; bwd: T <= 224 (LDS budget).
- * Replaces F.multi_head_attention_forward inside fairseq's TransformerSentenceEncoderLayer (model/xlsr.py:41) and its backward. */
-int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream);
+ * Replaces F.multi_head_attention_forward inside fairseq's TransformerSentenceEncoderLayer (model/xlsr.py:41) and its backward.
+ * drop_p / drop_seed: attention dropout on the probabilities (fairseq MultiheadAttention.dropout_module, p = cfg.attention_dropout):
+ * keep-mask hash(seed, ((b*H + h)*T + query)*T + key), recomputed by the backward from the same seed; 0 = off. */
+int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, float drop_p, uint32_t drop_seed,
+                 void* stream);
 /* bias_part (optional, f32 [B, 3*H*64]): per-utterance column sums of dqkv, from the f32 accumulators — summed over B (scl_colreduce_f32)
  * they are the q/k/v bias gradients, which otherwise cost a pass over dqkv. */
 int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, float* bias_part, int B, int T,
-                 int H, int D, float scale, void* stream);
+                 int H, int D, float scale, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* feature-extractor layer 0 (Conv1d(1,C,10,5) + LayerNorm + GELU), fused fwd / bwd            */

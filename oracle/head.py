@@ -83,11 +83,11 @@ def model_loss(output, feats, emb, labels, loss_type=1):
             3: {"L_CE": L_CE, "L_CF2": L_CF2}, 4: {"L_CE": L_CE}, 5: {"L_CF1": L_CF1, "L_CF2": L_CF2}}[loss_type]
 
 
-def full_forward(ssl_sd, head_sd, cfg, x, dropout_masks=None):
-    return head_forward(head_sd, W.forward(ssl_sd, cfg, x), dropout_masks)
+def full_forward(ssl_sd, head_sd, cfg, x, dropout_masks=None, enc_masks=None):
+    return head_forward(head_sd, W.forward(ssl_sd, cfg, x, masks=enc_masks), dropout_masks)
 
 
-def train_step(ssl_sd, head_sd, cfg, x, labels, loss_type=1, lr=1e-5, wd=1e-4, dropout_masks=None, opt_state=None):
+def train_step(ssl_sd, head_sd, cfg, x, labels, loss_type=1, lr=1e-5, wd=1e-4, dropout_masks=None, opt_state=None, enc_masks=None):
     """One iteration of main.py:53-80 on CPU with torch autograd + torch.optim.AdamW (main.py:339).
     Mutates the parameter tensors in place; returns (losses dict of floats, grads dict, outputs)."""
     params = {}
@@ -100,7 +100,7 @@ def train_step(ssl_sd, head_sd, cfg, x, labels, loss_type=1, lr=1e-5, wd=1e-4, d
     for p in train.values():
         p.requires_grad_(True)
         p.grad = None
-    out, feats, emb = full_forward(ssl_sd, head_sd, cfg, x, dropout_masks)
+    out, feats, emb = full_forward(ssl_sd, head_sd, cfg, x, dropout_masks, enc_masks)
     losses = model_loss(out, feats, emb, labels, loss_type)
     total = sum(losses.values())
     total.backward()

@@ -125,8 +125,12 @@ def conv_stack(sd, cfg, x):
     return outs
 
 
-def encoder_layer(sd, cfg, n, x, return_attn=False):
-    """fairseq TransformerSentenceEncoderLayer.forward, layer_norm_first=True, no dropout."""
+def encoder_layer(sd, cfg, n, x, return_attn=False, masks=None):
+    """fairseq TransformerSentenceEncoderLayer.forward, layer_norm_first=True.  masks (optional, train mode): dict of explicit
+    keep / (1 - p) factors for this layer — "attn" [B, H, T, T] on the attention probabilities (MultiheadAttention.dropout_module),
+    "d1" [B, T, E] (dropout1, on out_proj's output), "d2" [B, T, ffn] (dropout2, after the activation), "d3" [B, T, E] (dropout3, on
+    fc2's output); a missing key = no dropout at that site."""
+    masks = masks or {}
     p = "encoder.layers.%d." % n
     B, T, E = x.shape
     H = cfg.heads
@@ -140,23 +144,33 @@ def encoder_layer(sd, cfg, n, x, return_attn=False):
     k = k.view(B, T, H, D).transpose(1, 2)
     v = v.view(B, T, H, D).transpose(1, 2)
     attn = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
-    ctx = (attn @ v).transpose(1, 2).reshape(B, T, E)
-    x = res + F.linear(ctx, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+    pa = attn * masks["attn"] if "attn" in masks else attn
+    ctx = (pa @ v).transpose(1, 2).reshape(B, T, E)
+    o = F.linear(ctx, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+    x = res + (o * masks["d1"] if "d1" in masks else o)
     res = x
     h = F.layer_norm(x, (E,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], 1e-5)
     h = F.gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
-    x = res + F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    if "d2" in masks:
+        h = h * masks["d2"]
+    o = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    x = res + (o * masks["d3"] if "d3" in masks else o)
     return (x, attn) if return_attn else x
 
 
-def forward(sd, cfg, x, return_all=False):
+def forward(sd, cfg, x, return_all=False, masks=None):
     """x: [B, L] fp32 raw waveform (NOT normalised — the reference feeds it as is, Appendix A).
-    Returns [B, T, embed]; with return_all also a dict of intermediates."""
+    Returns [B, T, embed]; with return_all also a dict of intermediates.  masks (optional): explicit element-dropout factors as
+    fairseq's train mode would draw them — "in" [B, T, E] (Wav2Vec2Model.dropout_input on the projected features), "enc" [B, T, E]
+    (TransformerEncoder: F.dropout after the positional-conv residual add) and per layer n a dict under key n (see encoder_layer)."""
+    masks = masks or {}
     inter = {}
     feats = conv_stack(sd, cfg, x)
     inter["conv"] = feats
     h = F.layer_norm(feats[-1], (cfg.conv_dim,), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)
     h = F.linear(h, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
+    if "in" in masks:
+        h = h * masks["in"]
     inter["proj"] = h
     # positional conv: Conv1d(E, E, k, padding=k//2, groups) then drop the last frame (even k), GELU
     w = pos_conv_weight(sd)
@@ -164,11 +178,13 @@ def forward(sd, cfg, x, return_all=False):
     if cfg.pos_k % 2 == 0:
         pc = pc[:, :, :-1]
     h = h + F.gelu(pc).transpose(1, 2)
+    if "enc" in masks:
+        h = h * masks["enc"]
     inter["pos"] = h
     # (fairseq pads T to a multiple of 2 with a key-padding mask here: a mathematical no-op)
     layers = []
     for n in range(cfg.layers):
-        h = encoder_layer(sd, cfg, n, h)
+        h = encoder_layer(sd, cfg, n, h, masks=masks.get(n))
         layers.append(h)
     inter["layers"] = layers
     h = F.layer_norm(h, (cfg.embed,), sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], 1e-5)

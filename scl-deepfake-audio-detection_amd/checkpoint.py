@@ -84,9 +84,8 @@ def read_fairseq_checkpoint(path):
 
 
 def load_pretrained_into(model, path, strict_dropout=True):
-    """Copy the checkpoint's encoder tensors into `model` (names prefixed with ssl_model.model.) and return the encoder's
-    probabilities.  The HIP encoder implements LayerDrop but no element dropout inside the encoder: a checkpoint whose
-    cfg asks for one is refused (or, with strict_dropout False / SCL_ALLOW_DROPOUT_MISMATCH=1, loaded with a warning)."""
+    """Copy the checkpoint's encoder tensors into `model` (names prefixed with ssl_model.model.), set the encoder's element-dropout
+    probabilities from its cfg and return all of them (LayerDrop included; the caller applies that one)."""
     tensors, probs = read_fairseq_checkpoint(path)
     own = model.state_dict()
     sd, skipped = {}, []
@@ -100,12 +99,16 @@ def load_pretrained_into(model, path, strict_dropout=True):
     if missing:
         raise ValueError("pre-trained checkpoint %s lacks %d encoder tensors of this architecture (first: %s)" % (path, len(missing), missing[:3]))
     model.load_state_dict(sd, strict=False)
-    nz = {k: v for k, v in probs.items() if k in DROPOUT_KEYS and v != 0.0}
+    # element dropout inside the encoder: the probabilities the checkpoint was trained with are the ones fairseq's model object carries
+    # into fine-tuning (model/xlsr.py:14-16 builds the model from the checkpoint's own cfg and runs it in train mode, :33-41).
+    # dropout_features acts on a tensor the features_only output never reads.
+    cfg = model.cfg
+    for key in ("dropout", "attention_dropout", "activation_dropout", "dropout_input"):
+        if key in probs:
+            setattr(cfg, key, float(probs[key]))
+    nz = {k: v for k, v in probs.items() if k in DROPOUT_KEYS and k != "dropout_features" and v != 0.0}
     if nz:
-        msg = "checkpoint cfg asks for encoder dropout %s; the HIP encoder applies none (LayerDrop is supported)" % nz
-        if strict_dropout and os.environ.get("SCL_ALLOW_DROPOUT_MISMATCH", "0") != "1":
-            raise NotImplementedError(msg + " — set SCL_ALLOW_DROPOUT_MISMATCH=1 to fine-tune without it")
-        warnings.warn(msg)
+        print("[scl] encoder element dropout from the checkpoint cfg: %s" % nz)
     if skipped:
         print("[scl] pre-trained checkpoint: %d tensors without a counterpart ignored (first: %s)" % (len(skipped), skipped[:3]))
     return probs

@@ -123,8 +123,9 @@ __device__ __forceinline__ bf16x8 att_frag_tr(const char* tile, int rowa, int ro
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
-                                                       int T, int H, float scale) {
+template <bool DROP>      // attention dropout compiled in only where asked for: its index arithmetic pushes the plain kernel over its 128 registers
+__global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                       int T, int H, float scale, float drop_p, uint32_t drop_seed) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -187,6 +188,16 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
         if (g == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = scale * m + __logf(l);
+        if (DROP) {      // attention dropout (fairseq MultiheadAttention dropout_module on the probabilities): keep-mask by (row, key)
+            const uint64_t rowbase = (((uint64_t)b * H + h) * T + (uint64_t)(q < T ? q : 0)) * T;
+#pragma unroll
+            for (int t = 0; t < ATT_NTMAX; ++t) {
+                if (t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][r] *= dropout_scale(drop_seed, rowbase + (uint64_t)(16 * t + 4 * g + r), drop_p);
+                }
+            }
+        }
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -256,7 +267,8 @@ __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [
 
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                           bf16_t* __restrict__ dqkv, float* __restrict__ bias_part, int T, int H, float scale) {
+                                                           bf16_t* __restrict__ dqkv, float* __restrict__ bias_part, int T, int H, float scale,
+                                                           float drop_p, uint32_t drop_seed) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -370,8 +382,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                             for (int r = 0; r < 4; ++r) {
                                 const int qq = 32 * u + 16 * a + 4 * g + r;
                                 const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
-                                P[a][j][r] = p;
-                                dS[a][j][r] = p * (dp[r] - dq_[a][r]);
+                                // attention dropout: O = (P x mask) V, so dV takes P x mask and dP = (dO V^T) x mask; delta = <dO, O> is unchanged
+                                const float mk = drop_p > 0.f ? dropout_scale(drop_seed, (((uint64_t)b * H + h) * T + (uint64_t)(qq < T ? qq : 0)) * T + (uint64_t)key, drop_p) : 1.f;
+                                P[a][j][r] = p * mk;
+                                dS[a][j][r] = p * (dp[r] * mk - dq_[a][r]);
                             }
                         }
                     }
@@ -483,18 +497,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
 
 }  // namespace
 
-extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream) {
-    SCL_REQUIRE(qkv && ctx && lse && B > 0 && H > 0, "attn_fwd: bad args");
+extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, float drop_p, uint32_t drop_seed,
+                            void* stream) {
+    SCL_REQUIRE(qkv && ctx && lse && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f, "attn_fwd: bad args");
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 256, "attn_fwd: fused path needs head dim 64 and T <= 256 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
     const size_t lds = (size_t)2 * rows * 128;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale, drop_p, drop_seed);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale, drop_p, drop_seed);
     return scl_check_launch("scl_attn_fwd");
 }
 
 extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, float* bias_part, int B, int T,
-                            int H, int D, float scale, void* stream) {
-    SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0, "attn_bwd: bad args");
+                            int H, int D, float scale, float drop_p, uint32_t drop_seed, void* stream) {
+    SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f, "attn_bwd: bad args");
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 224, "attn_bwd: fused path needs head dim 64 and T <= 224 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
     const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 8 * 2048 + 64 * 4;
@@ -504,6 +520,6 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd8_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale);
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
     return scl_check_launch("scl_attn_bwd");
 }

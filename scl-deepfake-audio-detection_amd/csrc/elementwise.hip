@@ -430,6 +430,20 @@ extern "C" int scl_utt_head_bwd(const float* dlogp, const float* logp, const flo
     hipLaunchKernelGGL(utt_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dlogp, logp, emb, W, demb_in, demb, dW, db, ws, B, C, NC);
     return scl_check_launch("scl_utt_head_bwd");
 }
+// y[i] = x[i] * keep(seed, i) / (1 - p): the element-dropout sites of the encoder that no GEMM epilogue covers (fairseq
+// TransformerEncoder.extract_features: F.dropout after the positional-conv residual add; its backward; the backward of dropout_input)
+__global__ void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ y_bf, int64_t n, uint32_t seed, float p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i] * dropout_scale(seed, (uint64_t)i, p);
+        if (y) y[i] = v;
+        if (y_bf) y_bf[i] = f2bf(v);
+    }
+}
+extern "C" int scl_dropout_f32(const float* x, float* y_f32, void* y_bf16, int64_t n, uint32_t seed, float p, void* stream) {
+    SCL_REQUIRE(x && (y_f32 || y_bf16) && n > 0 && p >= 0.f && p < 1.f, "dropout_f32: bad args");
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y_f32, (bf16_t*)y_bf16, n, seed, p);
+    return scl_check_launch("scl_dropout_f32");
+}
 extern "C" int scl_add_f32(const float* a, const float* b, float* out, void* out_bf16, int64_t n, void* stream) {
     SCL_REQUIRE(a && (out || out_bf16) && n > 0, "add_f32: bad args");
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16_t*)out_bf16, n);

@@ -106,7 +106,13 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
                                                      bf16_t* __restrict__ dx_bf, float* __restrict__ part, int M, int C, int64_t ldx,
                                                      int64_t lddy, int64_t lddx, int rows_per_block, int act, int sum_dres,
-                                                     int out_rpb, int64_t out_rbstride, int64_t out_off) {
+                                                     int out_rpb, int64_t out_rbstride, int64_t out_off,
+                                                     uint32_t din_seed, float din_p, uint32_t dout_seed, float dout_p) {
+    // Element dropout of the encoder (fairseq dropout1 / dropout3, p = cfg.dropout, on the output of out_proj / fc2 BEFORE the residual
+    // add): the residual gradient `dres` passes this LayerNorm unmasked, but (a) its column sum = the bias gradient of the linear that
+    // fed the residual must be taken of dres x keep-mask of THAT linear's dropout (din), and (b) the bf16 copy of the output, which
+    // is only ever the dY operand of the next linear's weight / data gradient GEMMs, carries that linear's mask (dout).  Masks are
+    // recomputed from (seed, element index = row * C + column), exactly as the forward GEMM epilogue drew them.
     // sum_dres: also emit the column sums of `dres` (third partial row).  In a pre-LN transformer block the residual gradient
     // that enters this LayerNorm's backward IS the gradient of the preceding linear's output (fc2 / out_proj), so its column
     // sum is that linear's bias gradient — read here anyway, summed for free instead of by a separate pass over [M, C].
@@ -170,7 +176,10 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                     float r[8];
                     load8<true>(dres, (int64_t)row * lddx + c, r);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { o[i] += r[i]; ar[ch][i] += r[i]; }
+                    for (int i = 0; i < 8; ++i) {
+                        o[i] += r[i];
+                        ar[ch][i] += din_p > 0.f ? r[i] * dropout_scale(din_seed, (uint64_t)((int64_t)row * C + c + i), din_p) : r[i];
+                    }
                 }
                 if (sum_dres == 2) {      // column sums of the OUTPUT: dx of a conv layer's LayerNorm is d(conv output) => conv bias gradient
 #pragma unroll
@@ -182,6 +191,10 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
                     // by the caller): the phase-split conv dgrad reads [dy[u-1], dy[u]] as ONE overlapping GEMM row
                     const int64_t orow = out_rpb > 0 ? (int64_t)(row / out_rpb) * out_rbstride + (int64_t)(row % out_rpb) * lddx + out_off
                                                      : (int64_t)row * lddx;
+                    if (dout_p > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] *= dropout_scale(dout_seed, (uint64_t)((int64_t)row * C + c + i), dout_p);
+                    }
                     store8_bf16(dx_bf, orow + c, o);
                 }
             }
@@ -376,7 +389,10 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
                                  const float* rstd, const float* gamma, const float* beta, const float* dres,
                                  float* dx_f32, void* dx_bf16, float* part, int M, int C,
                                  int64_t ldx, int64_t lddy, int64_t lddx, int act, int sum_dres, int out_rpb, int64_t out_rbstride,
-                                 int64_t out_off, void* stream) {
+                                 int64_t out_off, uint32_t din_seed, float din_p, uint32_t dout_seed, float dout_p, void* stream) {
+    SCL_REQUIRE(din_p >= 0.f && din_p < 1.f && dout_p >= 0.f && dout_p < 1.f, "layernorm_bwd: dropout probabilities in [0, 1)");
+    SCL_REQUIRE(din_p == 0.f || sum_dres == 1, "layernorm_bwd: din mask applies to the column sums of dres (sum_dres = 1)");
+    SCL_REQUIRE(dout_p == 0.f || (dx_bf16 && out_rpb == 0 && lddx == C), "layernorm_bwd: dout mask needs a plain [M, C] bf16 output");
     SCL_REQUIRE(out_rpb == 0 || (dx_bf16 && out_rpb > 0 && (out_rbstride & 7) == 0 && (out_off & 7) == 0), "layernorm_bwd: padded output needs dx_bf16");
     SCL_REQUIRE(sum_dres == 0 || (sum_dres == 1 && dres) || (sum_dres == 2 && !dres), "layernorm_bwd: sum_dres 1 needs dres, 2 excludes it");
     SCL_REQUIRE(dy && x && mean && rstd && gamma && part && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
@@ -390,7 +406,7 @@ extern "C" int scl_layernorm_bwd(const void* dy, int dy_f32, const void* x, int 
     dim3 grid(nblk), block(256);
 #define LN_BWD(XF, DF, NC) hipLaunchKernelGGL((ln_bwd_kernel<XF, DF, NC>), grid, block, lds, s, dy, x, mean, rstd, gamma, beta, dres, \
                                               dx_f32, (bf16_t*)dx_bf16, part, M, C, ldx, lddy, lddx, rows_per_block, act, sum_dres, \
-                                              out_rpb, out_rbstride, out_off)
+                                              out_rpb, out_rbstride, out_off, din_seed, din_p, dout_seed, dout_p)
 #define LN_BWD_C(XF, DF) do { if (C <= 512) LN_BWD(XF, DF, 1); else if (C <= 1024) LN_BWD(XF, DF, 2); else LN_BWD(XF, DF, 4); } while (0)
     if (x_f32 && dy_f32) LN_BWD_C(true, true);
     else if (x_f32) LN_BWD_C(true, false);

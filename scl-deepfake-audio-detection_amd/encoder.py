@@ -22,12 +22,18 @@ from .ops import Op
 
 # fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
 FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
+WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "0") != "0"
 
 
 class W2VConfig:
     def __init__(self, conv_dim=512, conv_kernels=(10, 3, 3, 3, 3, 2, 2), conv_strides=(5, 2, 2, 2, 2, 2, 2), embed=1024,
                  layers=24, heads=16, ffn=4096, pos_k=128, pos_groups=16, final_dim=768, latent_vars=320, latent_groups=2,
-                 encoder_layerdrop=0.0):
+                 encoder_layerdrop=0.0, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0):
+        # element-dropout probabilities of fairseq's Wav2Vec2Config (read from the checkpoint's cfg by scl_amd.checkpoint; the
+        # reference runs the encoder in train mode, model/xlsr.py:33-41): `dropout` after the positional conv and on the outputs of
+        # out_proj / fc2, `attention_dropout` on the attention probabilities, `activation_dropout` after the FFN's GELU, `dropout_input`
+        # on the projected features
+        self.dropout, self.attention_dropout, self.activation_dropout, self.dropout_input = dropout, attention_dropout, activation_dropout, dropout_input
         self.conv_dim, self.conv_kernels, self.conv_strides = conv_dim, tuple(conv_kernels), tuple(conv_strides)
         self.embed, self.layers, self.heads, self.ffn = embed, layers, heads, ffn
         self.pos_k, self.pos_groups = pos_k, pos_groups
@@ -219,6 +225,41 @@ class Encoder:
         self._bufs[key] = d
         return d
 
+    # ---- element dropout: seeds --------------------------------------------------------------------
+    # Every site draws its keep-mask from hash(site seed, element index) in the kernel that applies it (GEMM epilogue, attention,
+    # LayerNorm backward, scl_dropout_f32); the backward recomputes the mask from the same seed.  A site seed mixes the step's seed
+    # with (layer, site).  Launch plans replay recorded argument lists, so every call that carries a seed leaves a "slot" behind
+    # (the descriptor or the argument list + position) and apply_seeds() re-seeds the slots before a replay.
+    SITE_IN, SITE_ENC, SITE_ATTN, SITE_1, SITE_2, SITE_3 = 1, 2, 3, 4, 5, 6
+
+    @staticmethod
+    def site_seed(step_seed, layer, site):
+        x = (int(step_seed) * 0x9E3779B1 + (layer + 1) * 0x85EBCA77 + site * 0xC2B2AE3D) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 12
+        return x & 0x7FFFFFFF
+
+    def drop_probs(self, training):
+        c = self.cfg
+        if not training:
+            return 0.0, 0.0, 0.0, 0.0
+        return float(c.dropout), float(c.attention_dropout), float(c.activation_dropout), float(c.dropout_input)
+
+    @staticmethod
+    def _slot(slots, handle, pos, layer, site):
+        """handle: a GEMM descriptor (pos None) or a recorded call entry (argument position pos); None when nothing was recorded."""
+        if handle is not None:
+            slots.append((handle, pos, layer, site))
+
+    def apply_seeds(self, slots, step_seed):
+        for handle, pos, layer, site in slots:
+            sd = self.site_seed(step_seed, layer, site)
+            if pos is None:
+                handle.drop_seed = sd
+            else:
+                handle[1][pos] = sd
+
     # ---- helpers ---------------------------------------------------------------------------------
     @contextlib.contextmanager
     def _side(self):
@@ -243,8 +284,9 @@ class Encoder:
         sk = _splitk(tiles, ksteps)
         # wide tiles (gemm_w8.hip: 256 x 256 output tiles, one 8-wave block per CU): size the split for one round of the 256 CUs
         t256 = ((Mo + 255) // 256) * ((No + 255) // 256) * kw.get("nb2", 1)
-        if t256 >= 32:
-            skw = max(1, min(8, (256 + t256 // 2) // t256, ksteps // 8))
+        if t256 >= 32 or (WGRAD_SMALL_SPLIT and t256 >= 12):
+            # 12-31 tiles (out-proj: 16): up to 16 slabs fill the 256 CUs once; the 128 x 128 sizing below left 160 blocks of 25 K steps
+            skw = max(1, min(8 if t256 >= 32 else 16, (256 + t256 // 2) // t256, ksteps // 8))
             if ops.gemm_wide_kind(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, splitk=skw, c_split_stride=out.numel() if skw > 1 else 0, **kw):
                 sk = skw
         if sk == 1:
@@ -271,10 +313,14 @@ class Encoder:
             ops.colreduce_seg(d["ln_part"], self.P.grad[ow:ow + 2 * C], nparts, 3 * C, out2=self.P.g(self.n(resid_bias)), split=2 * C)
 
     # ---- forward ---------------------------------------------------------------------------------
-    def forward(self, x, training=True, refresh=True):
-        """x [B, L] fp32 contiguous on the GPU -> (enc_out bf16 [B*T, E], ctx)."""
+    def forward(self, x, training=True, refresh=True, step_seed=0):
+        """x [B, L] fp32 contiguous on the GPU -> (enc_out bf16 [B*T, E], ctx).  step_seed: seed of this step's element-dropout masks."""
         cfg, P = self.cfg, self.P
         B, L = x.shape
+        p_res, p_attn, p_act, p_in = self.drop_probs(training)
+        slots = []
+        sseed = lambda layer, site: self.site_seed(step_seed, layer, site)
+        recording = ops._rec() is not None
         if refresh:
             self.refresh_weights()
         d = self.bufs(B, L)
@@ -293,12 +339,19 @@ class Encoder:
                               d["cmean"][i], d["crstd"][i], B * Tout, C, act=1)
         ops.layernorm_fwd(d["z"][-1], self.b("layer_norm.weight"), self.b("layer_norm.bias"), d["h0"], None, d["fmean"],
                           d["frstd"], M, C)
-        ops.gemm(Op(d["h0"], C), self.W("post_extract_proj.weight", C), d["x0"], M, E, C, bias=self.b("post_extract_proj.bias"))
+        dsc = ops.gemm(Op(d["h0"], C), self.W("post_extract_proj.weight", C), d["x0"], M, E, C, bias=self.b("post_extract_proj.bias"),
+                       drop_p=p_in, drop_seed=sseed(-1, self.SITE_IN))        # dropout_input
+        if p_in > 0 and recording:
+            self._slot(slots, dsc, None, -1, self.SITE_IN)
         # -- positional conv (grouped, weight-normed), GELU, residual (M2 head)
         ops.pad_rows(d["x0"], d["xpad"], B, T, E, T + K, K // 2)
         ops.gemm(Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wf, K * Cg, bs2=Cg * K * Cg),
                  d["xin"][0], M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=self.b("encoder.pos_conv.0.bias"), bias_bs2=Cg,
                  act=ACT_GELU, c2=d["pc_pre"], R=d["x0"], rmode=1)
+        if p_res > 0:      # F.dropout(x + pos_conv(x), p = cfg.dropout): after the residual add, so not a GEMM epilogue
+            self._slot(slots, ops.dropout(d["xin"][0], d["xin"][0], None, M * E, sseed(-1, self.SITE_ENC), p_res), ops.DROPOUT_SEED, -1, self.SITE_ENC)
+        if p_attn > 0 and not d["fused_attn"]:
+            raise NotImplementedError("attention_dropout needs the fused attention kernels (head dim 64, T <= 224)")
         # -- transformer layers
         skipped = []
         for n in range(cfg.layers):
@@ -314,24 +367,33 @@ class Encoder:
                      bias=self.b(pn + "self_attn.q_proj.bias"))  # q,k,v biases are adjacent in the flat buffer
             qkv = d["qkv"][n]
             if d["fused_attn"]:
-                ops.attn_fwd(qkv, d["ctx"][n], d["lse"][n], B, T, H, D, D ** -0.5)
+                e = ops.attn_fwd(qkv, d["ctx"][n], d["lse"][n], B, T, H, D, D ** -0.5, drop_p=p_attn, drop_seed=sseed(n, self.SITE_ATTN))
+                if p_attn > 0:
+                    self._slot(slots, e, ops.ATTN_FWD_SEED, n, self.SITE_ATTN)
             else:
                 ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
                          nb1=B, nb2=H, alpha=D ** -0.5, ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
                 ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, Tp, Tp)
                 ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
                          d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
-            ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
-                     bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
+            dsc = ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
+                           bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1, drop_p=p_res, drop_seed=sseed(n, self.SITE_1))    # dropout1
+            if p_res > 0 and recording:
+                self._slot(slots, dsc, None, n, self.SITE_1)
             ops.layernorm_fwd(d["x1"][n], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"),
                               d["h2"][n], None, d["m2"][n], d["r2"][n], M, E)
-            ops.gemm(Op(d["h2"][n], E), self.W(pn + "fc1.weight", E), d["a"][n], M, Fd, E, bias=self.b(pn + "fc1.bias"),
-                     act=ACT_GELU, c2=d["f"][n])
-            ops.gemm(Op(d["a"][n], Fd), self.W(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"),
-                     R=d["x1"][n], rmode=1)
+            dsc = ops.gemm(Op(d["h2"][n], E), self.W(pn + "fc1.weight", E), d["a"][n], M, Fd, E, bias=self.b(pn + "fc1.bias"),
+                           act=ACT_GELU, c2=d["f"][n], drop_p=p_act, drop_seed=sseed(n, self.SITE_2))                         # dropout2 (activation)
+            if p_act > 0 and recording:
+                self._slot(slots, dsc, None, n, self.SITE_2)
+            dsc = ops.gemm(Op(d["a"][n], Fd), self.W(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"),
+                           R=d["x1"][n], rmode=1, drop_p=p_res, drop_seed=sseed(n, self.SITE_3))                                # dropout3
+            if p_res > 0 and recording:
+                self._slot(slots, dsc, None, n, self.SITE_3)
         ops.layernorm_fwd(d["xin"][cfg.layers], self.b("encoder.layer_norm.weight"), self.b("encoder.layer_norm.bias"),
                           d["out"], None, d["omean"], d["orstd"], M, E)
-        return d["out"], {"d": d, "x": x, "B": B, "L": L, "skipped": skipped}
+        return d["out"], {"d": d, "x": x, "B": B, "L": L, "skipped": skipped, "drop": (p_res, p_attn, p_act, p_in), "step_seed": step_seed,
+                          "drop_slots": slots}
 
     # ---- fp32 scoring forward ----------------------------------------------------------------------
     def _f32_weights(self):
@@ -416,14 +478,25 @@ class Encoder:
         D, Cg = E // H, E // G
         Ts, T, M, Tp = d["Ts"], d["T"], d["M"], d["Tp"]
         nlnM = ops.layernorm_bwd_nparts(M)
+        p_res, p_attn, p_act, p_in = ctx.get("drop", (0.0, 0.0, 0.0, 0.0))
+        step_seed = ctx.get("step_seed", 0)
+        slots = []
+        sseed = lambda layer, site: self.site_seed(step_seed, layer, site)
+        recording = ops._rec() is not None
+        active = [n for n in range(cfg.layers) if n not in ctx["skipped"]]
+        def mask3_of(layer_list):      # dropout3 mask of the topmost active layer of the list: the bf16 gradient handed down to it carries it
+            return ((sseed(layer_list[-1], self.SITE_3), p_res), layer_list[-1]) if (p_res > 0 and layer_list) else ((0, 0.0), None)
         # final LayerNorm
         # residual-gradient buffers rotate over three (f32, bf16) pairs: a LayerNorm backward never writes the pair a weight-gradient
         # GEMM of the same layer may still be reading on the second stream
         rot = [(d["dx_a"], d["dxbf_a"]), (d["dx_b"], d["dxbf_b"]), (d["dx_c"], d["dxbf_c"])]
         cur = 0
         dx, dxb = rot[cur]
-        ops.layernorm_bwd(d_out, d["xin"][cfg.layers], d["omean"], d["orstd"], self.b("encoder.layer_norm.weight"), None, None,
-                          dx, dxb, d["ln_part"], M, E)
+        dout, lyr = mask3_of(active)
+        e = ops.layernorm_bwd(d_out, d["xin"][cfg.layers], d["omean"], d["orstd"], self.b("encoder.layer_norm.weight"), None, None,
+                              dx, dxb, d["ln_part"], M, E, dout=dout)
+        if lyr is not None:
+            self._slot(slots, e, ops.LN_BWD_DOUT_SEED, lyr, self.SITE_3)
         self._ln_grads(d, nlnM, E, "encoder.layer_norm.weight", "encoder.layer_norm.bias")
         other, otherb = rot[(cur + 1) % 3]
         for n in reversed(range(cfg.layers)):
@@ -440,11 +513,13 @@ class Encoder:
             with self._side():
                 self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
             # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
-            fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU)
+            fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
             nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
             if nrows * Fd > d["cs_fused"].numel():
                 nrows = 0
-            ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
+            dsc = ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
+            if p_act > 0 and recording:
+                self._slot(slots, dsc, None, n, self.SITE_2)
             if nrows:
                 ops.colreduce(d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd)
             with self._side():
@@ -453,8 +528,13 @@ class Encoder:
                 self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
-            ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_part"], M, E, sum_dres=True)
+            # dres = d(xout): fc2.bias.grad = colsum(dres x dropout3 mask); the bf16 output d(x1) feeds out_proj's gradients: dropout1 mask
+            e = ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
+                                  other, otherb, d["ln_part"], M, E, sum_dres=True,
+                                  din=(sseed(n, self.SITE_3), p_res), dout=(sseed(n, self.SITE_1), p_res))
+            if p_res > 0:
+                self._slot(slots, e, ops.LN_BWD_DIN_SEED, n, self.SITE_3)
+                self._slot(slots, e, ops.LN_BWD_DOUT_SEED, n, self.SITE_1)
             self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias")
             cur = (cur + 1) % 3
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d x1
@@ -464,8 +544,10 @@ class Encoder:
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
             qkv, dqkv = d["qkv"][n], d["dqkv"]
             if d["fused_attn"]:
-                ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5,
-                             bias_part=d["qkv_bias_part"] if FUSED_BIAS_GRAD else None)
+                e = ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5,
+                                 bias_part=d["qkv_bias_part"] if FUSED_BIAS_GRAD else None, drop_p=p_attn, drop_seed=sseed(n, self.SITE_ATTN))
+                if p_attn > 0:
+                    self._slot(slots, e, ops.ATTN_BWD_SEED, n, self.SITE_ATTN)
                 if FUSED_BIAS_GRAD:       # q/k/v bias gradients: per-utterance column sums out of attn_bwd's accumulators, summed over B
                     ops.colreduce(d["qkv_bias_part"], self._qkv_view(pn, "bias"), B, 3 * E)
             else:
@@ -490,8 +572,15 @@ class Encoder:
                 self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             # dx (= d x1) is the gradient of out_proj's output: out_proj.bias.grad rides on this LayerNorm backward
-            ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
-                              other, otherb, d["ln_part"], M, E, sum_dres=True)
+            # dres = d(x1): out_proj.bias.grad = colsum(dres x dropout1 mask); the bf16 output d(xin) feeds the fc2 gradients of the next
+            # active layer below: its dropout3 mask
+            dout, lyr = mask3_of([m_ for m_ in active if m_ < n])
+            e = ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
+                                  other, otherb, d["ln_part"], M, E, sum_dres=True, din=(sseed(n, self.SITE_1), p_res), dout=dout)
+            if p_res > 0:
+                self._slot(slots, e, ops.LN_BWD_DIN_SEED, n, self.SITE_1)
+                if lyr is not None:
+                    self._slot(slots, e, ops.LN_BWD_DOUT_SEED, lyr, self.SITE_3)
             self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
                            resid_bias=pn + "self_attn.out_proj.bias")
             cur = (cur + 1) % 3
@@ -501,6 +590,8 @@ class Encoder:
                 ops.host_callback(self.on_grads_ready, P.off(self.n(pn + "self_attn_layer_norm.weight")))
         # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
         pb = K // 2 - 1
+        if p_res > 0:      # backward of F.dropout(x0 + pos_conv(x0)): dx = d(xin[0]) x mask, in place (nothing reads the unmasked value again)
+            self._slot(slots, ops.dropout(dx, dx, None, M * E, sseed(-1, self.SITE_ENC), p_res), ops.DROPOUT_SEED, -1, self.SITE_ENC)
         ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)
         ops.colsum_reduce(d["dcpad"], d["cs_part"], P.g(self.n("encoder.pos_conv.0.bias")), B * (T + K), E)
         dwf = d["dwf"]
@@ -513,7 +604,10 @@ class Encoder:
         ops.gemm(Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wd, K * Cg, bs2=Cg * K * Cg),
                  other, M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, R=dx, rmode=1)
         dx0 = other
-        ops.cast_bf16(dx0, otherb, M * E)
+        if p_in > 0:       # backward of dropout_input: d(post_extract_proj output) = dx0 x mask (f32 for the bias sum, bf16 for the GEMMs)
+            self._slot(slots, ops.dropout(dx0, dx0, otherb, M * E, sseed(-1, self.SITE_IN), p_in), ops.DROPOUT_SEED, -1, self.SITE_IN)
+        else:
+            ops.cast_bf16(dx0, otherb, M * E)
         # ---- post_extract_proj + feature LayerNorm
         self._bias_grad(d, dx0, M, E, "post_extract_proj.bias")
         self._wgrad(d, Op(otherb, E), Op(d["h0"], C), P.g(self.n("post_extract_proj.weight")), E, C, M)
@@ -551,6 +645,7 @@ class Encoder:
                       self.b(fe % 0 + "2.1.bias"), d["dz"][0], d["conv0_ws"], P.g(self.n(fe % 0 + "0.weight")),
                       P.g(self.n(fe % 0 + "0.bias")), P.g(self.n(fe % 0 + "2.1.weight")), P.g(self.n(fe % 0 + "2.1.bias")),
                       B, L, C, cfg.conv_kernels[0], cfg.conv_strides[0], stats=d["conv0_stats"])
+        return slots
 
     def _qkv_view(self, pn, kind):
         """q/k/v gradients are adjacent in the flat buffer: one [3E, E] wgrad / [3E] bias-grad output."""

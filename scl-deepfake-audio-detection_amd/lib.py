@@ -90,7 +90,7 @@ def _protos():
         "scl_layernorm_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f32, _i32, _vp], _i32),
         "scl_layernorm_bwd_nparts": ([_i32], _i32),
         "scl_layernorm_bwd": ([_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64,
-                               _i64, _i32, _i32, _i32, _i64, _i64, _vp], _i32),
+                               _i64, _i32, _i32, _i32, _i64, _i64, _u32, _f32, _u32, _f32, _vp], _i32),
         "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
         "scl_colsum_nparts": ([_i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
@@ -105,6 +105,7 @@ def _protos():
         "scl_conv_weight_unpack_grad": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_posconv_weight_pack": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_posconv_weight_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_dropout_f32": ([_vp, _vp, _vp, _i64, _u32, _f32, _vp], _i32),
         "scl_meanpool_fwd": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_meanpool_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _u32, _vp], _i32),
         "scl_meanpool_fwd_f32": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
@@ -114,8 +115,8 @@ def _protos():
         # attention.hip
         "scl_softmax_fwd": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
-        "scl_attn_fwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
-        "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_attn_fwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp], _i32),
+        "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp], _i32),
         # conv0.hip
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_conv0_fwd_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),

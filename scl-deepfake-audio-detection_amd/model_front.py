@@ -172,13 +172,16 @@ class FrontHeadModel(nn.Module):
         use_plan = self.cfg.encoder_layerdrop == 0 or not ssl_train
         pk = ("fwd", ssl_train)
         plan = st["plans"].get(pk) if use_plan else None
+        self._drop_step = (getattr(self, "_drop_step", 0x5EED + 7919 * int(getattr(self, "rank", 0))) * 1664525 + 1013904223) & 0x7FFFFFFF
         if plan is not None:
+            ectx = plan["saved"]["ectx"]
+            self.ssl.apply_seeds(ectx["drop_slots"], self._drop_step)      # the encoder's element-dropout sites (none at p = 0)
             ops.replay(plan["calls"])
-            return st["feats"], plan["saved"]
+            return st["feats"], dict(plan["saved"], ectx=dict(ectx, step_seed=self._drop_step))
         if use_plan:
             ops.start_recording()
         P, E = self.P, self.cfg.embed
-        enc_out, ectx = self.ssl.forward(st["x"], training=ssl_train, refresh=False)
+        enc_out, ectx = self.ssl.forward(st["x"], training=ssl_train, refresh=False, step_seed=self._drop_step)
         M = B * st["T"]
         # the bf16 primary output of the GEMM is not needed here: it lands in dfe_bf, which the backward overwrites
         ops.gemm(Op(enc_out, E), Op(P.bf16, E, offset=P.off("LL.weight")), st["dfe_bf"], M, FEAT_DIM, E, bias=P.f32("LL.bias"),
@@ -199,10 +202,12 @@ class FrontHeadModel(nn.Module):
         pk = ("bwd", self.grad_sync is not None)
         plan = st["plans"].get(pk) if use_plan else None
         if plan is not None:
+            self.ssl.apply_seeds(plan["enc_slots"], sv["ectx"]["step_seed"])
             ops.replay(plan["calls"])
             return
         if use_plan:
             ops.start_recording()
+        enc_slots = []
         M = sv["B"] * st["T"]
         ops.cast_bf16(st["d_feats"], st["dfe_bf"], M * FEAT_DIM)
         ops.colsum_reduce(st["d_feats"], st["cs"], P.g("LL.bias"), M, FEAT_DIM)
@@ -211,9 +216,9 @@ class FrontHeadModel(nn.Module):
             ops.gemm(Op(st["dfe_bf"], FEAT_DIM), Op(P.bf16, E, offset=P.off("LL.weight")), st["denc"], M, E, FEAT_DIM, b_t=True)
             if self.grad_sync is not None:     # LL and the torch head's gradients (the END of the flat buffer) are final here
                 ops.host_callback(self.grad_sync.ready_above, P.off("LL.weight"))
-            self.ssl.backward(sv["ectx"], st["denc"])
+            enc_slots = self.ssl.backward(sv["ectx"], st["denc"])
         if use_plan:
-            st["plans"][pk] = dict(calls=ops.stop_recording())
+            st["plans"][pk] = dict(calls=ops.stop_recording(), enc_slots=enc_slots)
 
     # forward / loss --------------------------------------------------------------------------------
     def forward(self, x):

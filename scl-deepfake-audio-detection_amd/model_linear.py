@@ -211,8 +211,10 @@ class Model(nn.Module):
         if plan is not None:
             for dsc, sd in zip(plan["drop_descs"], seeds):
                 dsc.drop_seed = sd
+            ectx = plan["saved"]["ectx"]
+            self.encoder.apply_seeds(ectx["drop_slots"], self._step_seed)      # the encoder's element-dropout sites (none at p = 0)
             ops.replay(plan["calls"])
-            saved = dict(plan["saved"], seeds=seeds)
+            saved = dict(plan["saved"], seeds=seeds, ectx=dict(ectx, step_seed=self._step_seed))
             return st["logp"], st["feats"], st["emb"], saved
         if use_plan:
             ops.start_recording()
@@ -223,7 +225,7 @@ class Model(nn.Module):
 
     def _forward_kernels(self, st, B, L, ssl_train, drop, seeds):
         P, E = self.P, self.cfg.embed
-        enc_out, ectx = self.encoder.forward(st["x"], training=ssl_train, refresh=False)
+        enc_out, ectx = self.encoder.forward(st["x"], training=ssl_train, refresh=False, step_seed=self._step_seed)
         T = ectx["d"]["T"]
         M = B * T
         hb = self._head_bufs(B, T)
@@ -262,6 +264,7 @@ class Model(nn.Module):
             plan["drop_descs"][0].drop_seed = seeds[1]
             plan["drop_descs"][1].drop_seed = seeds[0]
             plan["meanpool_entry"][1][8] = seeds[2]
+            self.encoder.apply_seeds(plan["enc_slots"], sv["ectx"]["step_seed"])
             ops.replay(plan["calls"])
             return
         if use_plan:
@@ -278,7 +281,7 @@ class Model(nn.Module):
         ops.utt_head_bwd(st["d_logp"], sv["logp"], sv["emb"], P.f32("backend.m_utt_level.weight"), st["d_emb"], hb["demb"],
                          P.g("backend.m_utt_level.weight"), P.g("backend.m_utt_level.bias"), hb["ws"], B, HEAD_DIM, N_CLASS)
         mp_entry = ops.meanpool_bwd(hb["demb"], hb["pre"][2], hb["dpre"][2], B, T, HEAD_DIM, ACT_LEAKY, sv["drop"], seeds[2])
-        drop_descs = []
+        drop_descs, enc_slots = [], []
         for j, idx in reversed(list(enumerate((0, 3, 6)))):
             dpre = hb["dpre"][j]
             inp = hb["h"][j - 1] if j > 0 else hb["r0"]
@@ -300,8 +303,8 @@ class Model(nn.Module):
             ops.gemm(Op(hb["dfe_bf"], HEAD_DIM), W("LL.weight", E), hb["denc"], M, E, HEAD_DIM, b_t=True)
             if self.grad_sync is not None:      # head gradients (the END of the flat buffer) are final: start their all-reduce
                 ops.host_callback(self.grad_sync.ready_above, P.off("LL.weight"))
-            self.encoder.backward(sv["ectx"], hb["denc"])
-        return dict(drop_descs=drop_descs, meanpool_entry=mp_entry)
+            enc_slots = self.encoder.backward(sv["ectx"], hb["denc"])
+        return dict(drop_descs=drop_descs, meanpool_entry=mp_entry, enc_slots=enc_slots)
 
     def _score_fp32(self, x):
         """Scoring forward (no grad, eval mode): fp32 activations, fp32 master weights, exact-fp32 GEMMs end to end — the

@@ -254,12 +254,17 @@ def layernorm_bwd_nparts(M):
     return L.load().scl_layernorm_bwd_nparts(M)
 
 
+LN_BWD_DIN_SEED, LN_BWD_DOUT_SEED = 22, 24      # positions of the two mask seeds in a recorded scl_layernorm_bwd call
+ATTN_FWD_SEED, ATTN_BWD_SEED, DROPOUT_SEED = 9, 12, 4
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, beta, dres, dx_f32, dx_bf16, part, M, C, act=0, sum_dres=False, out_rpb=0,
-                  out_rbstride=0, out_off=0):
+                  out_rbstride=0, out_off=0, din=(0, 0.0), dout=(0, 0.0)):
     """part: f32 [nparts, 2*C] — per-slab (dgamma | dbeta) partial sums; [nparts, 3*C] with sum_dres (| colsum(dres)).
     out_rpb > 0: the bf16 output is written with per-utterance row padding (see include/scl_hip.h)."""
-    _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
-          _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, int(sum_dres), out_rpb, out_rbstride, out_off, _stream())
+    return _call("scl_layernorm_bwd", _p(dy), _isf32(dy), _p(x), _isf32(x), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                 _p(dres), _p(dx_f32), _p(dx_bf16), _p(part), M, C, C, C, C, act, int(sum_dres), out_rpb, out_rbstride, out_off,
+                 int(din[0]), float(din[1]), int(dout[0]), float(dout[1]), _stream())
 
 
 def colreduce(part, out, nparts, C, pstride=None, accumulate=False):
@@ -362,13 +367,18 @@ def softmax_bwd(P, dP, dS, R, T, lddP, Tp):
     _call("scl_softmax_bwd", _p(P), _p(dP), _p(dS), R, T, lddP, Tp, _stream())
 
 
-def attn_fwd(qkv, ctx, lse, B, T, H, D, scale):
-    _call("scl_attn_fwd", _p(qkv), _p(ctx), _p(lse), B, T, H, D, scale, _stream())
+def attn_fwd(qkv, ctx, lse, B, T, H, D, scale, drop_p=0.0, drop_seed=0):
+    return _call("scl_attn_fwd", _p(qkv), _p(ctx), _p(lse), B, T, H, D, scale, float(drop_p), int(drop_seed), _stream())
 
 
-def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale, bias_part=None):
+def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale, bias_part=None, drop_p=0.0, drop_seed=0):
     """bias_part: optional f32 [B, 3*H*D] — per-utterance column sums of dqkv (colreduce over B gives the q/k/v bias gradients)."""
-    _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(bias_part), B, T, H, D, scale, _stream())
+    return _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(bias_part), B, T, H, D, scale, float(drop_p), int(drop_seed), _stream())
+
+
+def dropout(x, y_f32, y_bf16, n, seed, p):
+    """y = x * keep-mask(seed, i) / (1 - p) to f32 and / or bf16 (in place allowed)."""
+    return _call("scl_dropout_f32", _p(x), _p(y_f32), _p(y_bf16), n, int(seed), float(p), _stream())
 
 
 def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5, stats=None):
