@@ -139,7 +139,8 @@ def main():
     model = Model(margs, dev, w2v_cfg=cfg, seed=0)          # same seed on every rank = replicated weights
     model.train()                                            # dropout on, as train_epoch does (main.py:48)
     g_lo, g_hi = model.trainable_range()
-    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, wire=os.environ.get("SCL_DP_WIRE", "fp32"), force=True) if dp else None
+    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, wire=os.environ.get("SCL_DP_WIRE", "fp32"), force=True,
+                    mode=os.environ.get("SCL_DP_MODE", "allreduce")) if dp else None
     model.grad_sync = sync
     opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4, grad_sync=sync)   # main.py:339 defaults (max_lr, weight_decay)
 

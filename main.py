@@ -251,7 +251,8 @@ def main(argv=None):
     from scl_amd.parallel import GradSync, shard_indices
     from scl_amd.prefetch import Prefetcher
     g_lo, g_hi = model.trainable_range()
-    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo) if world > 1 else None
+    # SCL_DP_MODE=shard: reduce-scatter + AdamW on the rank's shards + all-gather of the parameters instead of all-reduce + replicated AdamW
+    sync = GradSync(model.P.grad[g_lo:g_hi], base=g_lo, mode=os.environ.get("SCL_DP_MODE", "allreduce")) if world > 1 else None
     optimizer = FusedAdamW(model, lr=args.max_lr, weight_decay=args.weight_decay, grad_sync=sync)
     scheduler = torch.optim.lr_scheduler.CyclicLR(optimizer, base_lr=args.min_lr, max_lr=args.max_lr, step_size_up=3,
                                                   mode="exp_range", gamma=0.85, cycle_momentum=False)

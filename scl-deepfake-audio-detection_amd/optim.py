@@ -106,6 +106,18 @@ class FusedAdamW(torch.optim.Optimizer):
         # parameters that received no gradient (the whole encoder under flag_fix_ssl) are skipped, as torch.optim.AdamW skips
         # .grad is None: no weight decay on frozen weights
         lo, hi = self.model.trainable_range() if hasattr(self.model, "trainable_range") else (0, self.P.n_train)
+        gs = self.grad_sync
+        if gs is not None and getattr(gs, "mode", "allreduce") == "shard" and gs.active:
+            # sharded step (GradSync mode "shard"): this rank holds the summed gradient of its shards only; update those, then
+            # all-gather the parameters and refresh the bf16 working copy of the shards other ranks updated
+            for a, b in gs.owned():
+                a, b = lo + a, lo + b
+                ops.adamw_flat(self.P.flat[a:b], self.P.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.P.bf16[a:b], b - a,
+                               float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, scale)
+            gs.gather_params(self.P.flat[lo:hi])
+            ops.cast_bf16(self.P.flat[lo:hi], self.P.bf16[lo:hi], hi - lo)
+            self.model.optimizer_stepped(bf16_fresh=True)
+            return None
         ops.adamw_flat(self.P.flat[lo:hi], self.P.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.P.bf16[lo:hi], hi - lo,
                        float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, scale)
         self.model.optimizer_stepped(bf16_fresh=True)

@@ -40,7 +40,7 @@ class GradSync:
     fp32 wire stays the default).  Per-bucket timing (`report()`): when the bucket's all-reduce was issued and how long the
     optimizer had to wait for it at the end — the exposed part a scaling run needs to see."""
 
-    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0, wire="fp32", force=False):
+    def __init__(self, flat_grad, group=None, bucket_elems=16 * 1024 * 1024, base=0, wire="fp32", force=False, mode="allreduce"):
         """flat_grad: the slice of the flat gradient buffer that receives gradients (model.trainable_range()); `base` = its first
         element's offset in the whole buffer (ready_above() is called with whole-buffer offsets).  `force`: run the collectives
         even in a one-rank group (a single-GPU box can then rehearse the whole RCCL choreography: tests/test_dp_gpu.py)."""
@@ -51,6 +51,15 @@ class GradSync:
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.wire = wire
         assert wire in ("fp32", "bf16")
+        # mode "shard" (optional): every bucket is REDUCE-SCATTERED instead of all-reduced — rank r ends up with the
+        # summed gradient of the r-th 1/world of the bucket only, runs AdamW on that shard (optimizer HBM traffic and state / world)
+        # and the updated parameters are all-gathered afterwards (gather_params).  Same bytes on the links as the all-reduce
+        # (a ring all-reduce IS reduce-scatter + all-gather).  fp32 wire only.
+        assert mode in ("allreduce", "shard") and not (mode == "shard" and wire != "fp32")
+        self.mode = mode
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if mode == "shard":
+            bucket_elems = max(self.world, bucket_elems // self.world * self.world)
         n = flat_grad.numel()
         self.bounds = []
         hi = n
@@ -72,8 +81,39 @@ class GradSync:
         self.works = []
         self._t_issue, self._ev_done = [], []
 
+    def shard_of(self, lo, hi):
+        """The part of bucket [lo, hi) this rank owns in mode "shard" (the whole bucket when its size does not divide by the world
+        size — at most one, the lowest: it is all-reduced and updated on every rank)."""
+        if self.mode != "shard" or not self.active or (hi - lo) % self.world:
+            return lo, hi
+        sh = (hi - lo) // self.world
+        return lo + self.rank * sh, lo + (self.rank + 1) * sh
+
+    def owned(self):
+        """Slice-relative [lo, hi) ranges whose summed gradient this rank holds after finish() — what its optimizer updates."""
+        return [self.shard_of(lo, hi) for lo, hi in self.bounds]
+
+    def gather_params(self, flat_params):
+        """Mode "shard", after the optimizer step: all-gather every bucket of the parameter slice (same slicing as the gradient)
+        from the ranks that own its shards."""
+        if self.mode != "shard" or not self.active:
+            return
+        works = []
+        for lo, hi in self.bounds:
+            if (hi - lo) % self.world:
+                continue                                    # replicated bucket: every rank made the same update
+            a, b = self.shard_of(lo, hi)
+            works.append(dist.all_gather_into_tensor(flat_params[lo:hi], flat_params[a:b].clone(), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
     def _reduce(self, lo, hi):
         g = self.grad[lo:hi]
+        if self.mode == "shard" and (hi - lo) % self.world == 0:
+            a, b = self.shard_of(lo, hi)
+            out = torch.empty(b - a, dtype=g.dtype, device=g.device)      # not in place: only NCCL documents output == input chunk
+            w = dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return w, ("shard", out, a, b)
         if self.stage is None:
             return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None
         st = self.stage[: hi - lo]
@@ -97,7 +137,10 @@ class GradSync:
                     w, st = self._reduce(lo, hi)
                     if st is not None:
                         w.wait()                               # orders the copy-back behind the collective on the comm stream
-                        self.grad[lo:hi].copy_(st)
+                        if isinstance(st, tuple):
+                            self.grad[st[2]:st[3]].copy_(st[1])    # this rank's shard of the summed gradient
+                        else:
+                            self.grad[lo:hi].copy_(st)
                         w = None
                     done = torch.cuda.Event(enable_timing=False)
                     done.record(self.comm)
@@ -106,7 +149,10 @@ class GradSync:
                 w, st = self._reduce(lo, hi)
                 if st is not None:
                     w.wait()
-                    self.grad[lo:hi].copy_(st)
+                    if isinstance(st, tuple):
+                        self.grad[st[2]:st[3]].copy_(st[1])
+                    else:
+                        self.grad[lo:hi].copy_(st)
                     w = None
             self.works.append(w)
             self._t_issue.append(time.perf_counter())
@@ -126,7 +172,7 @@ class GradSync:
         self.last_report = {"buckets": len(self.bounds), "bucket_mib": [round((hi - lo) * (2 if self.stage is not None else 4) / 2 ** 20, 1)
                                                                          for lo, hi in self.bounds],
                             "issue_ms_before_finish": [round((t0 - t) * 1e3, 3) for t in self._t_issue],
-                            "host_wait_ms_at_finish": round((time.perf_counter() - t0) * 1e3, 3), "wire": self.wire}
+                            "host_wait_ms_at_finish": round((time.perf_counter() - t0) * 1e3, 3), "wire": self.wire, "mode": self.mode}
         self.works = []
         self.launched = 0
         return 1.0 / self.world

@@ -103,3 +103,56 @@ def test_bf16_wire_slice_base_and_bucket_order_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _worker_shard(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.parallel import GradSync
+    n = 1003                                     # the lowest bucket (3 elements at world 2 x bucket 250: 1003 = 4 * 250 + 3) does not divide
+    torch.manual_seed(11 + rank)
+    g = torch.randn(n)
+    gathered = [torch.empty(n) for _ in range(world)]
+    dist.all_gather(gathered, g.clone())
+    total = sum(gathered)
+    p = torch.arange(n, dtype=torch.float32)     # replicated "parameters"
+    sync = GradSync(g, bucket_elems=251, mode="shard")      # rounded down to a multiple of the world size
+    ok = all((hi - lo) % world == 0 for lo, hi in sync.bounds[:-1]) and sync.bounds[0][1] == n
+    sync.begin()
+    sync.ready_above(600)
+    launched_early = sync.launched
+    scale = sync.finish()
+    owned = sync.owned()
+    # the rank holds the SUM on the ranges it owns (whole lowest bucket: replicated) ...
+    for a, b in owned:
+        ok = ok and torch.allclose(g[a:b], total[a:b], atol=1e-5)
+    cover = torch.zeros(n)
+    for a, b in owned:
+        cover[a:b] += 1
+    allc = [torch.empty(n) for _ in range(world)]
+    dist.all_gather(allc, cover)
+    ok = ok and launched_early >= 1 and abs(scale - 1.0 / world) < 1e-12
+    lo_b, hi_b = sync.bounds[-1]
+    expect_cover = torch.ones(n); expect_cover[lo_b:hi_b] = world if (hi_b - lo_b) % world else 1
+    ok = ok and torch.equal(sum(allc), expect_cover)      # the shards tile the slice exactly once (the replicated remainder on every rank)
+    # ... updates them (a plain SGD step stands in for the HIP AdamW) and the all-gather restores replicated parameters
+    for a, b in owned:
+        p[a:b] -= 0.1 * scale * g[a:b]
+    sync.gather_params(p)
+    ok = ok and torch.allclose(p, torch.arange(n, dtype=torch.float32) - 0.1 * total / world, atol=1e-5)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_update_and_all_gather_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_shard, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

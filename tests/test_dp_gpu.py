@@ -31,7 +31,7 @@ def _step(model, opt, x, y, sync=None):
     opt.step()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from scl_amd.model_linear import Model
@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     dev = torch.device("cuda:0")
     m = Model(ARGS, dev, seed=0)
     m.eval()                                   # dropout off so the single-process reference below is comparable
-    sync = GradSync(m.P.grad, bucket_elems=40000)   # several buckets even for the tiny model
+    sync = GradSync(m.P.grad[: m.P.n_train], bucket_elems=40000, mode=mode)   # several buckets even for the tiny model
     opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-4, grad_sync=sync)
     x, y = _data(rank)
     for _ in range(3):                         # step 2 and 3 replay the recorded plan (with its bucket callbacks)
@@ -50,12 +50,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_mean_gradient_step(dev):
+@pytest.mark.parametrize("mode", ["allreduce", "shard"])
+def test_two_rank_step_equals_single_process_mean_gradient_step(dev, mode):
+    """mode "shard": reduce-scatter of every bucket, AdamW on the rank's own shards, all-gather of the parameters (SURVEY.md 8e's
+    optional ZeRO-1 form) — must land on the same weights as the all-reduce + replicated step and as the single-process reference."""
     world = 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict((r, (torch.from_numpy(w), nb)) for r, w, nb in (q.get(timeout=300) for _ in range(world)))
