@@ -13,16 +13,16 @@
 // Random draws (taps, positions, gains, noise) are sampled on the host with the reference's
 // distributions and passed in; the kernels are deterministic functions of their inputs.
 //
-// FIR kernel: direct form in fp32, 2048 outputs per workgroup (8 consecutive outputs per lane so one
-// LDS read feeds 8 FMAs), taps staged through LDS in chunks of 128, the x^p window of the chunk
-// staged in LDS with a +1-per-32 pad against bank conflicts; all N_f power branches are accumulated
-// in registers, so a clip is read once and written once (8 B/sample of HBM traffic).
+// FIR kernel: direct form in fp32 with a register sliding window, 4096 outputs per workgroup (16 consecutive outputs per lane: one
+// LDS read of the entering sample feeds 16 FMAs), taps staged through LDS in chunks of 256 and read four at a time, the x^p window of
+// the chunk staged in LDS with a +1-per-16 pad against bank conflicts; all N_f power branches are accumulated in registers, so a clip
+// is read once and written once (8 B/sample of HBM traffic).  The same kernel is the RIR convolution (one branch, 8000-16000 taps).
 #include "common.h"
 
 namespace {
 
-constexpr int FIR_TILE = 2048, FIR_TC = 128;
-__device__ __forceinline__ int padi(int i) { return i + (i >> 5); }
+constexpr int FIR_TILE = 4096, FIR_TC = 256;
+__device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
 
 __device__ __forceinline__ float ipow(float x, int p) {
     float r = x;
@@ -45,51 +45,76 @@ __device__ __forceinline__ void block_stats_store(float s, float mn, float mx, f
     }
 }
 
+// Register sliding window, 16 consecutive outputs per lane: for tap k the lane's 16 outputs read x[n .. n + 15 + h - k], so moving to
+// the next tap shifts the window by ONE sample — one LDS read (the entering sample) feeds 16 FMAs, the taps come four at a time by a
+// broadcast ds_read_b128.  The round-2 form (8 outputs per lane, one tap read per tap) issued 2 LDS reads per 8 FMAs and ran at the
+// LDS rate (0.18 of the fp32 vector peak).  4096 outputs per workgroup, taps in chunks of 256 (the x^p window of a chunk is staged
+// once: 4352 samples per 1 Mi FMAs); a partial last chunk runs only its own 16-tap groups.  The window index is padded by one word
+// per 16 (lane stride 17 words: the 32 lanes of a ds_read_b32 group hit 32 different banks).
+// MODE 0: scalar source, the compiler packs pairs of outputs into v_pk_fma_f32 (128 per 16 taps + ~40 v_mov for pairs that start at an
+// odd window offset); MODE 2 (SCL_FIR_MODE=2, A/B only): one v_fma_f32 per output and tap through inline asm.  Measured on MI355X
+// (tools/fir_probe.py, 64 clips x 64000 x 5 branches): 55 TFLOP/s either way, and an explicit aligned-pair form (two window copies, one
+// shifted by a sample) the same — the inner loop costs ~8 cycles per v_pk_fma_f32 and ~4 per other vector instruction per SIMD
+// whatever the packing, i.e. ~79 TFLOP/s is the fp32 FMA rate of the vector pipe; beyond that only the f32 matrix cores go.
+template <int MODE>
 __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, int64_t ldx, int Lin, const float* __restrict__ taps,
                                                   const int* __restrict__ tap_off, const int* __restrict__ tap_len,
                                                   const int* __restrict__ tap_h, int nf, int use_pow, float* __restrict__ y,
                                                   int64_t ldy, int Lout, float* __restrict__ part) {
-    __shared__ float win[FIR_TILE + FIR_TC + (FIR_TILE + FIR_TC) / 32 + 8];
-    __shared__ float bt[FIR_TC];
+    __shared__ float win[FIR_TILE + FIR_TC + (FIR_TILE + FIR_TC) / 16 + 24];
+    __shared__ __attribute__((aligned(16))) float bt[FIR_TC];
     const int clip = blockIdx.y;
     const int n0 = blockIdx.x * FIR_TILE;
     const int t = threadIdx.x;
     const float* xc = x + (int64_t)clip * ldx;
-    float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float out[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = 0.f;
     for (int f = 0; f < nf; ++f) {
         const int len = tap_len[clip * nf + f], off = tap_off[clip * nf + f], h = tap_h[clip * nf + f];
         const int p = use_pow ? f + 1 : 1;
         for (int k0 = 0; k0 < len; k0 += FIR_TC) {
+            // window sample idx holds x^p[ws + idx]; output i of lane t, chunk tap j = k0 + FIR_TC - 1 - jj reads window 16 t + i + jj
             const int ws = n0 + h - (k0 + FIR_TC - 1);
+            const int nvalid = min(FIR_TC, len - k0);
+            const int jstart = (FIR_TC - nvalid) & ~15;              // taps of a partial chunk sit at the END of the reversed order
             __syncthreads();
-            for (int idx = t; idx < FIR_TILE + FIR_TC; idx += 256) {
+            for (int idx = t + jstart; idx < FIR_TILE + FIR_TC + 1; idx += 256) {
                 const int xi = ws + idx;
                 win[padi(idx)] = (xi >= 0 && xi < Lin) ? ipow(xc[xi], p) : 0.f;
             }
-            if (t < FIR_TC) bt[t] = (k0 + t) < len ? taps[off + k0 + t] : 0.f;
+            bt[t] = (k0 + FIR_TC - 1 - t) < len ? taps[off + k0 + FIR_TC - 1 - t] : 0.f;      // reversed: bt[jj] multiplies window offset jj
             __syncthreads();
-            float r[8], nx[8];
+            {
+                float r[32];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = win[padi(8 * t + i)];
-            for (int j0 = 0; j0 < FIR_TC; j0 += 8) {
+                for (int i = 0; i < 16; ++i) r[i] = win[padi(16 * t + jstart + i)];
+                for (int j0 = jstart; j0 < FIR_TC; j0 += 16) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) nx[i] = win[padi(8 * t + j0 + 8 + i)];
+                    for (int i = 0; i < 16; ++i) r[16 + i] = win[padi(16 * t + j0 + 16 + i)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float c = bt[FIR_TC - 1 - (j0 + u)];
+                    for (int u4 = 0; u4 < 16; u4 += 4) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(bt + j0 + u4);
+                        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) out[i] += c * ((i + u) < 8 ? r[i + u] : nx[i + u - 8]);
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                if (MODE == 2) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(out[i]) : "v"(c[v]), "v"(r[i + u4 + v]));
+                                else out[i] = __builtin_fmaf(c[v], r[i + u4 + v], out[i]);
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) r[i] = r[16 + i];
                 }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) r[i] = nx[i];
             }
         }
     }
     float s = 0.f, sq = 0.f, mn = INFINITY, mx = -INFINITY;
     float* yc = y + (int64_t)clip * ldy;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int n = n0 + 8 * t + i;
+    for (int i = 0; i < 16; ++i) {
+        const int n = n0 + 16 * t + i;
         if (n < Lout) {
             yc[n] = out[i];
             s += out[i]; sq += out[i] * out[i]; mn = fminf(mn, out[i]); mx = fmaxf(mx, out[i]);
@@ -251,7 +276,9 @@ extern "C" int scl_fir_multi_f32(const float* x, int64_t ldx, int Lin, const flo
     SCL_REQUIRE(nclip >= 1 && nclip <= 65535 && nf >= 1 && Lin >= 1 && Lout >= 1, "fir: bad dims");
     dim3 grid(scl_fir_nblocks(Lout), nclip), block(256);
     SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
-    hipLaunchKernelGGL(fir_kernel, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
+    static const int mode = [] { const char* e = getenv("SCL_FIR_MODE"); return e ? atoi(e) : 0; }();
+    if (mode == 2) hipLaunchKernelGGL(fir_kernel<2>, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
+    else hipLaunchKernelGGL(fir_kernel<0>, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
     return scl_check_launch("scl_fir_multi_f32");
 }
 
