@@ -211,6 +211,17 @@ int scl_colreduce_f32(const float* part, float* out, int nparts, int C, int64_t 
  * scratch: f32 [SCL_COLREDUCE_SEGMENTS][C]; counters: as for scl_colsum_reduce (C <= 32 * SCL_COLSUM_MAX_GROUPS) */
 #define SCL_COLREDUCE_SEGMENTS 8
 #define SCL_COLSUM_MAX_GROUPS 128
+/* Up to SCL_REDUCE_MAX_JOBS column reductions in one launch (out[c] = sum_p part[p * pstride + c]; columns >= split go to out2 when
+ * it is given): the bias / LayerNorm-parameter gradient sums that close an encoder layer's backward (main.py:79). */
+#define SCL_REDUCE_MAX_JOBS 8
+typedef struct SclReduceJob {
+    const float* part;
+    float*       out;
+    float*       out2;
+    int64_t      pstride;
+    int32_t      nparts, C, split, _pad;
+} SclReduceJob;
+int scl_colreduce_multi(const SclReduceJob* jobs, int njobs, void* stream);
 /* out2 (optional): columns [split, C) are written to out2[0 .. C-split) instead of out[split ..) */
 int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int64_t pstride, int accumulate, float* scratch, int* counters,
                           float* out2, int split, void* stream);

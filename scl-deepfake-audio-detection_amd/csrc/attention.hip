@@ -265,6 +265,7 @@ __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [
     return q * 64 + ((((key32 >> 3) ^ (q >> 2)) & 3) << 4) + ((key32 & 7) << 1);
 }
 
+template <bool DROP>      // attention dropout compiled in only where asked for
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, float* __restrict__ bias_part, int T, int H, float scale,
@@ -311,10 +312,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     // staging roles: threads 0..255 carry Q, threads 256..511 carry dO + O (for delta) + LSE; one step ahead in registers
     const int half = threadIdx.x >> 8, st = threadIdx.x & 255;
     const int sr = st >> 3, sc = st & 7;
-    // two query tiles ahead in registers (sets A / B alternate): one step (~1 us) did not cover a cold HBM round trip under load
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0), w0 = make_uint4(0, 0, 0, 0), w1 = make_uint4(0, 0, 0, 0);
-    float lq_next = 0.f, lq_next2 = 0.f;
-    auto fetch_tile = [&](int u, uint4& v0, uint4& v1, float& lq_next) {
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+    float lq_next = 0.f;
+    auto fetch_tile = [&](int u) {
         const int q = 32 * u + sr;
         v0 = make_uint4(0, 0, 0, 0); v1 = make_uint4(0, 0, 0, 0); lq_next = 0.f;
         if (q < T) {
@@ -327,17 +327,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             }
         }
     };
-    fetch_tile(0, v0, v1, lq_next);
-    if (NT2 > 1) fetch_tile(1, w0, w1, lq_next2);
-    auto step = [&](int u, uint4& a0, uint4& a1, float& alq) {
+    fetch_tile(0);
+    for (int u = 0; u < NT2; ++u) {
         __syncthreads();   // A: previous step's readers are done with the query tiles and the dS image (and K/V staging on u == 0)
         if (half == 0) {
-            *reinterpret_cast<uint4*>(Qk + att_k_off(sr, sc)) = a0;
-            *reinterpret_cast<uint4*>(Qt + att_t_off(sr, 8 * sc)) = a0;
+            *reinterpret_cast<uint4*>(Qk + att_k_off(sr, sc)) = v0;
+            *reinterpret_cast<uint4*>(Qt + att_t_off(sr, 8 * sc)) = v0;
         } else {
-            *reinterpret_cast<uint4*>(Ok + att_k_off(sr, sc)) = a0;
-            *reinterpret_cast<uint4*>(Ot + att_t_off(sr, 8 * sc)) = a0;
-            const unsigned ow[4] = {a0.x, a0.y, a0.z, a0.w}, cw[4] = {a1.x, a1.y, a1.z, a1.w};
+            *reinterpret_cast<uint4*>(Ok + att_k_off(sr, sc)) = v0;
+            *reinterpret_cast<uint4*>(Ot + att_t_off(sr, 8 * sc)) = v0;
+            const unsigned ow[4] = {v0.x, v0.y, v0.z, v0.w}, cw[4] = {v1.x, v1.y, v1.z, v1.w};
             float dot = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -345,10 +344,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                 dot += __uint_as_float(ow[k] & 0xFFFF0000u) * __uint_as_float(cw[k] & 0xFFFF0000u);
             }
             dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-            if (sc == 0) { delS[sr] = dot; lseS[sr] = alq; }
+            if (sc == 0) { delS[sr] = dot; lseS[sr] = lq_next; }
         }
-        // this register set held tile u (now in LDS): refill it with tile u + 2; tile u + 1 is in flight in the other set
-        if (u + 2 < NT2) fetch_tile(u + 2, a0, a1, alq);
+        if (u + 1 < NT2) fetch_tile(u + 1);      // in flight during this step's MFMAs
         __syncthreads();   // B
         {
             f32x4 P[2][2], dS[2][2];
@@ -386,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                                 const int qq = 32 * u + 16 * a + 4 * g + r;
                                 const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
                                 // attention dropout: O = (P x mask) V, so dV takes P x mask and dP = (dO V^T) x mask; delta = <dO, O> is unchanged
-                                const float mk = drop_p > 0.f ? dropout_scale(drop_seed, (((uint64_t)b * H + h) * T + (uint64_t)(qq < T ? qq : 0)) * T + (uint64_t)key, drop_p) : 1.f;
+                                const float mk = DROP ? dropout_scale(drop_seed, (((uint64_t)b * H + h) * T + (uint64_t)(qq < T ? qq : 0)) * T + (uint64_t)key, drop_p) : 1.f;
                                 P[a][j][r] = p * mk;
                                 dS[a][j][r] = p * (dp[r] * mk - dq_[a][r]);
                             }
@@ -437,10 +435,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                     make_uint2(pack_bf2(dq[0] * scale, dq[1] * scale), pack_bf2(dq[2] * scale, dq[3] * scale));
             dqsum += dq;      // rows q >= T hold zeros (their P is masked to 0)
         }
-        };
-    for (int u = 0; u < NT2; u += 2) {      // the two register sets alternate by NAME (a swap would wait for the loads in flight)
-        step(u, v0, v1, lq_next);
-        if (u + 1 < NT2) step(u + 1, w0, w1, lq_next2);
     }
     // ---- dK, dV of this wave's keys: lane owns key 16(2w+j)+lc, d = 16dt + 4g + 0..3
 #pragma unroll
@@ -523,10 +517,13 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 8 * 2048 + 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd8_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd8_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
+    else hipLaunchKernelGGL(attn_bwd8_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                            (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
     return scl_check_launch("scl_attn_bwd");
 }

@@ -288,6 +288,39 @@ __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restr
     }
 }
 
+// Several column reductions in ONE launch: the four small reductions that close an encoder layer's backward (LayerNorm parameter
+// gradients + the residual linear's bias, twice; fc1 bias; q/k/v bias) were four ~10 us launches of 64-800 blocks each, latency-bound.
+// Block = 32 columns x 32 row lanes of one job; fixed summation order (row lane r adds rows r, r + 32, ...; the lanes are combined
+// 0..31) => deterministic.
+struct ReduceJobs { SclReduceJob job[SCL_REDUCE_MAX_JOBS]; int first_block[SCL_REDUCE_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(1024) void colreduce_multi_kernel(const ReduceJobs J) {
+    __shared__ float red[32][33];
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const SclReduceJob jb = J.job[j];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - J.first_block[j]) * 32 + tx;
+    float s = 0.f;
+    if (c < jb.C) {
+        int p = ty;
+        for (; p + 96 < jb.nparts; p += 128) {      // four independent loads in flight
+            const float a0 = jb.part[(int64_t)p * jb.pstride + c], a1 = jb.part[(int64_t)(p + 32) * jb.pstride + c];
+            const float a2 = jb.part[(int64_t)(p + 64) * jb.pstride + c], a3 = jb.part[(int64_t)(p + 96) * jb.pstride + c];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; p < jb.nparts; p += 32) s += jb.part[(int64_t)p * jb.pstride + c];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < jb.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][tx];
+        float* o = (jb.out2 && c >= jb.split) ? jb.out2 + (c - jb.split) : jb.out + c;
+        *o = t;
+    }
+}
+
 // column sums of a [M, N] matrix (bias gradients): part[rowchunk][n].  With `out` != null the launch also finishes the sum:
 // every block stores its partial row write-through (sc1), drains, and draws a ticket of its column group; the block that
 // draws the last one adds the group's partials (sc1 loads) in row-chunk order (fixed order => deterministic) and re-arms the
@@ -432,6 +465,24 @@ extern "C" int scl_colreduce_seg_f32(const float* part, float* out, int nparts, 
     hipLaunchKernelGGL(colreduce_seg_kernel, dim3((C + 31) / 32, nseg), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride,
                        accumulate, scratch, counters, out2, split);
     return scl_check_launch("scl_colreduce_seg_f32");
+}
+
+extern "C" int scl_colreduce_multi(const SclReduceJob* jobs, int njobs, void* stream) {
+    SCL_REQUIRE(jobs && njobs >= 1 && njobs <= SCL_REDUCE_MAX_JOBS, "colreduce_multi: 1 .. %d jobs", SCL_REDUCE_MAX_JOBS);
+    ReduceJobs J;
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SclReduceJob& b = jobs[i];
+        SCL_REQUIRE(b.part && b.out && b.nparts >= 1 && b.C >= 1 && b.pstride >= b.C, "colreduce_multi: job %d: bad arguments", i);
+        SCL_REQUIRE(!b.out2 || (b.split > 0 && b.split < b.C), "colreduce_multi: job %d: split must lie inside (0, C) when out2 is given", i);
+        J.job[i] = b;
+        J.first_block[i] = blocks;
+        blocks += (b.C + 31) / 32;
+    }
+    J.first_block[njobs] = blocks;
+    J.njobs = njobs;
+    hipLaunchKernelGGL(colreduce_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, J);
+    return scl_check_launch("scl_colreduce_multi");
 }
 
 // row slab per block: 256 rows, doubled until at most 64 slabs remain (finer slabs were measured slower: the finishing block

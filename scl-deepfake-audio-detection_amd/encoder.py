@@ -23,6 +23,8 @@ from .ops import Op
 # fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
 FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
 WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "0") != "0"
+# the (up to) four small column reductions that close a layer's backward in ONE launch (SCL_BATCH_REDUCE=0: one launch each)
+BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
 
 
 class W2VConfig:
@@ -212,6 +214,7 @@ class Encoder:
             d["dyp_geom"].append((Q, Rp))
         nln = max(ops.layernorm_bwd_nparts(B * t) for t in Ts)
         d["ln_part"] = f32(nln * 3 * max(C, E))
+        d["ln_part2"] = f32(nln * 3 * E)      # the layer's second LayerNorm backward when the layer's reductions are batched into one launch
         ncs = max(ops.colsum_nparts(B * (max(Ts[1:] + [T + K]) + 4)), 1) + 1      # conv bias sums run over the zero-padded dyp rows
         d["cs_part"] = f32(ncs * max(3 * E, Fd, C))
         d["qkv_bias_part"] = f32(B * 3 * E)
@@ -301,6 +304,14 @@ class Encoder:
 
     def _bias_grad(self, d, dy, Mrows, N, gname):
         ops.colsum_reduce(dy, d["cs_part"], self.P.g(self.n(gname)), Mrows, N)
+
+    def _ln_job(self, part, nparts, C, wname, bname, resid_bias=None):
+        """The reduction of _ln_grads as a job tuple for ops.colreduce_multi."""
+        ow, ob = self.P.off(self.n(wname)), self.P.off(self.n(bname))
+        assert ob == ow + C
+        if resid_bias is None:
+            return (part, self.P.grad[ow:ow + 2 * C], nparts, 2 * C)
+        return (part, self.P.grad[ow:ow + 2 * C], nparts, 3 * C, self.P.g(self.n(resid_bias)), 2 * C)
 
     def _ln_grads(self, d, nparts, C, wname, bname, resid_bias=None):
         """weight and bias of a LayerNorm are adjacent in the flat buffer: one reduction over the (dgamma | dbeta) partials;
@@ -520,8 +531,12 @@ class Encoder:
             dsc = ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
             if p_act > 0 and recording:
                 self._slot(slots, dsc, None, n, self.SITE_2)
+            jobs = []      # this layer's closing reductions (BATCH_REDUCE: one launch at the end of the layer)
             if nrows:
-                ops.colreduce(d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd)
+                if BATCH_REDUCE:
+                    jobs.append((d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd))
+                else:
+                    ops.colreduce(d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd)
             with self._side():
                 if not nrows:
                     self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
@@ -535,7 +550,10 @@ class Encoder:
             if p_res > 0:
                 self._slot(slots, e, ops.LN_BWD_DIN_SEED, n, self.SITE_3)
                 self._slot(slots, e, ops.LN_BWD_DOUT_SEED, n, self.SITE_1)
-            self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias")
+            if BATCH_REDUCE:
+                jobs.append(self._ln_job(d["ln_part"], nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias"))
+            else:
+                self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias")
             cur = (cur + 1) % 3
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
@@ -549,7 +567,10 @@ class Encoder:
                 if p_attn > 0:
                     self._slot(slots, e, ops.ATTN_BWD_SEED, n, self.SITE_ATTN)
                 if FUSED_BIAS_GRAD:       # q/k/v bias gradients: per-utterance column sums out of attn_bwd's accumulators, summed over B
-                    ops.colreduce(d["qkv_bias_part"], self._qkv_view(pn, "bias"), B, 3 * E)
+                    if BATCH_REDUCE:
+                        jobs.append((d["qkv_bias_part"], self._qkv_view(pn, "bias"), B, 3 * E))
+                    else:
+                        ops.colreduce(d["qkv_bias_part"], self._qkv_view(pn, "bias"), B, 3 * E)
             else:
                 Pn = d["P"][n]
                 bq = dict(nb1=B, nb2=H)
@@ -576,13 +597,19 @@ class Encoder:
             # active layer below: its dropout3 mask
             dout, lyr = mask3_of([m_ for m_ in active if m_ < n])
             e = ops.layernorm_bwd(d["d_h"], xin, d["m1"][n], d["r1"][n], self.b(pn + "self_attn_layer_norm.weight"), None, dx,
-                                  other, otherb, d["ln_part"], M, E, sum_dres=True, din=(sseed(n, self.SITE_1), p_res), dout=dout)
+                                  other, otherb, d["ln_part2"] if BATCH_REDUCE else d["ln_part"], M, E, sum_dres=True,
+                                  din=(sseed(n, self.SITE_1), p_res), dout=dout)
             if p_res > 0:
                 self._slot(slots, e, ops.LN_BWD_DIN_SEED, n, self.SITE_1)
                 if lyr is not None:
                     self._slot(slots, e, ops.LN_BWD_DOUT_SEED, lyr, self.SITE_3)
-            self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
-                           resid_bias=pn + "self_attn.out_proj.bias")
+            if BATCH_REDUCE:
+                jobs.append(self._ln_job(d["ln_part2"], nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
+                                         resid_bias=pn + "self_attn.out_proj.bias"))
+                ops.colreduce_multi(jobs)
+            else:
+                self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
+                               resid_bias=pn + "self_attn.out_proj.bias")
             cur = (cur + 1) % 3
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d xin
             self._join_side()          # d_f / dqkv / the bf16 residual gradients of this layer are free again; its gradients are final

@@ -26,6 +26,11 @@ class SclOperand(ctypes.Structure):
                 ("ld", ctypes.c_int32), ("cin", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
+class SclReduceJob(ctypes.Structure):
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("pstride", ctypes.c_int64),
+                ("nparts", ctypes.c_int32), ("C", ctypes.c_int32), ("split", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
 class SclGemmDesc(ctypes.Structure):
     _fields_ = [("A", SclOperand), ("B", SclOperand), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
                 ("R", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -94,6 +99,7 @@ def _protos():
         "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
         "scl_colsum_nparts": ([_i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
+        "scl_colreduce_multi": ([P(SclReduceJob), _i32, _vp], _i32),
         "scl_colreduce_seg_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp], _i32),
         "scl_colsum_reduce": ([_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp], _i32),
         # elementwise.hip

@@ -271,6 +271,17 @@ def colreduce(part, out, nparts, C, pstride=None, accumulate=False):
     _call("scl_colreduce_f32", _p(part), _p(out), nparts, C, pstride or C, 1 if accumulate else 0, _stream())
 
 
+def colreduce_multi(jobs):
+    """jobs: list of (part, out, nparts, C[, out2, split]) — up to 8 column reductions in one launch."""
+    arr = (L.SclReduceJob * len(jobs))()
+    for i, jb in enumerate(jobs):
+        part, out, nparts, C = jb[:4]
+        out2, split = (jb[4], jb[5]) if len(jb) > 4 and jb[4] is not None else (None, 0)
+        arr[i].part, arr[i].out, arr[i].out2 = _p(part), _p(out), _p(out2)
+        arr[i].pstride, arr[i].nparts, arr[i].C, arr[i].split = C, nparts, C, split
+    _call("scl_colreduce_multi", arr, len(jobs), _stream(), keep=arr)
+
+
 def colsum_nparts(M):
     return L.load().scl_colsum_nparts(M)
 

@@ -44,7 +44,7 @@ def test_argument_validation_returns_error_codes_without_touching_the_gpu():
     assert b"M,N,K" in L.scl_last_error()
     assert L.scl_layernorm_fwd(None, 1, None, None, None, None, None, None, 4, 8, 8, 8, 1e-5, 0, None) == -1
     assert L.scl_prof_enable(99, 1) == -1
-    assert L.scl_fir_nblocks(64000) == 32 and L.scl_supcon_nchunks(25472) == 32 and L.scl_supcon_nchunks(1 << 20) == 512
+    assert L.scl_fir_nblocks(64000) == 16 and L.scl_supcon_nchunks(25472) == 32 and L.scl_supcon_nchunks(1 << 20) == 512
 
 
 def test_product_path_refuses_cpu():
