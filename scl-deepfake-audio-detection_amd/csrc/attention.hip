@@ -123,13 +123,18 @@ __device__ __forceinline__ bf16x8 att_frag_tr(const char* tile, int rowa, int ro
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool DROP>      // attention dropout compiled in only where asked for: its index arithmetic pushes the plain kernel over its 128 registers
+// NTC: number of 16-key tiles as a compile-time constant (0 = run time).  With a run-time tile count every step of the unrolled tile
+// loops is predicated (v_cndmask on 4 x 16 score registers, the tile counter and masks in SGPRs that spill to lanes: 150 cndmask +
+// 300 readlane / writelane in a 1300-instruction kernel that is VALU-bound); the encoder's lengths give 13 tiles (T = 193 .. 208: 64000- and
+// 64600-sample clips) or 4 (16000-sample clips), everything else takes the generic form.
+template <bool DROP, int NTC>      // attention dropout compiled in only where asked for: its index arithmetic pushes the plain kernel over its 128 registers
 __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
                                                        int T, int H, float scale, float drop_p, uint32_t drop_seed) {
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int NT = (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
+    const int NT = NTC ? NTC : (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
+    constexpr int NTB = NTC ? NTC : ATT_NTMAX, NT2B = (NTB + 1) / 2;      // unroll bounds
     char* Kt = asmem;                 // [rows][128 B] row-read image
     char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
@@ -156,10 +161,10 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
             if (q < T) u = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 32 * ks + 8 * g);
             qf[ks] = __builtin_bit_cast(bf16x8, u);
         }
-        f32x4 s[ATT_NTMAX];
+        f32x4 s[NTB + 1];
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < ATT_NTMAX; ++t) {
+        for (int t = 0; t < NTB; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < NT) {
 #pragma unroll
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
                         if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
                 }
                 m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                if (NTC && (t & 1)) __builtin_amdgcn_sched_barrier(0);      // keeps the K-fragment reads of later tiles from being hoisted (128-register budget)
             }
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
         float l = 0.f;
         const float msl = -m * sl2;
 #pragma unroll
-        for (int t = 0; t < ATT_NTMAX; ++t) {
+        for (int t = 0; t < NTB; ++t) {
             if (t < NT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, msl)); l += s[t][r]; }      // = exp(scale * (s - m))
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
         if (DROP) {      // attention dropout (fairseq MultiheadAttention dropout_module on the probabilities): keep-mask by (row, key)
             const uint64_t rowbase = (((uint64_t)b * H + h) * T + (uint64_t)(q < T ? q : 0)) * T;
 #pragma unroll
-            for (int t = 0; t < ATT_NTMAX; ++t) {
+            for (int t = 0; t < NTB; ++t) {
                 if (t < NT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[t][r] *= dropout_scale(drop_seed, rowbase + (uint64_t)(16 * t + 4 * g + r), drop_p);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < ATT_NTMAX / 2; ++u) {
+        for (int u = 0; u < NT2B; ++u) {
             if (u < NT2) {
                 const int ta = 2 * u, tb = 2 * u + 1;
                 // the un-normalised exponentials (<= 1) are the B operand; 1 / l multiplies the 16 outputs instead of the 4 NT probabilities
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_tr(Vt, 16 * ta, 16 * tb, dt, lane), pf, o[dt], 0, 0, 0);
+                if (NTC) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (q < T) {
@@ -265,7 +272,7 @@ __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [
     return q * 64 + ((((key32 >> 3) ^ (q >> 2)) & 3) << 4) + ((key32 & 7) << 1);
 }
 
-template <bool DROP>      // attention dropout compiled in only where asked for
+template <bool DROP, int NTC>      // attention dropout compiled in only where asked for; NTC: compile-time key-tile count (0 = run time), as in attn_fwd_kernel
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, float* __restrict__ bias_part, int T, int H, float scale,
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int NT = (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
+    const int NT = NTC ? NTC : (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
     char* Kk = asmem;
     char* Kt = Kk + rows * 128;
     char* Vk = Kt + rows * 128;
@@ -423,7 +430,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
         {   // ---- dQ tile [16 q (tile qa_) x 16 d (tile dt)] over all keys; lane ends up with 4 consecutive d of one query
             const int qa_ = wave & 1, dt = wave >> 1;
             f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < NT2; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < (NTC ? (NTC + 1) / 2 : ATT_NTMAX / 2); ++ks) {
+                if (!NTC && ks >= NT2) break;
                 const int row = 16 * qa_ + lc;
                 const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(dSs + ks * 2048 + row * 64 + (((g ^ (row >> 2)) & 3) << 4));
                 const bf16x8 kf = att_frag_tr_nat(Kt, 32 * ks, dt, lane);
@@ -504,8 +513,12 @@ extern "C" int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 256, "attn_fwd: fused path needs head dim 64 and T <= 256 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
     const size_t lds = (size_t)2 * rows * 128;
-    if (drop_p > 0.f) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale, drop_p, drop_seed);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale, drop_p, drop_seed);
+#define ATT_FWD(DR, N) hipLaunchKernelGGL((attn_fwd_kernel<DR, N>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T, H, scale, drop_p, drop_seed)
+    if (drop_p > 0.f) ATT_FWD(true, 0);
+    else if (NT == 13) ATT_FWD(false, 13);
+    else if (NT == 4) ATT_FWD(false, 4);
+    else ATT_FWD(false, 0);
+#undef ATT_FWD
     return scl_check_launch("scl_attn_fwd");
 }
 
@@ -517,13 +530,16 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 8 * 2048 + 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_bwd8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)attn_bwd8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel<false, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_bwd8_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (drop_p > 0.f) hipLaunchKernelGGL(attn_bwd8_kernel<true>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
-    else hipLaunchKernelGGL(attn_bwd8_kernel<false>, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                            (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed);
+#define ATT_BWD(DR, N) hipLaunchKernelGGL((attn_bwd8_kernel<DR, N>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)ctx, \
+                                          (const bf16_t*)dctx, lse, (bf16_t*)dqkv, bias_part, T, H, scale, drop_p, drop_seed)
+    if (drop_p > 0.f) ATT_BWD(true, 0);
+    else if (NT == 13) ATT_BWD(false, 13);
+    else ATT_BWD(false, 0);
+#undef ATT_BWD
     return scl_check_launch("scl_attn_bwd");
 }
