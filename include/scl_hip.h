@@ -277,6 +277,8 @@ int scl_utt_head_bwd(const float* dlogp, const float* logp, const float* emb, co
 /* ------------------------------------------------------------------------------------------ */
 int scl_softmax_fwd(const float* S, void* P, int64_t R, int T, int ldS, int Tp, void* stream);
 int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, int lddP, int Tp, void* stream);
+/* the forward with f32 probabilities (columns T..Tp-1 zero): the fp32 scoring path (main.py:161-214 runs fp32 end to end) */
+int scl_softmax_fwd_f32(const float* S, float* P, int64_t R, int T, int ldS, int Tp, void* stream);
 /* Fused attention for head dim 64 (scores stay on chip).  qkv / dqkv: bf16 [B, T, 3, H, 64]; ctx / dctx: bf16 [B, T, H*64];
  * lse: f32 [B, H, T] row log-sum-exp of the scaled scores.  fwd: T <= 256; bwd: T <= 224 (LDS budget).
  * Replaces F.multi_head_attention_forward inside fairseq's TransformerSentenceEncoderLayer (model/xlsr.py:41) and its backward.

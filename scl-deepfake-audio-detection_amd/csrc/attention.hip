@@ -12,7 +12,8 @@ namespace {
 
 constexpr int MAXV = 8;  // up to 512 columns kept in registers
 
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, bf16_t* __restrict__ P, int64_t R,
+template <typename TP>      // TP: bf16_t (training path: P is a GEMM operand) or float (fp32 scoring path)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, TP* __restrict__ P, int64_t R,
                                                           int T, int ldS, int Tp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -35,11 +36,14 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
         sum += v[i];
     }
     const float inv = 1.0f / wave_sum(sum);
-    bf16_t* p = P + row * Tp;
+    TP* p = P + row * Tp;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = i * 64 + lane;
-        if (c < Tp) p[c] = f2bf(v[i] * inv);
+        if (c < Tp) {
+            if constexpr (sizeof(TP) == 4) p[c] = v[i] * inv;
+            else p[c] = f2bf(v[i] * inv);
+        }
     }
 }
 
@@ -72,8 +76,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 
 extern "C" int scl_softmax_fwd(const float* S, void* P, int64_t R, int T, int ldS, int Tp, void* stream) {
     SCL_REQUIRE(S && P && R > 0 && T > 0 && T <= 512 && Tp >= T && Tp <= 512 && (Tp & 7) == 0, "softmax_fwd: need T <= Tp <= 512, Tp %% 8 == 0");
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, R, T, ldS, Tp);
+    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, R, T, ldS, Tp);
     return scl_check_launch("scl_softmax_fwd");
+}
+
+extern "C" int scl_softmax_fwd_f32(const float* S, float* P, int64_t R, int T, int ldS, int Tp, void* stream) {
+    SCL_REQUIRE(S && P && R > 0 && T > 0 && T <= 512 && Tp >= T && Tp <= 512 && (Tp & 3) == 0, "softmax_fwd_f32: need T <= Tp <= 512, Tp %% 4 == 0");
+    hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, R, T, ldS, Tp);
+    return scl_check_launch("scl_softmax_fwd_f32");
 }
 
 extern "C" int scl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t R, int T, int lddP, int Tp, void* stream) {

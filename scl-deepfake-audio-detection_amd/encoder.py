@@ -468,7 +468,7 @@ class Encoder:
             ops.gemm(Op(d["h"], E), Wf(pn + "self_attn.q_proj.weight", E), qkv, M, 3 * E, E, bias=self.b(pn + "self_attn.q_proj.bias"))
             ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), S, T, T, D, nb1=B, nb2=H, alpha=D ** -0.5,
                      ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
-            Pm[: B * H * T * Tp].view(-1, Tp)[:, :T] = torch.softmax(S.view(-1, Tp)[:, :T], dim=-1)        # fp32 soft-max, as fairseq
+            ops.softmax_fwd_f32(S, Pm, B * H * T, T, Tp, Tp)                                               # fp32 soft-max, as fairseq (one wave per row)
             ops.gemm(Op(Pm, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["ctx"], T, D, T, b_t=True,
                      nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
             ops.gemm(Op(d["ctx"], E), Wf(pn + "self_attn.out_proj.weight", E), d["x1"], M, E, E, bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)

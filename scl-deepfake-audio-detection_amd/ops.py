@@ -374,6 +374,10 @@ def softmax_fwd(S, P, R, T, ldS, Tp):
     _call("scl_softmax_fwd", _p(S), _p(P), R, T, ldS, Tp, _stream())
 
 
+def softmax_fwd_f32(S, P, R, T, ldS, Tp):
+    _call("scl_softmax_fwd_f32", _p(S), _p(P), R, T, ldS, Tp, _stream())
+
+
 def softmax_bwd(P, dP, dS, R, T, lddP, Tp):
     _call("scl_softmax_bwd", _p(P), _p(dP), _p(dS), R, T, lddP, Tp, _stream())
 
