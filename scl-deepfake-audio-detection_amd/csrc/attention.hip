@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     float lq_next = 0.f;
     auto fetch_tile = [&](int u) {
         const int q = 32 * u + sr;
-        v0 = make_uint4(0, 0, 0, 0); v1 = make_uint4(0, 0, 0, 0); lq_next = 0.f;
+        v0 = make_uint4(0, 0, 0, 0); v1 = make_uint4(0, 0, 0, 0); lq_next = 1e30f;      // rows past T: exp(0 - huge) = 0, no per-element row test
         if (q < T) {
             if (half == 0) {
                 v0 = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r]; dq_[a][r] = delS[16 * a + 4 * g + r]; }
+                    for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r] * 1.4426950408889634f; dq_[a][r] = delS[16 * a + 4 * g + r]; }
+                const float sc2 = scale * 1.4426950408889634f;      // P = 2^(sc2 * S - lse * log2 e): one fma + v_exp per element
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (j < nkt) {
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                         const bf16x8 k0 = att_frag_rows(Kk, kb, 0, lane), k1 = att_frag_rows(Kk, kb, 1, lane);
                         const bf16x8 vv0 = att_frag_rows(Vk, kb, 0, lane), vv1 = att_frag_rows(Vk, kb, 1, lane);
                         const int key = 16 * kb + lc;
+                        const bool key_dead = key >= T;      // only the last key tile can hold one (K rows past T are zeros: S = 0, P would be e^-lse)
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
                             f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int qq = 32 * u + 16 * a + 4 * g + r;
-                                const float p = (key < T && qq < T) ? __expf(scale * sv[r] - lq[a][r]) : 0.f;
+                                const float p = key_dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc2, -lq[a][r]));
                                 // attention dropout: O = (P x mask) V, so dV takes P x mask and dP = (dO V^T) x mask; delta = <dO, O> is unchanged
                                 const float mk = DROP ? dropout_scale(drop_seed, (((uint64_t)b * H + h) * T + (uint64_t)(qq < T ? qq : 0)) * T + (uint64_t)key, drop_p) : 1.f;
                                 P[a][j][r] = p * mk;

@@ -28,6 +28,36 @@ def shard_indices(n_items, rank, world, epoch_seed=None, drop_last=True):
     return idx[rank::world].tolist()
 
 
+class GatherForGlobalLoss(torch.autograd.Function):
+    """all_gather of a per-rank tensor [b, ...] into [world * b, ...] (rank order) for a loss term that EVERY rank evaluates identically on
+    the gathered tensor — the optional global-batch SupCon of SURVEY.md 8(e): nn.DataParallel in the reference would have gathered
+    `feats` onto one device before Model.loss.  Backward: the rank keeps the rows it contributed and multiplies them by the world
+    size — the N identical copies of the term each back-propagate only through their own rows, the gradient exchange then averages over
+    ranks, and N x (1/N) leaves exactly the gradient of ONE global term.  No second collective."""
+
+    @staticmethod
+    def forward(ctx, x, group=None):
+        world = dist.get_world_size(group)
+        ctx.rank, ctx.world, ctx.b = dist.get_rank(group), world, x.shape[0]
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.b:(ctx.rank + 1) * ctx.b] * float(ctx.world), None
+
+
+def gather_for_global_loss(x, group=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    if x.requires_grad:
+        return GatherForGlobalLoss.apply(x, group)
+    out = torch.empty((dist.get_world_size(group) * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
 class GradSync:
     """Bucketed all-reduce of the flat gradient slice, launched in backward order.
 

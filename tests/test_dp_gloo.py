@@ -156,3 +156,41 @@ def test_reduce_scatter_sharded_update_and_all_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _worker_gather(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.parallel import gather_for_global_loss
+    torch.manual_seed(5)
+    full = torch.randn(world * 3, 4, 2)                       # the global batch every rank would see
+    w = torch.randn(world * 3, 4, 2)
+    local = full[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    g = gather_for_global_loss(local)
+    ok = torch.equal(g.detach(), full)
+    # a term every rank evaluates identically on the gathered tensor; the exchange then AVERAGES the ranks' gradients
+    loss = (g * g * w).sum()
+    loss.backward()
+    mine = torch.zeros_like(full)
+    mine[rank * 3:(rank + 1) * 3] = local.grad
+    dist.all_reduce(mine)
+    mean_over_ranks = mine / world
+    ok = ok and torch.allclose(mean_over_ranks, 2 * full * w, atol=1e-6)        # = the gradient of ONE global term
+    lab = gather_for_global_loss(torch.tensor([rank, rank + 10]))
+    ok = ok and lab.tolist() == [0, 10, 1, 11][: 2 * world]
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_global_loss_gather_backward_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

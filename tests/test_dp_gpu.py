@@ -214,3 +214,59 @@ def test_gradsync_choreography_on_rccl_with_one_rank(dev, wire):
         assert torch.equal(plain, synced)
     else:       # gradients rounded to bf16 on the wire: three AdamW steps of lr 1e-3 later the weights agree to a few 1e-4
         assert (plain - synced).abs().max().item() < 3.1e-3 and not torch.equal(plain, synced)
+
+
+def _worker_global_supcon(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SCL_GLOBAL_SUPCON="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.model_linear import Model
+    from scl_amd.parallel import GradSync
+    dev = torch.device("cuda:0")
+    m = Model(ARGS, dev, seed=0)
+    m.eval()
+    sync = GradSync(m.P.grad[: m.P.n_train], bucket_elems=40000)
+    m.grad_sync = sync
+    x, y = _data(rank)
+    out, feats, emb = m(x.to(dev))
+    losses = m.loss(out, feats, emb, y.to(dev), CONF)
+    sync.begin()
+    sum(losses.values()).backward()
+    scale = sync.finish()
+    torch.cuda.synchronize()
+    q.put((rank, (m.P.grad[: m.P.n_train] * scale).cpu().numpy(), {k: float(v) for k, v in losses.items()}))
+    dist.destroy_process_group()
+
+
+def test_global_batch_supcon_over_two_ranks_equals_the_one_process_global_loss(dev):
+    """SCL_GLOBAL_SUPCON=1 (optional): the SupCon terms see the features of both ranks (all-gathered), the NLL term stays
+    rank-local.  The averaged gradient of the two ranks must equal the gradient of (CE_0 + CE_1) / 2 + SupCon(all 8 utterances)
+    computed in one process on the concatenated batch."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_global_supcon, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (torch.from_numpy(g), l)) for r, g, l in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1]["L_CF1"] - res[1][1]["L_CF1"]) < 1e-6 and res[0][1]["L_CE"] != res[1][1]["L_CE"]      # one global term, two local ones
+    from scl_amd.model_linear import Model, _LossFn
+    m = Model(ARGS, dev, seed=0)
+    m.eval()
+    (x0, y0), (x1, y1) = _data(0), _data(1)
+    x, y = torch.cat([x0, x1]).to(dev), torch.cat([y0, y1]).to(dev)
+    out, feats, emb = m(x)
+    ce0, _, _ = _LossFn.apply(out[:4], feats[:4], emb[:4], y[:4])
+    ce1, _, _ = _LossFn.apply(out[4:], feats[4:], emb[4:], y[4:])
+    _, cf1, cf2 = _LossFn.apply(out, feats, emb, y)
+    assert abs(cf1.item() - res[0][1]["L_CF1"]) < 1e-3 * abs(cf1.item()) + 1e-6
+    (0.5 * (ce0 + ce1) + cf1 + cf2).backward()
+    torch.cuda.synchronize()
+    ref = m.P.grad[: m.P.n_train].cpu()
+    got = res[0][0]
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel          # the batch-8 forward and the two batch-4 forwards pick different GEMM tiles: bf16 round-off only
