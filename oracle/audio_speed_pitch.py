@@ -8,8 +8,9 @@ PARITY PARTLY PINNED: neither package can be imported here.  The speed path's AR
 `audioop` (mul / add), which is in this container's standard library — tests/golden/audioop.npz holds the whole speedup()
 sequence below executed with the real audioop.mul / audioop.add in place of `_mul` / `_add` (factors below and above 1, a
 speech-like and a full-scale clip; oracle/gen_golden.py::gen_audioop, tests/test_oracle_golden.py).  What remains a restatement
-of pydub's published source is the sequence itself (slicing, fade steps, looped overlay, append).  The pitch path (librosa)
-stays UNPINNED.  Both are anchored on the reference's call sites above and on its converters (utils.py:20-30, pinned in
+of pydub's published source is the sequence itself (slicing, fade steps, looped overlay, append).  Of the pitch path (librosa) the
+two transforms at its ends, `stft` and `istft` (and the periodic Hann window), are pinned to scipy.signal's stft / istft with
+librosa's framing (tests/test_speed_pitch_cpu.py); the phase vocoder and the resampler stay UNPINNED restatements.  Both are anchored on the reference's call sites above and on its converters (utils.py:20-30, pinned in
 oracle/audio_int16.py).
 
 `Seg` restates the part of pydub.AudioSegment that speedup() touches, for mono 16-bit audio, statement by statement: millisecond

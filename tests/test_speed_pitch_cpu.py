@@ -105,3 +105,27 @@ def test_resampler_passes_the_band_and_rejects_above_the_cutoff():
     assert len(out) == int(np.ceil(4000 * 0.9)) and np.abs(out[100:-100] - want[100:-100]).max() < 1e-3
     hi = np.sin(2 * np.pi * 0.49 * t).astype(np.float32)               # above the new Nyquist (0.45): removed
     assert np.abs(SP.resample_sinc(hi, 0.9)[100:-100]).max() < 1e-3
+
+
+def test_stft_and_istft_restatements_match_scipy_signal():
+    """librosa is absent, but the two transforms at either end of pitch_shift have a second public implementation in this image:
+    scipy.signal.stft / istft with librosa's framing (periodic Hann, n_fft 2048, hop 512, centred with zero padding) — equal up to
+    scipy's 'spectrum' scaling by the window sum.  Pins `stft`, `istft` and the window; the phase vocoder and the resampler stay
+    restated (see the oracle's header)."""
+    import scipy.signal as ss
+    from oracle import audio_speed_pitch as SP
+    rs = np.random.RandomState(3)
+    y = (0.2 * rs.randn(16000 + 333)).astype(np.float32)
+    w = SP.hann_periodic(SP.N_FFT)
+    assert np.allclose(w, ss.get_window("hann", SP.N_FFT, fftbins=True), atol=1e-15)
+    f, t, Z = ss.stft(y.astype(np.float64), window=w, nperseg=SP.N_FFT, noverlap=SP.N_FFT - SP.HOP, nfft=SP.N_FFT, boundary="zeros", padded=False,
+                      return_onesided=True, scaling="spectrum")
+    D = SP.stft(y)
+    assert D.shape == Z.shape == (1025, 1 + len(y) // SP.HOP)
+    scale = np.abs(Z).max() * w.sum()
+    assert np.abs(D - Z * w.sum()).max() / scale < 1e-6
+    back = SP.istft(D, len(y))
+    assert np.abs(back - y).max() < 1e-5                       # the round trip is the identity away from nothing at all (COLA at hop = n_fft / 4)
+    _, x2 = ss.istft(Z, window=w, nperseg=SP.N_FFT, noverlap=SP.N_FFT - SP.HOP, nfft=SP.N_FFT, boundary=True, scaling="spectrum")
+    n = min(len(x2), len(y))
+    assert np.abs(back[:n] - x2[:n]).max() < 1e-5
