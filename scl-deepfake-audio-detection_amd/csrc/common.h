@@ -113,21 +113,28 @@ __device__ __forceinline__ float dropout_scale(uint32_t seed, uint64_t idx, floa
     return u >= p ? 1.0f / (1.0f - p) : 0.0f;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions on the DPP data path (no LDS crossbar): __shfl_xor lowers to ds_bpermute_b32 on gfx950 — six DEPENDENT
+// LDS round trips (~100 cycles each) per reduction, which a kernel with two waves per SIMD (conv0_bwd: two reductions per frame)
+// cannot hide.  Here: two quad permutes, row_half_mirror, row_mirror (every lane of a 16-lane row then holds the row's value),
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 (lane 63 holds the total) and one v_readlane.  Fixed order:
+// deterministic; the association differs from the butterfly's, so sums may differ from round 2's in the last bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float scl_dpp(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+#define SCL_WAVE_REDUCE(OP, IDENT)                                                           \
+    v = OP(v, scl_dpp<0xB1, 0xF>(v, v));   /* quad_perm [1,0,3,2] */                          \
+    v = OP(v, scl_dpp<0x4E, 0xF>(v, v));   /* quad_perm [2,3,0,1] */                          \
+    v = OP(v, scl_dpp<0x141, 0xF>(v, v));  /* row_half_mirror */                              \
+    v = OP(v, scl_dpp<0x140, 0xF>(v, v));  /* row_mirror */                                   \
+    v = OP(v, scl_dpp<0x142, 0xA>(v, IDENT));  /* row_bcast:15 -> rows 1, 3 */                \
+    v = OP(v, scl_dpp<0x143, 0xC>(v, IDENT));  /* row_bcast:31 -> rows 2, 3 */                \
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+__device__ __forceinline__ float scl_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum(float v) { SCL_WAVE_REDUCE(scl_addf, 0.f) }
+__device__ __forceinline__ float wave_max(float v) { SCL_WAVE_REDUCE(fmaxf, -INFINITY) }
+__device__ __forceinline__ float wave_min(float v) { SCL_WAVE_REDUCE(fminf, INFINITY) }
+#undef SCL_WAVE_REDUCE
 
 // host side ---------------------------------------------------------------------------------
 void scl_set_error(const char* fmt, ...);

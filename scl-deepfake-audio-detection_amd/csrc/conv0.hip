@@ -43,6 +43,15 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
     conv0_stage(wT, xs, w, x + (int64_t)b * L, C, k, L, t0 * stride, nx);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float bia[MAXCH0][8], gam[MAXCH0][8], bet[MAXCH0][8];      // this lane's channels of bias / gamma / beta: loop-invariant over the wave's frames
+#pragma unroll
+    for (int ch = 0; ch < MAXCH0; ++ch) {
+        const int c = ch * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bia[ch][i] = c < C ? bias[c + i] : 0.f; gam[ch][i] = c < C ? gamma[c + i] : 0.f; bet[ch][i] = c < C ? beta[c + i] : 0.f;
+        }
+    }
     for (int r = wv; r < nrows; r += 4) {
         float y[MAXCH0][8];
         float s = 0.f;
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             const int c = ch * 512 + lane * 8;
             if (c < C) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[ch][i] = bias[c + i];
+                for (int i = 0; i < 8; ++i) y[ch][i] = bia[ch][i];
                 for (int j = 0; j < k; ++j) {
                     const float xv = xs[r * stride + j];
                     const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             if (c < C) {
                 float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (y[ch][i] - mean) * rstd * gamma[c + i] + beta[c + i];
+                for (int i = 0; i < 8; ++i) o[i] = (y[ch][i] - mean) * rstd * gam[ch][i] + bet[ch][i];
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // two elements per packed-f32 instruction, same bits as gelu_f
                 const int64_t off = ((int64_t)b * T0 + t0 + r) * C + c;
@@ -131,14 +140,32 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
         for (int q = 0; q < KT + 3; ++q) aw[i][q] = 0.f;
     const int c = lane * 8;
     const bool act = c < C;
+    // the frame's dz vector and (mean, rstd) are requested one frame ahead: with two waves per SIMD (216 registers) an un-prefetched
+    // HBM round trip per frame was fully exposed
+    float gam[8], bet[8], bia[8];      // this lane's 8 channels of the affine / bias vectors: loop-invariant, kept in registers
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gam[i] = act ? gamma[c + i] : 0.f; bet[i] = act ? beta[c + i] : 0.f; bia[i] = act ? bias[c + i] : 0.f; }
+    uint4 u_next = make_uint4(0, 0, 0, 0);
+    float mean_next = 0.f, rstd_next = 0.f;
+    if (wv < nrows) {
+        const int64_t row0 = (int64_t)b * T0 + t0 + wv;
+        if (act) u_next = *reinterpret_cast<const uint4*>(dz + row0 * C + c);
+        if (STATS) { mean_next = stats[2 * row0]; rstd_next = stats[2 * row0 + 1]; }
+    }
     for (int r = wv; r < nrows; r += 4) {
         float y[8], g8[8], dzv[8], xr[KT];
         const int64_t row = (int64_t)b * T0 + t0 + r;
+        const uint4 u = u_next;
+        const float mean_cur = mean_next, rstd_cur = rstd_next;
+        if (r + 4 < nrows) {
+            if (act) u_next = *reinterpret_cast<const uint4*>(dz + (row + 4) * C + c);
+            if (STATS) { mean_next = stats[2 * (row + 4)]; rstd_next = stats[2 * (row + 4) + 1]; }
+        }
 #pragma unroll
         for (int j = 0; j < KT; ++j) xr[j] = j < k ? xs[r * stride + j] : 0.f;
         if (act) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) y[i] = bias[c + i];
+            for (int i = 0; i < 8; ++i) y[i] = bia[i];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 if (j < k) {
@@ -148,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
                     y[4] += w1.x * xr[j]; y[5] += w1.y * xr[j]; y[6] += w1.z * xr[j]; y[7] += w1.w * xr[j];
                 }
             }
-            const uint4 u = *reinterpret_cast<const uint4*>(dz + row * C + c);
             const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dzv[2 * i] = __uint_as_float(uw[i] << 16); dzv[2 * i + 1] = __uint_as_float(uw[i] & 0xFFFF0000u); }
@@ -158,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
         }
         float mean, rstd;
         if (STATS) {
-            mean = stats[2 * row]; rstd = stats[2 * row + 1];
+            mean = mean_cur; rstd = rstd_cur;
         } else {
             float s = 0.f;
 #pragma unroll
@@ -175,13 +201,13 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
         if (act) {
             float gg[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gg[i] = ((y[i] - mean) * rstd) * gamma[c + i] + beta[c + i];
+            for (int i = 0; i < 8; ++i) gg[i] = ((y[i] - mean) * rstd) * gam[i] + bet[i];
 #pragma unroll
             for (int i = 0; i < 8; i += 2) gelu_grad2(gg[i], gg[i + 1]);      // packed-f32 form, same bits as gelu_grad_f
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float h = (y[i] - mean) * rstd;
-                const float gmi = gamma[c + i];
+                const float gmi = gam[i];
                 const float dyn = dzv[i] * gg[i];
                 aw[i][KT + 1] += dyn * h;  // dgamma
                 aw[i][KT + 2] += dyn;      // dbeta
