@@ -148,15 +148,27 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
     char* Kt = asmem;                 // [rows][128 B] row-read image
     char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
-    for (int idx = threadIdx.x; idx < rows * 8; idx += blockDim.x) {
-        const int key = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < T) {
-            kv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
-            vv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+    // K / V staging: all of a thread's loads are requested before the first LDS write (a rolled load -> write loop paid one memory
+    // round trip per iteration; rows * 8 <= 2048 vectors = 4 per thread)
+    {
+        uint4 kv[4], vv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + 512 * it, key = idx >> 3, c = idx & 7;
+            kv[it] = make_uint4(0, 0, 0, 0); vv[it] = make_uint4(0, 0, 0, 0);
+            if (idx < rows * 8 && key < T) {
+                kv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
+                vv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+            }
         }
-        *reinterpret_cast<uint4*>(Kt + att_k_off(key, c)) = kv;
-        *reinterpret_cast<uint4*>(Vt + att_t_off(key, 8 * c)) = vv;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + 512 * it, key = idx >> 3, c = idx & 7;
+            if (idx < rows * 8) {
+                *reinterpret_cast<uint4*>(Kt + att_k_off(key, c)) = kv[it];
+                *reinterpret_cast<uint4*>(Vt + att_t_off(key, 8 * c)) = vv[it];
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -302,16 +314,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     float* lseS = reinterpret_cast<float*>(dSs + 8 * 2048);   // [32]
     float* delS = lseS + 32;               // [32]
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
-    for (int idx = threadIdx.x; idx < rows * 8; idx += 512) {
-        const int key = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < T) {
-            kv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
-            vv = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+    {   // all loads first, then the LDS writes (see attn_fwd_kernel); rows * 8 <= 1792 vectors = 4 per thread
+        uint4 kv[4], vv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + 512 * it, key = idx >> 3, c = idx & 7;
+            kv[it] = make_uint4(0, 0, 0, 0); vv[it] = make_uint4(0, 0, 0, 0);
+            if (idx < rows * 8 && key < T) {
+                kv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
+                vv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
+            }
         }
-        *reinterpret_cast<uint4*>(Kk + att_k_off(key, c)) = kv;
-        *reinterpret_cast<uint4*>(Kt + att_t_off(key, 8 * c)) = kv;
-        *reinterpret_cast<uint4*>(Vk + att_k_off(key, c)) = vv;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + 512 * it, key = idx >> 3, c = idx & 7;
+            if (idx < rows * 8) {
+                *reinterpret_cast<uint4*>(Kk + att_k_off(key, c)) = kv[it];
+                *reinterpret_cast<uint4*>(Kt + att_t_off(key, 8 * c)) = kv[it];
+                *reinterpret_cast<uint4*>(Vk + att_k_off(key, c)) = vv[it];
+            }
+        }
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7

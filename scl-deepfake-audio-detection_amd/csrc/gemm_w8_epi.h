@@ -14,8 +14,13 @@ namespace sclg {
 // a lane owns 8 consecutive columns of one row, 8 lanes own a row's 64 columns, so bias / residual loads and the C / C2 stores of
 // one wave-instruction cover 8 rows x 128 (bf16) or 256 (f32) contiguous bytes.  Arithmetic per element is the old epilogue's,
 // in the same order: results are bit-identical.
-static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[4][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
-                                                 int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr) {
+// NMT: 16-row blocks the accumulator array holds (4: 16-KiB block per wave; the persistent kernel hands over 2 at a time: 8 KiB).
+// cs_carry (optional, 8 floats of the caller): column sums are added to it instead of being reduced and stored per pass (the caller
+// finishes with w8_colsum_store once all its passes are done).
+template <int NMT>
+static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
+                                                 int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr,
+                                                 float* cs_carry = nullptr) {
     const int flags = d.flags;
     const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
     const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
@@ -24,7 +29,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
     const int g = lane >> 4, lc = lane & 15;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
         if (mt < nmt) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -139,7 +144,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += rr[j];
             }
-            if (csum_row) {
+            if (csum_row || cs_carry) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) cs[j] += v[j];
             }
@@ -158,7 +163,10 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
             for (int j = 0; j < 8; ++j) epi_scalar(ea, v[j], off + j, col + j, bias);
         }
     }
-    if (csum_row) {      // lanes that share c = lane & 7 hold the same 8 columns for rows rsub, rsub + 8, ...: fixed-order butterfly over rsub
+    if (cs_carry) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs_carry[j] += cs[j];
+    } else if (csum_row) {      // lanes that share c = lane & 7 hold the same 8 columns for rows rsub, rsub + 8, ...: fixed-order butterfly over rsub
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             cs[j] += __shfl_xor(cs[j], 8, 64);
@@ -172,5 +180,20 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     }
 }
 
+
+// finish a carried column sum: butterfly over the 8 row lanes that share a column group, lanes 0-7 store 8 columns each
+static __device__ __forceinline__ void w8_colsum_store(const GemmK& d, float (&cs)[8], float* csum_row, int nbase, int lane) {
+    const int col = nbase + 8 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        cs[j] += __shfl_xor(cs[j], 8, 64);
+        cs[j] += __shfl_xor(cs[j], 16, 64);
+        cs[j] += __shfl_xor(cs[j], 32, 64);
+    }
+    if (lane < 8 && d.vec_ok && col + 8 <= d.N) {
+        *reinterpret_cast<float4*>(csum_row + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(csum_row + col + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+    }
+}
 
 }  // namespace sclg

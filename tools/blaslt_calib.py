@@ -3,9 +3,11 @@ the encoder's shapes?  Gives the distance of scl_gemm_* from a tuned library ker
 import torch
 
 dev = torch.device("cuda:0")
-shapes = [("fc1 fwd", 6368, 4096, 1024, "nt"), ("fc2 fwd", 6368, 1024, 4096, "nt"), ("qkv fwd", 6368, 3072, 1024, "nt"),
-          ("out fwd", 6368, 1024, 1024, "nt"), ("fc1 dgrad", 6368, 1024, 4096, "nn"), ("fc1 wgrad", 4096, 1024, 6368, "tn"),
-          ("fc2 wgrad", 1024, 4096, 6368, "tn"), ("conv1", 204768, 512, 1536, "nt"), ("conv2", 102368, 512, 1536, "nt"),
+import sys
+MB = int(sys.argv[1]) if len(sys.argv) > 1 else 12736          # rows of the encoder linears: 12736 = batch 64, 6368 = batch 32
+shapes = [("fc1 fwd", MB, 4096, 1024, "nt"), ("fc2 fwd", MB, 1024, 4096, "nt"), ("qkv fwd", MB, 3072, 1024, "nt"),
+          ("out fwd", MB, 1024, 1024, "nt"), ("fc1 dgrad", MB, 1024, 4096, "nn"), ("fc2 dgrad", MB, 4096, 1024, "nn"), ("fc1 wgrad", 4096, 1024, MB, "tn"),
+          ("fc2 wgrad", 1024, 4096, MB, "tn"), ("out wgrad", 1024, 1024, MB, "tn"), ("conv1", 6399 * (MB // 199), 512, 1536, "nt"),
           ("big square", 8192, 8192, 8192, "nt")]
 for name, M, N, K, lay in shapes:
     a = torch.randn((M, K) if lay[0] == "n" else (K, M), device=dev, dtype=torch.bfloat16)
