@@ -141,6 +141,10 @@ int scl_gemm_colsum_rows(const SclGemmDesc* desc);
 /* diagnostic: copy the per-block stamps of the last SCL_GEMM_STAMPS launch: 8 x u64 per block = {realtime (100 MHz), shader
  * clock} at kernel entry, after the prologue, after the K loop, after the epilogue (blocks 0 .. nblocks-1, nblocks <= 4096). */
 int scl_debug_gemm_stamps(unsigned long long* out, int nblocks);
+/* diagnostic: launches so far (this process) that took the persistent wide-tile kernel (gemm_w8.hip, w8p: one resident block per CU
+ * walks several tiles, next tile's first K stage requested before the epilogue).  Environment SCL_GEMM_PERSIST: 0 (default) never, 1
+ * when a launch has more than one round of tiles, 8 .. 256 = that many resident blocks whenever the kernel is legal (tests). */
+long long scl_debug_gemm_persistent_launches(void);
 
 /* Split-K with the epilogue kept: run `desc` as a plain split-K GEMM into f32 slabs ([nslabs][M][N], slab stride `stride` elements:
  * same A / B, C = slabs, ldc = N, splitk = nslabs, no epilogue flags, alpha as in desc), then this pass stores

@@ -856,6 +856,8 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     return scl_check_launch("scl_gemm_bf16");
 }
 
+extern "C" long long scl_debug_gemm_persistent_launches(void) { return scl_gemm_w8p_launches(); }
+
 extern "C" int scl_debug_gemm_stamps(unsigned long long* out, int nblocks) {
     SCL_REQUIRE(out && nblocks > 0 && nblocks <= 4096, "gemm stamps: bad args");
     return scl_gemm_read_stamps(out, nblocks);

@@ -224,9 +224,10 @@ bool fill_operand(const SclOperand& o, const char* name, long long rows, long lo
 int scl_gemm_f32_launch(const SclGemmDesc& d, GemmK& k, hipStream_t s);   // gemm_f32.hip
 
 // gemm_w8.hip (host side)
-struct W8Plan { int variant, tiles_m, tile_m; long long tiles, cost; };
+struct W8Plan { int variant, tiles_m, tile_m; long long tiles, cost; int ncu = 0; };
 bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan);
 int scl_gemm_read_stamps(unsigned long long* out, int nblocks);
+long long scl_gemm_w8p_launches();
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s);
 
 // gemm_x2.hip (host side): 208 x 128 tiles, two 4-wave workgroups per CU (plan->variant = 2)

@@ -391,6 +391,177 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     }
 }
 
+// ---- persistent single-barrier variant ("w8p") -----------------------------------------------------------------------------
+// One block per CU stays resident and walks the tiles v = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: v & 7, the XCD of
+// tile_coords, is the block's own).  Why: with one 160-KiB block per CU nothing overlaps a block's retirement, the dispatch of the
+// next one, its argument loads and the first LDS-DMA round trip — at K = 1024 a 208 x 256 tile spends 23 us in its 16 K steps and
+// 35 us on the CU (fc1 forward, plain stores: 141 us for 4 rounds; the vendor library's persistent kernel: 117 us).  Here
+//   * K step nk-2 of a tile stages the NEXT tile's K-stage 0 instead of out-of-range pieces (A into the ring slot that is free,
+//     B into the image just consumed): it lands under the last two K steps;
+//   * the epilogue runs in the 96 KiB that do not hold that stage: a wave's transposition block is two 4-KiB halves (two 16-row
+//     blocks per pass) at ITS OWN piece offsets of the two free A slots, its R staging the same 4 KiB of the free B image — so
+//     after its last pass a wave stages K-stage 1 of the next tile straight into those regions without a block-wide barrier;
+//   * the next K loop starts on stage 0 (landed before the epilogue), its first wait covers stage 1 and the epilogue's stores.
+// Same tile, same K order, same epilogue arithmetic and column-sum partial rows as w8s: bit-identical results.
+// The descriptor is NOT kept in scalar registers across the K loops (w8s already spills some; here the epilogue's and the loaders'
+// fields would be live through every K step of every tile): the hand-over step and the epilogue re-read it from the kernel-argument
+// segment through a pointer the compiler cannot trace back (scalar loads, a few hundred cycles once per tile).
+typedef const __attribute__((address_space(4))) GemmK* W8KArg;
+__device__ __forceinline__ const GemmK* w8p_args(W8KArg p) {
+    asm volatile("" : "+s"(p));
+    return (const GemmK*)p;
+}
+template <bool AT, bool BT, int RBW>
+__device__ __forceinline__ void w8p_body(const GemmK& d, W8KArg kp, char* smem, const char* Ab, const char* Bb, int ab, int tiles_m, int tiles_n,
+                                         int lane, int wave, int wc) {
+    typedef typename W8Sel<AT>::type LA;
+    typedef typename W8Sel<BT>::type LB;
+    const unsigned stepA = LA::kstep(d.A), stepB = LB::kstep(d.B);
+    const int nk = d.K / BK;                                       // >= 3, no split-K (host)
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int nbk = wc * 4;
+    char* const bimg = smem + W8_NA * W8_OPB;
+    char *a_cur = smem, *a_nxt = smem + W8_OPB, *a_fill = smem + 2 * W8_OPB;
+    int bpar = 0;                                                  // B image that holds K-stage 0 of the current tile
+    int v = blockIdx.x, tm, tn;
+    tile_coords(v, ntiles, tiles_m, tiles_n, tm, tn, d.group_m);
+    const int tile_m = d.tile_m, Mrows = d.M, group_m = d.group_m;
+    int m0 = tm * tile_m, n0 = tn * W8_BN, mlimit = min(Mrows, m0 + tile_m);
+    LA la;
+    LB lb;
+    la.init(d.A, Ab, m0, mlimit, lane, wave);
+    lb.init(d.B, Bb, n0, d.N, lane, wave);
+    la.template issue2<0>(a_cur, wave, 0u, true); la.template issue2<2>(a_cur, wave, 0u, true);
+    lb.template issue2<0>(bimg, wave, 0u, true); lb.template issue2<2>(bimg, wave, 0u, true);
+    la.template issue2<0>(a_nxt, wave, stepA, true); la.template issue2<2>(a_nxt, wave, stepA, true);
+    lb.template issue2<0>(bimg + W8_OPB, wave, stepB, true); lb.template issue2<2>(bimg + W8_OPB, wave, stepB, true);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#define W8S_READ(FA, FB, TA, TB, KS)                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = w8_frag<BT>(TB, nbk + j, KS, lane); \
+    _Pragma("unroll") for (int i = 0; i < RBW; ++i) FA[i] = w8_frag<AT>(TA, ab + i, KS, lane);
+#define W8S_MFMA(FA, FB)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
+    for (;;) {
+        f32x4 acc[RBW][4];
+#pragma unroll
+        for (int i = 0; i < RBW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa0[RBW], fa1[RBW], fb0[4], fb1[4];
+        const int vn = v + G;
+        const bool has_next = vn < ntiles;
+        int m0n = 0, n0n = 0, mlimn = 0;
+        if (has_next) {
+            tile_coords(vn, ntiles, tiles_m, tiles_n, tm, tn, group_m);
+            m0n = tm * tile_m; n0n = tn * W8_BN; mlimn = min(Mrows, m0n + tile_m);
+        }
+        unsigned soffA = stepA, soffB = stepB;                     // K-stage 1 is in flight, stage 0 visible
+        W8S_READ(fa0, fb0, a_cur, bimg + bpar * W8_OPB, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+            char* tB = bimg + ((kt + bpar) & 1) * W8_OPB;
+            const bool hand = kt + 2 == nk;                        // this step stages the next tile's K-stage 0
+            const bool live2 = kt + 2 < nk || (hand && has_next);
+            soffA += stepA; soffB += stepB;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            W8S_READ(fa1, fb1, a_cur, tB, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            W8S_MFMA(fa0, fb0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (hand && has_next) {      // the current tile's last A stage was requested at kt-1
+                const GemmK* dh = w8p_args(kp);
+                la.init(dh->A, reinterpret_cast<const char*>(dh->A.ptr), m0n, mlimn, lane, wave);
+            }
+            {
+                const unsigned sa = hand ? 0u : soffA;
+                la.template issue2<0>(a_fill, wave, sa, live2); la.template issue2<2>(a_fill, wave, sa, live2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (hand && has_next) {
+                const GemmK* dh = w8p_args(kp);
+                lb.init(dh->B, reinterpret_cast<const char*>(dh->B.ptr), n0n, dh->N, lane, wave);
+            }
+            {
+                const unsigned sb = hand ? 0u : soffB;
+                lb.template issue2<0>(tB, wave, sb, live2); lb.template issue2<2>(tB, wave, sb, live2);
+            }
+            if (kt + 1 < nk) { W8S_READ(fa0, fb0, a_nxt, bimg + (((kt + bpar) & 1) ^ 1) * W8_OPB, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            W8S_MFMA(fa1, fb1)
+            __builtin_amdgcn_sched_barrier(0);
+            char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
+        }
+        // a_cur: stage 0 of the next tile (or zeros); a_nxt: the zero pieces of step nk-1; a_fill: K tile nk-1; B image
+        // (nk-1+bpar)&1: zero pieces.  Everything has landed and every wave is past its last fragment read after this barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* const bfree = bimg + ((nk - 1 + bpar) & 1) * W8_OPB;
+        {
+            const GemmK& d = *w8p_args(kp);      // shadows the kernel's by-value copy on purpose
+            const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias : nullptr;
+            char* wlds = a_fill + wave * 4096;
+            const int bstride = (int)(a_nxt - a_fill);
+            char* wextra = bfree + wave * 4096;
+            float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
+            float cs[8];
+#pragma unroll
+            for (int pr = 0; pr < (RBW + 1) / 2; ++pr) {
+                if (pr == 0 || pr == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+                }
+                if (2 * pr + 1 < RBW) {
+                    f32x4 (&a2)[2][4] = *reinterpret_cast<f32x4 (*)[2][4]>(&acc[2 * pr]);
+                    w8_epilogue_pass<2>(d, a2, 2, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
+                                        cs0 ? cs : nullptr, bstride);
+                } else {
+                    f32x4 (&a1)[1][4] = *reinterpret_cast<f32x4 (*)[1][4]>(&acc[2 * pr]);
+                    w8_epilogue_pass<1>(d, a1, 1, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
+                                        cs0 ? cs : nullptr, bstride);
+                }
+                if (cs0 && (pr == 1 || pr == (RBW + 1) / 2 - 1)) w8_colsum_store(d, cs, cs0 + (pr >> 1) * d.N, n0 + wc * 64, lane);
+            }
+        }
+        if (!has_next) break;
+        // K-stage 1 of the next tile into this wave's own epilogue regions (its LDS reads have returned: their values were stored)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        la.template issue2<0>(a_nxt, wave, stepA, true); la.template issue2<2>(a_nxt, wave, stepA, true);
+        lb.template issue2<0>(bfree, wave, stepB, true); lb.template issue2<2>(bfree, wave, stepB, true);
+        bpar = (bpar + nk) & 1;
+        v = vn; m0 = m0n; n0 = n0n; mlimit = mlimn;
+    }
+#undef W8S_READ
+#undef W8S_MFMA
+}
+
+template <bool AT, bool BT, int RB0, int RB1>
+__global__ __launch_bounds__(512, 2) void scl_gemm_w8p_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr);
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr);
+    W8KArg kp = (W8KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    if (RB0 == RB1) {
+        w8p_body<AT, BT, RB0>(d, kp, smem, Ab, Bb, wr * RB0, tiles_m, tiles_n, lane, wave, wc);
+    } else if (wr == 0) {
+        w8p_body<AT, BT, RB0>(d, kp, smem, Ab, Bb, 0, tiles_m, tiles_n, lane, wave, wc);
+    } else {
+        w8p_body<AT, BT, RB1>(d, kp, smem, Ab, Bb, RB0, tiles_m, tiles_n, lane, wave, wc);
+    }
+}
+
 template <int RB0, int RB1>
 void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, int mode) {
     static bool attr_set = false;
@@ -403,9 +574,18 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         attr_set = true;
     }
     const dim3 block(512);
+    if (mode == 2) {      // persistent: grid = resident blocks (never both operands transposed: those launches take the ping-pong loop)
+        if (!at && !bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else if (!at && bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+        else SCL_LAUNCH((scl_gemm_w8p_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+        return;
+    }
     if (mode == 1) {
         if (!at && !bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
         else if (!at && bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
@@ -442,11 +622,14 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
         if (best < 0 || cost < best) {
             best = cost;
             plan->variant = v; plan->tiles_m = (int)ntm; plan->tile_m = (int)((d.M + ntm - 1) / ntm);
-            plan->tiles = ntm * tiles_n; plan->cost = cost;
+            plan->tiles = ntm * tiles_n; plan->cost = cost; plan->ncu = ncu;
         }
     }
     return true;
 }
+
+static long long w8p_launches = 0;
+long long scl_gemm_w8p_launches() { return w8p_launches; }
 
 int scl_gemm_read_stamps(unsigned long long* out, int nblocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(scl_gemm_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
@@ -466,9 +649,25 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // and dgrad shapes (single barrier ahead), the ping-pong 2-9 % ahead when both operands are transposed (wgrads: twice the LDS
     // read instructions per fragment)
     const char* me = getenv("SCL_W8_MODE");
-    const int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
-    if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, grid, s, mode);
-    else w8_launch_rb<8, 8>(k, at, bt, grid, s, mode);
+    int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
+    // persistent blocks (w8p): SCL_GEMM_PERSIST = 0 (default) never, 1 when the launch has more than one round of tiles, 8 .. 256 =
+    // that many resident blocks whenever the kernel is legal (tests: several tiles per block on small problems).  Opt-in: measured
+    // on MI355X against one-tile blocks (tools/persist_probe.py, profiles/r3_gemm_persistent_vs_one_tile.txt) it is equal within
+    // +-2 % on the encoder's 3- and 4-round launches — the first K step of the next tile still waits (in-order vmcnt) for the
+    // epilogue's stores, whose drain into HBM, with every CU storing at once, is what a block switch already overlapped — and the
+    // 256-row variant spills.
+    const char* pe = getenv("SCL_GEMM_PERSIST");
+    const int pv = pe ? atoi(pe) : 0;
+    dim3 g = grid;
+    if (mode == 1 && pv > 0 && zdim == 1 && k.splitk == 1 && k.K / BK >= 3 && !(k.flags & SCL_GEMM_STAMPS)) {
+        const long long ncu = plan.ncu >= 8 ? plan.ncu : 256;
+        const long long rounds = (plan.tiles + ncu - 1) / ncu;
+        long long G = pv >= 8 ? (pv & ~7) : ((((plan.tiles + rounds - 1) / rounds) + 7) & ~7ll);      // equal rounds on every block, a multiple of 8
+        if (G > (ncu & ~7ll) && pv < 8) G = ncu & ~7ll;
+        if ((pv >= 8 || rounds >= 2) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
+    }
+    if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
+    else w8_launch_rb<8, 8>(k, at, bt, g, s, mode);
     return 0;
 }
 

@@ -15,12 +15,13 @@ namespace sclg {
 // one wave-instruction cover 8 rows x 128 (bf16) or 256 (f32) contiguous bytes.  Arithmetic per element is the old epilogue's,
 // in the same order: results are bit-identical.
 // NMT: 16-row blocks the accumulator array holds (4: 16-KiB block per wave; the persistent kernel hands over 2 at a time: 8 KiB).
-// cs_carry (optional, 8 floats of the caller): column sums are added to it instead of being reduced and stored per pass (the caller
-// finishes with w8_colsum_store once all its passes are done).
+// cs_carry (optional, 8 floats of the caller): the column sums START from it and are handed back in it instead of being reduced and
+// stored per pass (the caller finishes with w8_colsum_store): two 2-block passes then add a lane's rows in the order one 4-block pass does.
+// blk_stride: byte distance between the wave's 4-KiB (16-row) transposition blocks (4096: one contiguous block).
 template <int NMT>
 static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
                                                  int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr,
-                                                 float* cs_carry = nullptr) {
+                                                 float* cs_carry = nullptr, const int blk_stride = 4096) {
     const int flags = d.flags;
     const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
     const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
@@ -33,7 +34,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
         if (mt < nmt) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(wlds + (mt * 16 + lc) * 256 + (((nt * 4 + g) ^ lc) << 4)) = acc[mt][nt];
+                *reinterpret_cast<f32x4*>(wlds + mt * blk_stride + lc * 256 + (((nt * 4 + g) ^ lc) << 4)) = acc[mt][nt];
         }
     }
     const int c = lane & 7, rsub = lane >> 3;
@@ -46,6 +47,10 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     }
     const EpiArgs ea = {d.C, d.C2, d.R, d.N, d.flags, d.drop_seed, d.drop_p};
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of this lane's 8 columns over the rows it stores (csum_row)
+    if (cs_carry) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] = cs_carry[j];
+    }
     // The R operand (activation-gradient input / residual) comes in through LDS-DMA, several rows at a time: loads and stores share
     // the in-order vmcnt counter, so a wait for row i's R vector requested after row i-1's stores also waits for those stores'
     // acknowledgement — one memory round trip per row (tools/epilogue_probe.py: reading R cost 52 us per launch where a second
@@ -81,8 +86,9 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
             rstage = dst - (r_f32 ? i * 2048 : i * 1024);      // row-batch i lives at rstage + i * (2048 | 1024)
         }
         const int r = 8 * i + rsub;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c) ^ (r & 15)) << 4));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + r * 256 + (((2 * c + 1) ^ (r & 15)) << 4));
+        const char* wrow = wlds + (r >> 4) * blk_stride + (r & 15) * 256;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + (((2 * c) ^ (r & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + (((2 * c + 1) ^ (r & 15)) << 4));
         const int row = mbase + r;
         if (row >= mlimit) continue;
         const unsigned q = udiv_magic((unsigned)row, d.c_magic, d.c_shift);
@@ -165,7 +171,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     }
     if (cs_carry) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cs_carry[j] += cs[j];
+        for (int j = 0; j < 8; ++j) cs_carry[j] = cs[j];
     } else if (csum_row) {      // lanes that share c = lane & 7 hold the same 8 columns for rows rsub, rsub + 8, ...: fixed-order butterfly over rsub
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

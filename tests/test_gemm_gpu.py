@@ -364,6 +364,93 @@ def test_two_blocks_per_cu_kernel_epilogues_and_conv_rows(dev):
     assert torch.equal(outs[0], outs[1])
 
 
+def _persistent_launches():
+    return ops.L.load().scl_debug_gemm_persistent_launches()
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("M,N,K,blocks", [(12736, 4096, 1024, "1"), (12736, 3072, 1024, "1"), (2184, 3072, 1024, "8"), (5128, 1288, 192, "16"),
+                                          (3000, 1000, 320, "8"), (5 * 208 + 8, 2 * 256 + 40, 448, "8"), (6400 * 2, 512, 1536, "24")])
+def test_persistent_wide_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_t, M, N, K, blocks):
+    """gemm_w8.hip's persistent blocks (w8p): every resident block walks several tiles, requests the next tile's first K stage two K
+    steps before its epilogue and the second one from inside its own epilogue regions.  Same tiles and K order as the one-tile
+    blocks => bit-identical to the 128 x 128 kernel: the encoder's multi-round shapes with the automatic grid, and small problems
+    with 8-24 resident blocks (many tiles per block, a ragged last round, 3 K steps = the minimum, an odd number of K steps = the
+    B images swap roles from tile to tile, ragged M / N edges); operands are followed by NaN so an unchecked fetch shows."""
+    A = _rand((M, K), dev, 171, 0.3); B = _rand((N, K), dev, 172, 0.3)
+    def nanpad(mat):
+        buf = torch.full((mat.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=dev)
+        buf[:mat.numel()] = mat.reshape(-1)
+        return buf
+    opA = ops.Op(nanpad(A.t().contiguous()), M) if a_t else ops.Op(nanpad(A), K)
+    opB = ops.Op(nanpad(B.t().contiguous()), N) if b_t else ops.Op(nanpad(B), K)
+    outs = []
+    for persist, kw in (("0", dict(no_p8=True, no_big=True, no_w8=True, no_x2=True)), ("0", dict(force_w8=True)), (blocks, dict(force_w8=True)),
+                        (blocks, dict(force_w8=True))):
+        monkeypatch.setenv("SCL_GEMM_PERSIST", persist)
+        n0 = _persistent_launches()
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(opA, opB, C, M, N, K, a_t=a_t, b_t=b_t, act=2, **kw)
+        assert _persistent_launches() - n0 == (0 if persist == "0" else 1), (persist, kw)
+        outs.append(C)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    _close(outs[2], torch.relu(A.float() @ B.float().t()), 8e-3, "w8p a_t=%s b_t=%s" % (a_t, b_t))
+
+
+def test_persistent_wide_kernel_epilogues_column_sums_and_conv_rows(dev, monkeypatch):
+    """Every fused epilogue of the encoder through the persistent blocks (two 16-row blocks per pass, R staged in the free B image)
+    against the 128 x 128 kernel, bit for bit; the per-tile column sums must equal the one-tile kernel's partial rows bit for bit
+    (same rows in the same order per lane); utterance-batched overlapping conv rows."""
+    M, N, K = 9 * 199 + 57, 1024, 512
+    A = _rand((M, K), dev, 181, 0.3); W = _rand((N, K), dev, 182, 0.05); Wt = W.t().contiguous()
+    bias = torch.randn(N, device=dev); Rb = _rand((M, N), dev, 183, 1.0); Rf = torch.randn(M, N, device=dev)
+    cases = [
+        (dict(bias=bias, act=1), torch.bfloat16, True),                      # fc1 forward: GELU + pre-activation copy
+        (dict(R=Rb, rmode=2, ract=1), torch.bfloat16, False),                # fc2 data gradient
+        (dict(bias=bias, R=Rf, rmode=1), torch.float32, False),              # out-proj / fc2 forward: f32 residual stream
+        (dict(bias=bias, R=Rb, rmode=1), torch.float32, False),
+        (dict(R=Rf, rmode=2, ract=1), torch.bfloat16, False),
+        (dict(bias=bias, act=3, drop_p=0.5, drop_seed=1234), torch.bfloat16, True),
+    ]
+    for kw, cdt, c2 in cases:
+        for b_t, opB in ((False, ops.Op(W, K)), (True, ops.Op(Wt, N))):
+            outs = []
+            for persist, sel in (("0", dict(no_w8=True, no_p8=True, no_big=True, no_x2=True)), ("8", dict(force_w8=True))):
+                monkeypatch.setenv("SCL_GEMM_PERSIST", persist)
+                n0 = _persistent_launches()
+                C = torch.full((M, N), float("nan"), dtype=cdt, device=dev)
+                C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev) if c2 else None
+                ops.gemm(ops.Op(A, K), opB, C, M, N, K, b_t=b_t, c2=C2, **kw, **sel)
+                assert _persistent_launches() - n0 == int(persist != "0")
+                outs.append((C, C2))
+            assert torch.equal(outs[0][0], outs[1][0]), kw.keys()
+            if c2:
+                assert torch.equal(outs[0][1], outs[1][1]), kw.keys()
+    # column sums: partial rows of the persistent blocks == partial rows of the one-tile blocks
+    kw = dict(b_t=True, R=Rb, rmode=2, ract=1, force_w8=True)
+    parts = []
+    for persist in ("0", "8"):
+        monkeypatch.setenv("SCL_GEMM_PERSIST", persist)
+        C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        rows = ops.gemm_colsum_rows(ops.Op(A, K), ops.Op(Wt, N), C, M, N, K, **kw)
+        part = torch.full((rows, N), float("nan"), device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(Wt, N), C, M, N, K, colsum_part=part, **kw)
+        parts.append((C, part))
+    assert torch.equal(parts[0][0], parts[1][0]) and torch.equal(parts[0][1], parts[1][1]) and torch.isfinite(parts[1][1]).all()
+    Bz, Tin, C_, k, s = 6, 1601, 512, 3, 2
+    Tout = (Tin - k) // s + 1
+    z = _rand((Bz * Tin * C_ + 65536,), dev, 61, 0.3); wk = _rand((C_, k * C_), dev, 62, 0.05)
+    cb = torch.randn(C_, device=dev)
+    outs = []
+    for persist, sel in (("0", dict(no_w8=True, no_p8=True, no_big=True, no_x2=True)), ("8", dict(force_w8=True))):
+        monkeypatch.setenv("SCL_GEMM_PERSIST", persist)
+        y = torch.full((Bz * Tout, C_), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(ops.Op(z, s * C_, rpb=Tout, rbstride=Tin * C_), ops.Op(wk, k * C_), y, Bz * Tout, C_, k * C_, bias=cb, **sel)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K,b_t", [(12736, 4096, 1024, True), (1000, 520, 256, False), (3 * 206 + 5, 1024, 512, True)])
 def test_wide_tile_epilogue_column_sums(dev, M, N, K, b_t):
     """SclGemmDesc.colsum_part: the wide tiles also write per-tile column sums of the f32 values they store (the bias gradient of the
