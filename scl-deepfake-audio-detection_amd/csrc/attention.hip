@@ -287,13 +287,23 @@ __device__ __forceinline__ bf16x8 att_pack8(const f32x4& a, const f32x4& b) {
 //   * dS of all waves goes to ONE LDS image of eight [32 q][32 keys] sub-images (sub-image = owning wave = one 32-deep k step);
 //   * dQ is produced without partial sums: wave w computes the [16 q x 16 d] output tile (q-tile w&1, d-tile w>>1) over ALL keys
 //     (<= 8 MFMAs) and stores it, so the 32 KiB of per-wave f32 partials and the 4-wave combine pass are gone;
-//   * Q is staged by threads 0-255, dO / O / delta by threads 256-511, both prefetched one step ahead.
-// LDS: K (row image), K (tr image), V (row image) + 16 KiB query tiles + 16 KiB dS = 116 KiB for T = 199.
+//   * wave 7 owns no keys (T <= 224): it alone stages the query tiles (Q, dO, O for delta, LSE), fetched two steps ahead;
+//   * query tiles and the dS image are double-buffered, so a step has ONE barrier:  [S, dP, P, dS, dV, dK of tile u | stage tile u+1]
+//     barrier  [dQ of tile u], and a wave runs dQ(u) and the MFMA phase of u+1 back to back;
+//   * barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier): global loads stay in flight across them;
+//   * dK / dV leave through the wave's own K / V LDS rows as whole 128-byte rows; the 8- and 16-lane sums run on the DPP path.
+// Stamps of each stage of this restructuring (28.8 -> 22.6 us per block, 111.9 -> 94.7 us per launch): profiles/r3_attn_bwd_stamps.txt.
+// LDS: K (row image), K (tr image), V (row image) + 2 x 16 KiB query tiles + 2 x 16 KiB dS = 148.5 KiB for T = 199.
 // -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [32 q][32 keys], 64-B rows, 16-B chunk ^= (q>>2)&3
     return q * 64 + ((((key32 >> 3) ^ (q >> 2)) & 3) << 4) + ((key32 & 7) << 1);
 }
 
+// Workgroup barrier for LDS hand-offs only: __syncthreads() also drains vmcnt (its release fence covers global memory), which made
+// every step of the backward wait for the acknowledgement of its dQ stores (barrier A), for the query-tile loads it had just
+// requested for the NEXT step (barrier B), and the bias-sum tail for the dK / dV stores.  Here: this wave's LDS operations retired,
+// then s_barrier; global loads stay in flight (the compiler still waits for them where their registers are first used).
+#define ATT_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 template <bool DROP, int NTC>      // attention dropout compiled in only where asked for; NTC: compile-time key-tile count (0 = run time), as in attn_fwd_kernel
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
@@ -306,14 +316,33 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     char* Kk = asmem;
     char* Kt = Kk + rows * 128;
     char* Vk = Kt + rows * 128;
-    char* Qk = Vk + rows * 128;            // 4 KiB each
-    char* Qt = Qk + 4096;
-    char* Ok = Qt + 4096;
-    char* Ot = Ok + 4096;
-    char* dSs = Ot + 4096;                 // [8 waves][32 q][64 B]
-    float* lseS = reinterpret_cast<float*>(dSs + 8 * 2048);   // [32]
-    float* delS = lseS + 32;               // [32]
+    char* QO = Vk + rows * 128;            // 2 buffers x {Q rows, Q tr, dO rows, dO tr} of 4 KiB, then 2 dS images of 16 KiB
+    float* lseS = reinterpret_cast<float*>(QO + 65536);   // 2 x {lse[32], delta[32]}
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
+    // Staging role: wave 7 never owns keys (T <= 224 = 14 key tiles, two per wave), so it alone carries the query tiles — Q, dO, O
+    // (for delta) and LSE of 32 queries, four 16-byte pieces of each per lane, fetched two steps ahead of their use and written to the
+    // idle tile buffer while waves 0-6 are in their MFMA phase.
+    const bool stager = wave == 7;
+    const int sc = lane & 7, sr0 = lane >> 3;      // piece i of this lane: query row sr0 + 8 i, 16-byte chunk sc
+    uint4 vq[4], vo[4], vc[4];
+    float lqn[4];
+    auto fetch_tile = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 32 * u + sr0 + 8 * i;
+            vq[i] = make_uint4(0, 0, 0, 0); vo[i] = make_uint4(0, 0, 0, 0); vc[i] = make_uint4(0, 0, 0, 0);
+            lqn[i] = 1e30f;      // rows past T: exp(0 - huge) = 0, no per-element row test
+            if (q < T) {
+                vq[i] = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
+                vo[i] = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+                vc[i] = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
+                if (sc == 0) lqn[i] = lse[((int64_t)b * H + h) * T + q];
+            }
+        }
+    };
+    if (stager) fetch_tile(0);
     {   // all loads first, then the LDS writes (see attn_fwd_kernel); rows * 8 <= 1792 vectors = 4 per thread
         uint4 kv[4], vv[4];
 #pragma unroll
@@ -335,11 +364,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             }
         }
     }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
     const int lc = lane & 15, g = lane >> 4;
     int nkt = NT - 2 * wave; nkt = nkt < 0 ? 0 : (nkt > 2 ? 2 : nkt);     // 16-key tiles this wave owns
-    char* dSw = dSs + wave * 2048;
 
     f32x4 dVt[4][2], dKt[4][2];
 #pragma unroll
@@ -348,45 +374,41 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
         for (int j = 0; j < 2; ++j) { dVt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     f32x4 dqsum = f32x4{0.f, 0.f, 0.f, 0.f};      // bias_part: column sums of this wave's dQ tiles over the query steps
 
-    // staging roles: threads 0..255 carry Q, threads 256..511 carry dO + O (for delta) + LSE; one step ahead in registers
-    const int half = threadIdx.x >> 8, st = threadIdx.x & 255;
-    const int sr = st >> 3, sc = st & 7;
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-    float lq_next = 0.f;
-    auto fetch_tile = [&](int u) {
-        const int q = 32 * u + sr;
-        v0 = make_uint4(0, 0, 0, 0); v1 = make_uint4(0, 0, 0, 0); lq_next = 1e30f;      // rows past T: exp(0 - huge) = 0, no per-element row test
-        if (q < T) {
-            if (half == 0) {
-                v0 = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 8 * sc);
-            } else {
-                v0 = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
-                v1 = *reinterpret_cast<const uint4*>(ctx + ((int64_t)b * T + q) * E + h * ATT_D + 8 * sc);
-                if (sc == 0) lq_next = lse[((int64_t)b * H + h) * T + q];
-            }
-        }
-    };
-    fetch_tile(0);
-    for (int u = 0; u < NT2; ++u) {
-        __syncthreads();   // A: previous step's readers are done with the query tiles and the dS image (and K/V staging on u == 0)
-        if (half == 0) {
-            *reinterpret_cast<uint4*>(Qk + att_k_off(sr, sc)) = v0;
-            *reinterpret_cast<uint4*>(Qt + att_t_off(sr, 8 * sc)) = v0;
-        } else {
-            *reinterpret_cast<uint4*>(Ok + att_k_off(sr, sc)) = v0;
-            *reinterpret_cast<uint4*>(Ot + att_t_off(sr, 8 * sc)) = v0;
-            const unsigned ow[4] = {v0.x, v0.y, v0.z, v0.w}, cw[4] = {v1.x, v1.y, v1.z, v1.w};
+    // One barrier per step: the query tiles and the dS image are double-buffered (buffer = step parity), so while a step's dS is
+    // being consumed by the dQ tiles (after the barrier) nothing a later step writes can touch it, and the NEXT step's query tiles are
+    // staged before the same barrier.  A wave therefore runs  dQ(u) | S, dP, P, dS, dV, dK (u+1)  back to back without a barrier in
+    // between (the latency-bound dQ chain of one wave overlaps the fragment reads of the next step).
+    auto stage_tile = [&](int p) {      // registers (tile fetched earlier) -> tile buffer p
+        char* qo = QO + p * 16384;
+        float* ls = lseS + p * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sr = sr0 + 8 * i;
+            *reinterpret_cast<uint4*>(qo + att_k_off(sr, sc)) = vq[i];
+            *reinterpret_cast<uint4*>(qo + 4096 + att_t_off(sr, 8 * sc)) = vq[i];
+            *reinterpret_cast<uint4*>(qo + 8192 + att_k_off(sr, sc)) = vo[i];
+            *reinterpret_cast<uint4*>(qo + 12288 + att_t_off(sr, 8 * sc)) = vo[i];
+            const unsigned ow[4] = {vo[i].x, vo[i].y, vo[i].z, vo[i].w}, cw[4] = {vc[i].x, vc[i].y, vc[i].z, vc[i].w};
             float dot = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dot += __uint_as_float(ow[k] << 16) * __uint_as_float(cw[k] << 16);
                 dot += __uint_as_float(ow[k] & 0xFFFF0000u) * __uint_as_float(cw[k] & 0xFFFF0000u);
             }
-            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-            if (sc == 0) { delS[sr] = dot; lseS[sr] = lq_next; }
+            dot = lanes8_sum(dot);
+            if (sc == 0) { ls[32 + sr] = dot; ls[sr] = lqn[i]; }
         }
-        if (u + 1 < NT2) fetch_tile(u + 1);      // in flight during this step's MFMAs
-        __syncthreads();   // B
+    };
+    auto main_phase = [&](int u) {      // S, dP, P, dS, dV^T, dK^T of query tile u (tile buffer u & 1) and this wave's keys; dS -> image u & 1
+        const int p = u & 1;
+        const char* Qk = QO + p * 16384;
+        const char* Qt = Qk + 4096;
+        const char* Ok = Qk + 8192;
+        const char* Ot = Qk + 12288;
+        char* dSs = QO + 32768 + p * 16384;      // [8 waves][32 q][64 B]
+        char* dSw = dSs + wave * 2048;
+        const float* lseP = lseS + p * 64;
+        const float* delP = lseP + 32;
         {
             f32x4 P[2][2], dS[2][2];
 #pragma unroll
@@ -401,9 +423,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                     for (int ks = 0; ks < 2; ++ks) { qa[a][ks] = att_frag_rows(Qk, a, ks, lane); oa[a][ks] = att_frag_rows(Ok, a, ks, lane); }
                 float lq[2][4], dq_[2][4];
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { lq[a][r] = lseS[16 * a + 4 * g + r] * 1.4426950408889634f; dq_[a][r] = delS[16 * a + 4 * g + r]; }
+                for (int a = 0; a < 2; ++a) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(lseP + 16 * a + 4 * g), d4 = *reinterpret_cast<const float4*>(delP + 16 * a + 4 * g);
+                    lq[a][0] = l4.x * 1.4426950408889634f; lq[a][1] = l4.y * 1.4426950408889634f; lq[a][2] = l4.z * 1.4426950408889634f; lq[a][3] = l4.w * 1.4426950408889634f;
+                    dq_[a][0] = d4.x; dq_[a][1] = d4.y; dq_[a][2] = d4.z; dq_[a][3] = d4.w;
+                }
                 const float sc2 = scale * 1.4426950408889634f;      // P = 2^(sc2 * S - lse * log2 e): one fma + v_exp per element
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -423,11 +447,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int qq = 32 * u + 16 * a + 4 * g + r;
-                                const float p = key_dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc2, -lq[a][r]));
+                                const float pv = key_dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sc2, -lq[a][r]));
                                 // attention dropout: O = (P x mask) V, so dV takes P x mask and dP = (dO V^T) x mask; delta = <dO, O> is unchanged
                                 const float mk = DROP ? dropout_scale(drop_seed, (((uint64_t)b * H + h) * T + (uint64_t)(qq < T ? qq : 0)) * T + (uint64_t)key, drop_p) : 1.f;
-                                P[a][j][r] = p * mk;
-                                dS[a][j][r] = p * (dp[r] * mk - dq_[a][r]);
+                                P[a][j][r] = pv * mk;
+                                dS[a][j][r] = pv * (dp[r] * mk - dq_[a][r]);
                             }
                         }
                     }
@@ -460,7 +484,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                             *reinterpret_cast<bf16_t*>(dSw + att_s_off(16 * a + 4 * g + r, 16 * j + lc)) = f2bf(dS[a][j][r]);
             }
         }
-        __syncthreads();   // C: every wave's dS is in LDS
+    };
+    auto dq_phase = [&](int u) {
+        char* dSs = QO + 32768 + (u & 1) * 16384;
         {   // ---- dQ tile [16 q (tile qa_) x 16 d (tile dt)] over all keys; lane ends up with 4 consecutive d of one query
             const int qa_ = wave & 1, dt = wave >> 1;
             f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -478,19 +504,56 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
                     make_uint2(pack_bf2(dq[0] * scale, dq[1] * scale), pack_bf2(dq[2] * scale, dq[3] * scale));
             dqsum += dq;      // rows q >= T hold zeros (their P is masked to 0)
         }
+    };
+    if (stager) {
+        stage_tile(0);      // tile 0 was requested before the K / V loads
+        if (1 < NT2) fetch_tile(1);
+        ATT_LDS_BARRIER();      // K / V images and query tile 0 are in LDS
+        for (int u = 0; u < NT2; ++u) {
+            if (u + 1 < NT2) {
+                stage_tile((u & 1) ^ 1);      // tile u+1 -> the other buffer: its last readers finished before the previous barrier
+                if (u + 2 < NT2) fetch_tile(u + 2);
+            }
+            ATT_LDS_BARRIER();
+            dq_phase(u);
+        }
+    } else {
+        ATT_LDS_BARRIER();
+        for (int u = 0; u < NT2; ++u) {
+            main_phase(u);
+            ATT_LDS_BARRIER();   // every wave's dS of this step and the next step's query tiles are in LDS
+            dq_phase(u);
+        }
     }
-    // ---- dK, dV of this wave's keys: lane owns key 16(2w+j)+lc, d = 16dt + 4g + 0..3
+    // ---- dK, dV of this wave's keys: lane owns key 16(2w+j)+lc, d = 16dt + 4g + 0..3 — 8 bytes of a 128-byte row.  Stored directly
+    // that is 16 instructions of sixteen 32-byte row pieces each (stamps: 1.8 us to issue them, and the block's tail waited on their
+    // drain); instead the wave turns its [32 keys][64 d] blocks around in LDS — the K and V row images of ITS OWN keys, which
+    // nobody reads after the last step's barrier C — and stores whole 128-byte rows, 8 rows per instruction.
+    if (nkt > 0) {
+        char* tk = Kk + wave * 4096;
+        char* tv = Vk + wave * 4096;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int key = 16 * (2 * wave + j) + lc;
-        if (j < nkt && key < T) {
-            bf16_t* dst = dqkv + ((int64_t)b * T + key) * 3 * E + h * ATT_D + 4 * g;
+        for (int j = 0; j < 2; ++j) {
+            const int row = 16 * j + lc;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<uint2*>(dst + E + 16 * dt) = make_uint2(pack_bf2(dKt[dt][j][0] * scale, dKt[dt][j][1] * scale),
-                                                                         pack_bf2(dKt[dt][j][2] * scale, dKt[dt][j][3] * scale));
-                *reinterpret_cast<uint2*>(dst + 2 * E + 16 * dt) = make_uint2(pack_bf2(dVt[dt][j][0], dVt[dt][j][1]),
-                                                                             pack_bf2(dVt[dt][j][2], dVt[dt][j][3]));
+                const int off = row * 128 + ((((2 * dt + (g >> 1)) ^ (row & 7))) << 4) + ((g & 1) << 3);
+                *reinterpret_cast<uint2*>(tk + off) = make_uint2(pack_bf2(dKt[dt][j][0] * scale, dKt[dt][j][1] * scale),
+                                                                 pack_bf2(dKt[dt][j][2] * scale, dKt[dt][j][3] * scale));
+                *reinterpret_cast<uint2*>(tv + off) = make_uint2(pack_bf2(dVt[dt][j][0], dVt[dt][j][1]), pack_bf2(dVt[dt][j][2], dVt[dt][j][3]));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-local: no barrier
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + (lane >> 3), cc = lane & 7;
+            const int key = 32 * wave + row;
+            const uint4 kq = *reinterpret_cast<const uint4*>(tk + row * 128 + ((cc ^ (row & 7)) << 4));
+            const uint4 vq = *reinterpret_cast<const uint4*>(tv + row * 128 + ((cc ^ (row & 7)) << 4));
+            if (key < T) {
+                bf16_t* dst = dqkv + ((int64_t)b * T + key) * 3 * E + h * ATT_D + 8 * cc;
+                *reinterpret_cast<uint4*>(dst + E) = kq;
+                *reinterpret_cast<uint4*>(dst + 2 * E) = vq;
             }
         }
     }
@@ -498,14 +561,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     // ---- column sums of this (utterance, head)'s dQ / dK / dV block -> bias_part[b][3E]: the q/k/v bias gradient is the column sum
     // of dqkv (autograd of F.linear), summed here from the f32 accumulators instead of by a pass over the 78 MB tensor.
     // Fixed order: butterfly over the 16 key / query lanes, then waves in index order => deterministic.
-    __syncthreads();                       // the dS image is free
-    float* red = reinterpret_cast<float*>(dSs);      // [8 waves][16 (dq) + 64 (dk) + 64 (dv)] f32 = 4.5 KiB
+    ATT_LDS_BARRIER();                     // the dS image is free
+    float* red = reinterpret_cast<float*>(QO + 32768);      // [8 waves][16 (dq) + 64 (dk) + 64 (dv)] f32 = 4.5 KiB (first dS image)
     {
         float v[4] = {dqsum[0] * scale, dqsum[1] * scale, dqsum[2] * scale, dqsum[3] * scale};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] += __shfl_xor(v[r], 1, 64); v[r] += __shfl_xor(v[r], 2, 64); v[r] += __shfl_xor(v[r], 4, 64); v[r] += __shfl_xor(v[r], 8, 64);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = lanes16_sum(v[r]);
         if (lc == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave * 144 + 4 * g + r] = v[r];
@@ -517,8 +578,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             for (int r = 0; r < 4; ++r) {      // keys >= T and tiles this wave does not own hold zeros
                 kk[r] = (dKt[dt][0][r] + dKt[dt][1][r]) * scale;
                 vv[r] = dVt[dt][0][r] + dVt[dt][1][r];
-                kk[r] += __shfl_xor(kk[r], 1, 64); kk[r] += __shfl_xor(kk[r], 2, 64); kk[r] += __shfl_xor(kk[r], 4, 64); kk[r] += __shfl_xor(kk[r], 8, 64);
-                vv[r] += __shfl_xor(vv[r], 1, 64); vv[r] += __shfl_xor(vv[r], 2, 64); vv[r] += __shfl_xor(vv[r], 4, 64); vv[r] += __shfl_xor(vv[r], 8, 64);
+                kk[r] = lanes16_sum(kk[r]);
+                vv[r] = lanes16_sum(vv[r]);
             }
             if (lc == 0) {
 #pragma unroll
@@ -526,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
             }
         }
     }
-    __syncthreads();
+    ATT_LDS_BARRIER();
     if (threadIdx.x < 192) {
         const int which = threadIdx.x >> 6, d = threadIdx.x & 63;      // 0: q, 1: k, 2: v
         float t = 0.f;
@@ -561,7 +622,7 @@ extern "C" int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     SCL_REQUIRE(qkv && ctx && dctx && lse && dqkv && B > 0 && H > 0 && drop_p >= 0.f && drop_p < 1.f, "attn_bwd: bad args");
     SCL_REQUIRE(D == ATT_D && T >= 1 && T <= 224, "attn_bwd: fused path needs head dim 64 and T <= 224 (got D=%d, T=%d)", D, T);
     const int NT = (T + 15) / 16, rows = 32 * ((NT + 1) / 2);
-    const size_t lds = (size_t)3 * rows * 128 + 4 * 4096 + 8 * 2048 + 64 * 4;
+    const size_t lds = (size_t)3 * rows * 128 + 2 * 16384 + 2 * 16384 + 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)attn_bwd8_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -131,6 +131,19 @@ __device__ __forceinline__ float scl_dpp(float v, float old) {
     v = OP(v, scl_dpp<0x143, 0xC>(v, IDENT));  /* row_bcast:31 -> rows 2, 3 */                \
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 __device__ __forceinline__ float scl_addf(float a, float b) { return a + b; }
+// sums over aligned groups of 8 / 16 lanes, every lane of the group ends up with the group's total; same pairing tree as the
+// __shfl_xor 1, 2, 4(, 8) butterfly (bitwise equal), on the DPP path
+__device__ __forceinline__ float lanes8_sum(float v) {
+    v += scl_dpp<0xB1, 0xF>(v, v);
+    v += scl_dpp<0x4E, 0xF>(v, v);
+    v += scl_dpp<0x141, 0xF>(v, v);
+    return v;
+}
+__device__ __forceinline__ float lanes16_sum(float v) {
+    v = lanes8_sum(v);
+    v += scl_dpp<0x140, 0xF>(v, v);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) { SCL_WAVE_REDUCE(scl_addf, 0.f) }
 __device__ __forceinline__ float wave_max(float v) { SCL_WAVE_REDUCE(fmaxf, -INFINITY) }
 __device__ __forceinline__ float wave_min(float v) { SCL_WAVE_REDUCE(fminf, INFINITY) }
