@@ -59,7 +59,8 @@ def gemm_source_sha():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "scl-deepfake-audio-detection_amd", "csrc", "gemm*"))):
+    csrc = os.path.join(ROOT, "scl-deepfake-audio-detection_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "gemm*")) + glob.glob(os.path.join(csrc, "posconv*"))):
         if f.endswith((".hip", ".h")):
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -226,7 +227,7 @@ def main():
                    "per_gpu_batch": B, "samples": L, "parallelism": "dp%d" % world, "tiny": bool(args.tiny)},
         "final_loss": loss_val,
         "model_flops_fraction_of_bf16_peak": (utt_s * flop_per_utt / (world * PEAK_BF16_TFLOPS * 1e12)) if flop_per_utt else None,
-        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{w8,w8s,dma}_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "scl_gemm_{w8,w8s,dma}_kernel + posconv_mfma_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
                      "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,

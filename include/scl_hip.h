@@ -138,6 +138,16 @@ int scl_gemm_uses_wide_tiles(const SclGemmDesc* desc);
  * that can (then colsum_part must be null: scl_gemm_bf16 refuses it). */
 int scl_gemm_colsum_rows(const SclGemmDesc* desc);
 
+/* Grouped positional convolution of the encoder (fairseq ConvPositionalEmbedding behind model/xlsr.py:41) as an implicit GEMM with the
+ * utterance's padded input resident in LDS (csrc/posconv.hip).  xpad: bf16 [B][T + K][G * Cg], output row t of utterance b reads rows
+ * t .. t + K - 1; w: bf16 [G][Cg out][K * Cg] with k = tap * Cg + in (scl_posconv_weight_pack's forward or data-gradient image);
+ * fwd != 0: C = gelu(conv + bias) + R, c2 = bf16(conv + bias) (the pre-activation the backward needs); fwd == 0: C = conv + R
+ * (bias / c2 unused).  C, R: f32 [B * T][G * Cg].  Bit-identical to the same contraction through scl_gemm_bf16.
+ * scl_posconv_supported: 1 when the shape can take this kernel (Cg = 64, T <= 208, even K <= 128), else the caller uses the GEMM. */
+int scl_posconv_supported(int T, int K, int G, int Cg);
+int scl_posconv_mfma(const void* xpad, const void* w, float* C, const float* bias, void* c2, const float* R, int B, int T, int K, int G,
+                     int Cg, int fwd, void* stream);
+
 /* diagnostic: copy the per-block stamps of the last SCL_GEMM_STAMPS launch: 8 x u64 per block = {realtime (100 MHz), shader
  * clock} at kernel entry, after the prologue, after the K loop, after the epilogue (blocks 0 .. nblocks-1, nblocks <= 4096). */
 int scl_debug_gemm_stamps(unsigned long long* out, int nblocks);

@@ -40,56 +40,83 @@ __device__ __forceinline__ void store8_f32(float* base, int64_t off, const float
     *reinterpret_cast<float4*>(base + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-template <bool XF32>
+// One wave per NR rows (NR = 2: both rows' loads are requested before either reduction — a wave that handles one [1024] row is a
+// single dependent chain load -> sum -> sum -> store, and 12736 such waves reached 3.2 TB/s; see tools/ln_probe.py).
+template <bool XF32, int NR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y_bf,
                                                      float* __restrict__ y_f32, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int C, int64_t ldx,
                                                      int64_t ldy, float eps, int act) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float v[MAXCH][8];
-    float s = 0.f;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
+    if (row0 >= M) return;
+    constexpr int NCHR = NR == 1 ? MAXCH : 2;      // the multi-row form serves C <= 1024
+    float v[NR][NCHR][8];
+    float s[NR];
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-        const int c = ch * 512 + lane * 8;
-        if (c < C) {
-            load8<XF32>(x, (int64_t)row * ldx + c, v[ch]);
+    for (int r = 0; r < NR; ++r) {
+        s[r] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[ch][i];
+        for (int ch = 0; ch < NCHR; ++ch) {
+            const int c = ch * 512 + lane * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[r][ch][i] = 0.f;
+            if (c < C && row0 + r < M) load8<XF32>(x, (int64_t)(row0 + r) * ldx + c, v[r][ch]);
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    float mean[NR], rstd[NR];
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-        const int c = ch * 512 + lane * 8;
-        if (c < C) {
+    for (int r = 0; r < NR; ++r) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float d = v[ch][i] - mean; q += d * d; }
+        for (int ch = 0; ch < NCHR; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[r] += v[r][ch][i];
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
+        mean[r] = wave_sum(s[r]) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCHR; ++ch) {
+            const int c = ch * 512 + lane * 8;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = v[r][ch][i] - mean[r]; q += d * d; }
+            }
+        }
+        rstd[r] = rsqrtf(wave_sum(q) / (float)C + eps);
     }
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
+    for (int ch = 0; ch < NCHR; ++ch) {
         const int c = ch * 512 + lane * 8;
         if (c < C) {
-            float g[8], b[8], o[8];
+            float g[8], b[8];
             load8<true>(gamma, c, g);
             load8<true>(beta, c, b);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (v[ch][i] - mean) * rstd * g[i] + b[i];
-            if (act == 1) {
+            for (int r = 0; r < NR; ++r) {
+                const int row = row0 + r;
+                if (row < M) {
+                    float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // packed-f32 form, same bits as gelu_f
+                    for (int i = 0; i < 8; ++i) o[i] = (v[r][ch][i] - mean[r]) * rstd[r] * g[i] + b[i];
+                    if (act == 1) {
+#pragma unroll
+                        for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // packed-f32 form, same bits as gelu_f
+                    }
+                    if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
+                    if (y_f32) store8_f32(y_f32, (int64_t)row * ldy + c, o);
+                }
             }
-            if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
-            if (y_f32) store8_f32(y_f32, (int64_t)row * ldy + c, o);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (lane == 0 && row0 + r < M) {
+            if (mean_out) mean_out[row0 + r] = mean[r];
+            if (rstd_out) rstd_out[row0 + r] = rstd[r];
         }
     }
 }
@@ -398,10 +425,15 @@ extern "C" int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, c
     SCL_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
     SCL_REQUIRE(M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (ldx & 7) == 0 && (ldy & 7) == 0,
                 "layernorm_fwd: need 8 <= C <= 2048, C, ldx, ldy multiples of 8 (C=%d)", C);
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (x_f32) hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act);
-    else hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act);
+    static const int nr_env = [] { const char* e = getenv("SCL_LN_ROWS"); return e ? atoi(e) : 2; }();
+    const int nr = (nr_env == 2 && C <= 1024 && M >= 4096) ? 2 : 1;
+    dim3 grid((M + 4 * nr - 1) / (4 * nr));
+#define LN_FWD(XF, NR) hipLaunchKernelGGL((ln_fwd_kernel<XF, NR>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act)
+    if (x_f32) { if (nr == 2) LN_FWD(true, 2); else LN_FWD(true, 1); }
+    else { if (nr == 2) LN_FWD(false, 2); else LN_FWD(false, 1); }
+#undef LN_FWD
     return scl_check_launch("scl_layernorm_fwd");
 }
 

@@ -25,6 +25,8 @@ FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
 WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "0") != "0"
 # the (up to) four small column reductions that close a layer's backward in ONE launch (SCL_BATCH_REDUCE=0: one launch each)
 BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
+# positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
+POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 
 
 class W2VConfig:
@@ -356,9 +358,12 @@ class Encoder:
             self._slot(slots, dsc, None, -1, self.SITE_IN)
         # -- positional conv (grouped, weight-normed), GELU, residual (M2 head)
         ops.pad_rows(d["x0"], d["xpad"], B, T, E, T + K, K // 2)
-        ops.gemm(Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wf, K * Cg, bs2=Cg * K * Cg),
-                 d["xin"][0], M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=self.b("encoder.pos_conv.0.bias"), bias_bs2=Cg,
-                 act=ACT_GELU, c2=d["pc_pre"], R=d["x0"], rmode=1)
+        if POSCONV_MFMA and ops.posconv_supported(T, K, G, Cg):      # utterance slab resident in LDS, weights streamed (csrc/posconv.hip)
+            ops.posconv_mfma(d["xpad"], self.pos_wf, d["xin"][0], d["x0"], B, T, K, G, Cg, bias=self.b("encoder.pos_conv.0.bias"), c2=d["pc_pre"])
+        else:
+            ops.gemm(Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wf, K * Cg, bs2=Cg * K * Cg),
+                     d["xin"][0], M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, bias=self.b("encoder.pos_conv.0.bias"), bias_bs2=Cg,
+                     act=ACT_GELU, c2=d["pc_pre"], R=d["x0"], rmode=1)
         if p_res > 0:      # F.dropout(x + pos_conv(x), p = cfg.dropout): after the residual add, so not a GEMM epilogue
             self._slot(slots, ops.dropout(d["xin"][0], d["xin"][0], None, M * E, sseed(-1, self.SITE_ENC), p_res), ops.DROPOUT_SEED, -1, self.SITE_ENC)
         if p_attn > 0 and not d["fused_attn"]:
@@ -628,8 +633,11 @@ class Encoder:
         ops.posconv_weight_bwd(dwf, self.b("encoder.pos_conv.0.weight_v"), self.b("encoder.pos_conv.0.weight_g"), self.pos_norm,
                                self.ws_small, P.g(self.n("encoder.pos_conv.0.weight_v")), P.g(self.n("encoder.pos_conv.0.weight_g")),
                                E, Cg, K)
-        ops.gemm(Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wd, K * Cg, bs2=Cg * K * Cg),
-                 other, M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, R=dx, rmode=1)
+        if POSCONV_MFMA and ops.posconv_supported(T, K, G, Cg):
+            ops.posconv_mfma(d["dcpad"], self.pos_wd, other, dx, B, T, K, G, Cg)
+        else:
+            ops.gemm(Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(self.pos_wd, K * Cg, bs2=Cg * K * Cg),
+                     other, M, Cg, K * Cg, nb2=G, ldc=E, c_bs2=Cg, R=dx, rmode=1)
         dx0 = other
         if p_in > 0:       # backward of dropout_input: d(post_extract_proj output) = dx0 x mask (f32 for the bias sum, bf16 for the GEMMs)
             self._slot(slots, ops.dropout(dx0, dx0, otherb, M * E, sseed(-1, self.SITE_IN), p_in), ops.DROPOUT_SEED, -1, self.SITE_IN)

@@ -78,6 +78,8 @@ def _protos():
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
+        "scl_posconv_supported": ([_i32, _i32, _i32, _i32], _i32),
+        "scl_posconv_mfma": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_debug_gemm_stamps": ([_vp, _i32], _i32),
         "scl_debug_gemm_persistent_launches": ([], ctypes.c_longlong),
         "scl_gemm_uses_wide_tiles": ([P(SclGemmDesc)], _i32),

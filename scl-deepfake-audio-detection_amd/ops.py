@@ -332,6 +332,16 @@ def pad_rows(src, dst, B, T, C, rows_out, pad_before, pre=None, ract=0):
     _call("scl_pad_rows_bf16", _p(src), _isf32(src), _p(dst), _p(pre), ract, B, T, C, rows_out, pad_before, _stream())
 
 
+def posconv_supported(T, K, G, Cg):
+    return bool(L.load().scl_posconv_supported(T, K, G, Cg))
+
+
+def posconv_mfma(xpad, w, C, R, B, T, K, G, Cg, bias=None, c2=None):
+    """Grouped positional conv with the utterance slab resident in LDS (csrc/posconv.hip): forward form (bias, GELU, pre-activation copy
+    c2, + R) when bias is given, data-gradient form (+ R) otherwise."""
+    return _call("scl_posconv_mfma", _p(xpad), _p(w), _p(C), _p(bias), _p(c2), _p(R), B, T, K, G, Cg, 1 if bias is not None else 0, _stream())
+
+
 def col2im(dcol, dz, B, Tin, Tout, C, k, s):
     _call("scl_col2im_bf16", _p(dcol), _p(dz), B, Tin, Tout, C, k, s, _stream())
 

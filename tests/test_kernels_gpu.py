@@ -355,3 +355,44 @@ def test_fused_attention_fwd_bwd(dev, B, T, H):
     exact = torch.stack([(q.grad * 1.0).permute(0, 2, 1, 3).reshape(B, T, E), k.grad.permute(0, 2, 1, 3).reshape(B, T, E),
                          v.grad.permute(0, 2, 1, 3).reshape(B, T, E)], dim=2).reshape(B, T, 3 * E).sum(1)
     assert rel(part, exact) < 2.5e-2
+
+
+@pytest.mark.parametrize("B,T,K,G", [(3, 199, 128, 16), (2, 208, 128, 2), (2, 49, 128, 16), (1, 7, 16, 1), (2, 100, 32, 3)])
+def test_posconv_mfma_equals_the_grouped_gemm(dev, B, T, K, G):
+    """csrc/posconv.hip (utterance slab resident in LDS, weights streamed tap by tap) against the same contraction through
+    scl_gemm_bf16 (2-level contiguous index over the padded rows), forward form (bias + GELU + pre-activation copy + f32 residual) and
+    data-gradient form (+ residual): bit for bit, including T = 208 (all 13 row tiles full), short utterances, few taps, and buffers
+    followed by NaN (a fetch outside the utterance's padded rows would show)."""
+    from scl_amd.ops import Op
+    Cg = 64
+    E, M = G * Cg, B * T
+    gen = torch.Generator().manual_seed(5)
+    def nan_tail(t, extra=65536):
+        buf = torch.full((t.numel() + extra,), float("nan"), dtype=t.dtype, device=dev)
+        buf[:t.numel()] = t.reshape(-1).to(dev)
+        return buf
+    xpad = torch.zeros(B, T + K, E)
+    xpad[:, K // 2: K // 2 + T] = torch.randn(B, T, E, generator=gen) * 0.5
+    xpad = nan_tail(xpad.to(torch.bfloat16))
+    w = nan_tail((torch.randn(G, Cg, K * Cg, generator=gen) * 0.02).to(torch.bfloat16))
+    bias = torch.randn(E, generator=gen).to(dev)
+    R = torch.randn(M, E, generator=gen).to(dev)
+    assert ops.posconv_supported(T, K, G, Cg)
+    outs = []
+    for kernel in ("gemm", "mfma"):
+        for fwd in (True, False):
+            C = torch.full((M, E), float("nan"), device=dev)
+            c2 = torch.full((M, E), float("nan"), dtype=torch.bfloat16, device=dev) if fwd else None
+            if kernel == "gemm":
+                kw = dict(bias=bias, bias_bs2=Cg, act=1, c2=c2) if fwd else {}
+                ops.gemm(Op(xpad, E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), Op(w, K * Cg, bs2=Cg * K * Cg), C, M, Cg, K * Cg,
+                         nb2=G, ldc=E, c_bs2=Cg, R=R, rmode=1, **kw)
+            else:
+                ops.posconv_mfma(xpad, w, C, R, B, T, K, G, Cg, bias=bias if fwd else None, c2=c2)
+            outs.append((C, c2))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.isfinite(outs[i][0]).all()
+        assert torch.equal(outs[i][0], outs[2 + i][0]), ("fwd" if i == 0 else "dgrad", (outs[i][0] - outs[2 + i][0]).abs().max().item())
+    assert torch.equal(outs[0][1], outs[2][1])
+    assert not ops.posconv_supported(209, 128, 16, 64) and not ops.posconv_supported(199, 128, 16, 32) and not ops.posconv_supported(199, 127, 16, 64)

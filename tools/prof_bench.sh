@@ -23,8 +23,8 @@ t=glob.glob('gpurun_out/prof_%s/**/*kernel_trace.csv'%tag,recursive=True)
 agg=collections.defaultdict(lambda:[0,0.0])
 for r in csv.DictReader(open(t[0])):
     nm=r['Kernel_Name']
-    if 'gemm' not in nm: continue
-    key=(nm.split('(sclg::GemmK')[0].replace('void (anonymous namespace)::','')[-60:], r.get('Grid_Size_X', r.get('Grid_Size','')), r.get('Grid_Size_Z',''))
+    if 'gemm' not in nm and 'posconv_mfma' not in nm: continue
+    key=(nm.split('(sclg::GemmK')[0].split('(unsigned short const*')[0].replace('void (anonymous namespace)::','')[-60:], r.get('Grid_Size_X', r.get('Grid_Size','')), r.get('Grid_Size_Z',''))
     d=float(r['End_Timestamp'])-float(r['Start_Timestamp'])
     agg[key][0]+=1; agg[key][1]+=d
 P("--- GEMM launches by (kernel, grid x, grid z): calls/step, avg us, ms/step")

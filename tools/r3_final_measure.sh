@@ -29,7 +29,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != name: continue
         k = r["Kernel_Name"]
-        fam = "gemm" if "scl_gemm" in k else ("adamw" if "adamw" in k else ("ln_bwd" if "ln_bwd" in k else ("attn_bwd" if "attn_bwd" in k else ("fir" if "fir_kernel" in k else None))))
+        fam = "gemm" if ("scl_gemm" in k or "posconv_mfma" in k) else ("adamw" if "adamw" in k else ("ln_bwd" if "ln_bwd" in k else ("attn_bwd" if "attn_bwd" in k else ("fir" if "fir_kernel" in k else None))))
         if fam is None: continue
         agg[fam][0] += float(r["Counter_Value"]); agg[fam][1] += 1
     out[name] = {k: [v[0] / max(v[1], 1), v[1]] for k, v in agg.items()}   # mean KiB per launch, launches
