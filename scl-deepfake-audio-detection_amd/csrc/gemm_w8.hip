@@ -353,6 +353,11 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
     w8_stamp(d, 0, lane, wave);
+    // experiment (SCL_W8_STAGGER, units of s_sleep 127 ~ 3.9 us): the first-round blocks of every other XCD start late, so that the
+    // epilogues of the two halves of the chip do not hit HBM at the same moment for the rest of the launch
+    if ((d.debug >> 8) && (blockIdx.x & 1) && blockIdx.x < 256 && blockIdx.z == 0) {
+        for (int i = 0; i < (d.debug >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn, d.group_m);
@@ -650,6 +655,11 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // read instructions per fragment)
     const char* me = getenv("SCL_W8_MODE");
     int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
+    {
+        const char* sg = getenv("SCL_W8_STAGGER");
+        const int stg = sg ? atoi(sg) : 0;
+        if (stg > 0 && plan.tiles > 256 && zdim == 1) k.debug |= (stg & 0xFF) << 8;
+    }
     // persistent blocks (w8p): SCL_GEMM_PERSIST = 0 (default) never, 1 when the launch has more than one round of tiles, 8 .. 256 =
     // that many resident blocks whenever the kernel is legal (tests: several tiles per block on small problems).  Opt-in: measured
     // on MI355X against one-tile blocks (tools/persist_probe.py, profiles/r3_gemm_persistent_vs_one_tile.txt) it is equal within
