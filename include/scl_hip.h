@@ -95,8 +95,9 @@ typedef struct SclOperand {
 #define SCL_GEMM_NO_X2    0x10000000  /* never that kernel (testing / A-B comparison) */
 #define SCL_GEMM_AB_F32   0x40000000  /* A and B are f32 (strides in f32 elements, multiples of 4): exact-fp32 MFMA kernel (gemm_f32.hip) */
 #define SCL_GEMM_STAMPS   0x20000000  /* diagnostic: the wide kernels record per-block time stamps (scl_debug_gemm_stamps) */
-#define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01) */
-#define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT */
+#define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01), 5 gelu(erf) with C2 = gelu'(pre-activation) instead
+                                       * of the pre-activation (the backward multiplies by it: RACT 4) */
+#define SCL_GEMM_RMODE_SHIFT 12       /* 0 none, 1 C += R, 2 C *= act'(R) with act = RACT (RACT 4: C *= R, R holds the derivative) */
 #define SCL_GEMM_RACT_SHIFT  16
 
 typedef struct SclGemmDesc {

@@ -83,10 +83,35 @@ __device__ __forceinline__ void gelu_grad2(float& a, float& b) {      // a, b :=
     const f32x2 y = __builtin_elementwise_fma(x * 0.39894228040143268f, e, cdf);
     a = y[0]; b = y[1];
 }
-// activation ids shared with SCL_GEMM_ACT_SHIFT: 0 none, 1 gelu, 2 relu, 3 leaky_relu(0.01)
+// GELU and its derivative from ONE evaluation of the shared parts (activation id 5: the forward epilogue stores gelu'(pre-activation) as
+// its second output, so the data-gradient epilogue that consumes it multiplies by a stored number instead of re-evaluating erf and exp
+// per element): value = gelu_f's x * cdf, derivative = gelu_grad_f's fma — scalar and packed forms agree to the last bit.
+__device__ __forceinline__ float gelu_grad_from_parts(float x, float cdf, float e) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(x * 0.39894228040143268f, e, cdf);
+}
+__device__ __forceinline__ void gelu_both_f(float x, float& y, float& dy) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    dy = gelu_grad_from_parts(x, cdf, e);
+    y = x * cdf;
+}
+__device__ __forceinline__ f32x2 gelu_grad_from_parts2(f32x2 x, f32x2 cdf, f32x2 e) {
+#pragma clang fp contract(off)
+    return __builtin_elementwise_fma(x * 0.39894228040143268f, e, cdf);
+}
+__device__ __forceinline__ void gelu_both2(float& a, float& b, float& da, float& db) {      // a, b := gelu; da, db := gelu'
+    f32x2 cdf, e;
+    const f32x2 x = {a, b};
+    gelu_parts2(x, cdf, e);
+    const f32x2 g = gelu_grad_from_parts2(x, cdf, e);
+    da = g[0]; db = g[1];
+    a = a * cdf[0]; b = b * cdf[1];
+}
+// activation ids shared with SCL_GEMM_ACT_SHIFT: 0 none, 1 gelu, 2 relu, 3 leaky_relu(0.01), 5 gelu with C2 = gelu'(pre-activation)
 __device__ __forceinline__ float act_f(int id, float x) {
     switch (id) {
-        case 1: return gelu_f(x);
+        case 1: case 5: return gelu_f(x);
         case 2: return x > 0.f ? x : 0.f;
         case 3: return x > 0.f ? x : 0.01f * x;
         default: return x;
@@ -97,6 +122,7 @@ __device__ __forceinline__ float act_grad_f(int id, float x) {
         case 1: return gelu_grad_f(x);
         case 2: return x > 0.f ? 1.f : 0.f;
         case 3: return x > 0.f ? 1.f : 0.01f;
+        case 4: return x;      // RACT 4: R already holds the derivative (written by an ACT 5 forward epilogue)
         default: return 1.f;
     }
 }

@@ -896,11 +896,13 @@ __global__ __launch_bounds__(256) void scl_gemm_finish_kernel(const GemmK d, con
             const float4 bb = *reinterpret_cast<const float4*>(bias + col);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
         }
+        float c2v[4] = {v[0], v[1], v[2], v[3]};
+        if (act == 5) { gelu_both_f(v[0], v[0], c2v[0]); gelu_both_f(v[1], v[1], c2v[1]); gelu_both_f(v[2], v[2], c2v[2]); gelu_both_f(v[3], v[3], c2v[3]); }
         if (flags & SCL_GEMM_HAS_C2) {
-            if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
-            else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(c2v[0], c2v[1], c2v[2], c2v[3]);
+            else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(c2v[0], c2v[1]), pack_bf2(c2v[2], c2v[3]));
         }
-        if (act) { v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]); }
+        if (act && act != 5) { v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]); }
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (rmode) {
             if (r_f32) {

@@ -120,11 +120,13 @@ static __device__ __noinline__ void epi_scalar(EpiArgs d, float t, long long o, 
     const int flags = d.flags;
     const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF, rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF, ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
     if (flags & SCL_GEMM_HAS_BIAS) t += bias[col];
+    float c2v = t;
+    if (act == 5) gelu_both_f(t, t, c2v);
     if (flags & SCL_GEMM_HAS_C2) {
-        if (flags & SCL_GEMM_C2_F32) reinterpret_cast<float*>(d.C2)[o] = t;
-        else reinterpret_cast<bf16_t*>(d.C2)[o] = f2bf(t);
+        if (flags & SCL_GEMM_C2_F32) reinterpret_cast<float*>(d.C2)[o] = c2v;
+        else reinterpret_cast<bf16_t*>(d.C2)[o] = f2bf(c2v);
     }
-    t = act_f(act, t);
+    if (act != 5) t = act_f(act, t);
     float r = 0.f;
     if (rmode) r = (flags & SCL_GEMM_R_F32) ? reinterpret_cast<const float*>(d.R)[o] : bf2f(reinterpret_cast<const bf16_t*>(d.R)[o]);
     if (rmode == 2) t *= act_grad_f(ract, r);
@@ -168,11 +170,13 @@ __device__ __forceinline__ void gemm_epilogue_blk(const GemmK& d, f32x4 (&acc)[N
                     const float4 bb = *reinterpret_cast<const float4*>(bias + col);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                 }
+                float c2v[4] = {v[0], v[1], v[2], v[3]};
+                if (act == 5) { gelu_both_f(v[0], v[0], c2v[0]); gelu_both_f(v[1], v[1], c2v[1]); gelu_both_f(v[2], v[2], c2v[2]); gelu_both_f(v[3], v[3], c2v[3]); }
                 if (has_c2) {
-                    if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    if (c2_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C2) + off) = make_float4(c2v[0], c2v[1], c2v[2], c2v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.C2) + off) = make_uint2(pack_bf2(c2v[0], c2v[1]), pack_bf2(c2v[2], c2v[3]));
                 }
-                if (act) {
+                if (act && act != 5) {
                     v[0] = act_f(act, v[0]); v[1] = act_f(act, v[1]); v[2] = act_f(act, v[2]); v[3] = act_f(act, v[3]);
                 }
                 float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
@@ -186,7 +190,9 @@ __device__ __forceinline__ void gemm_epilogue_blk(const GemmK& d, f32x4 (&acc)[N
                         r2 = __uint_as_float(t.y << 16); r3 = __uint_as_float(t.y & 0xFFFF0000u);
                     }
                 }
-                if (rmode == 2) {
+                if (rmode == 2 && ract == 4) {
+                    v[0] *= r0; v[1] *= r1; v[2] *= r2; v[3] *= r3;
+                } else if (rmode == 2) {
                     v[0] *= act_grad_f(ract, r0); v[1] *= act_grad_f(ract, r1); v[2] *= act_grad_f(ract, r2); v[3] *= act_grad_f(ract, r3);
                 }
                 if (drop) {

@@ -29,6 +29,40 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
     const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
     const int g = lane >> 4, lc = lane & 15;
+    const int c = lane & 7, rsub = lane >> 3;
+    const int col = nbase + 8 * c;
+    const bool colv = d.vec_ok && col + 8 <= d.N;
+    // The R operand (activation-gradient input / residual) comes in through LDS-DMA, several rows at a time: loads and stores share
+    // the in-order vmcnt counter, so a wait for row i's R vector requested after row i-1's stores also waits for those stores'
+    // acknowledgement — one memory round trip per row (tools/epilogue_probe.py: reading R cost 52 us per launch where a second
+    // store costs 14).  Staged this way the queue is drained once per batch, and the loop stays rolled (the kernels are 44 KB of
+    // code: unrolling the epilogue to keep R in registers slowed every variant, R or not, by 20-36 us).  bf16 R: batches of four
+    // rows in the wave's 4 KiB above the transposition blocks.  f32 R (twice the bytes): rows 0-1 and 2-3 there, rows 4-7 in the
+    // first half of the wave's own transposition block, whose rows have been consumed by then.
+    // The FIRST batch is requested before the accumulators are parked in LDS: its round trip runs under those ds_writes.
+    const bool r_dma = rmode && d.vec_ok && !(d.debug & 2) && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
+    __amdgpu_buffer_rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(r_dma ? d.R : d.C));
+    auto r_issue = [&](int i) {
+        const int nrow = r_f32 ? (i == 4 ? 4 : 2) : 4;
+        char* dst = (r_f32 && i == 4) ? wlds : wextra;
+        for (int u = 0; u < nrow; ++u) {
+            const int row2 = mbase + 8 * (i + u) + rsub;
+            unsigned offb = OOB;
+            if (i + u < 2 * nmt && row2 < mlimit && colv) {
+                const unsigned q2 = udiv_magic((unsigned)row2, d.c_magic, d.c_shift);
+                const long long o2 = cbase + (long long)q2 * d.c_rbstride + (long long)((unsigned)row2 - q2 * d.c_rpb) * d.ldc + col;
+                offb = (unsigned)(o2 << (r_f32 ? 2 : 1));
+            }
+            if (r_f32) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048), 16, offb, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048 + 1024), 16, offb == OOB ? OOB : offb + 16, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 1024), 16, offb, 0, 0, 0);
+            }
+        }
+        return dst;
+    };
+    if (r_dma) r_issue(0);
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
         if (mt < nmt) {
@@ -37,9 +71,6 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
                 *reinterpret_cast<f32x4*>(wlds + mt * blk_stride + lc * 256 + (((nt * 4 + g) ^ lc) << 4)) = acc[mt][nt];
         }
     }
-    const int c = lane & 7, rsub = lane >> 3;
-    const int col = nbase + 8 * c;
-    const bool colv = d.vec_ok && col + 8 <= d.N;
     float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (has_bias && colv) {
         const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
@@ -51,37 +82,12 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
 #pragma unroll
         for (int j = 0; j < 8; ++j) cs[j] = cs_carry[j];
     }
-    // The R operand (activation-gradient input / residual) comes in through LDS-DMA, several rows at a time: loads and stores share
-    // the in-order vmcnt counter, so a wait for row i's R vector requested after row i-1's stores also waits for those stores'
-    // acknowledgement — one memory round trip per row (tools/epilogue_probe.py: reading R cost 52 us per launch where a second
-    // store costs 14).  Staged this way the queue is drained once per batch, and the loop stays rolled (the kernels are 44 KB of
-    // code: unrolling the epilogue to keep R in registers slowed every variant, R or not, by 20-36 us).  bf16 R: batches of four
-    // rows in the wave's 4 KiB above the transposition blocks.  f32 R (twice the bytes): rows 0-1 and 2-3 there, rows 4-7 in the
-    // first half of the wave's own transposition block, whose rows have been consumed by then.
-    const bool r_dma = rmode && d.vec_ok && !(d.debug & 2) && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7) && !((unsigned long long)d.R & 15);
-    __amdgpu_buffer_rsrc_t r_rsrc = make_rsrc(reinterpret_cast<const char*>(r_dma ? d.R : d.C));
     const char* rstage = wextra;
     for (int i = 0; i < 2 * nmt; ++i) {
         const bool issue = r_dma && (r_f32 ? (i == 0 || i == 2 || i == 4) : (i & 3) == 0);
         if (issue) {
-            const int nrow = r_f32 ? (i == 4 ? 4 : 2) : 4;
-            char* dst = (r_f32 && i == 4) ? wlds : wextra;
             if (r_f32 && i == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of rows 0-31 have returned
-            for (int u = 0; u < nrow; ++u) {
-                const int row2 = mbase + 8 * (i + u) + rsub;
-                unsigned offb = OOB;
-                if (i + u < 2 * nmt && row2 < mlimit && colv) {
-                    const unsigned q2 = udiv_magic((unsigned)row2, d.c_magic, d.c_shift);
-                    const long long o2 = cbase + (long long)q2 * d.c_rbstride + (long long)((unsigned)row2 - q2 * d.c_rpb) * d.ldc + col;
-                    offb = (unsigned)(o2 << (r_f32 ? 2 : 1));
-                }
-                if (r_f32) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048), 16, offb, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 2048 + 1024), 16, offb == OOB ? OOB : offb + 16, 0, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + u * 1024), 16, offb, 0, 0, 0);
-                }
-            }
+            char* dst = i == 0 ? wextra : r_issue(i);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             rstage = dst - (r_f32 ? i * 2048 : i * 1024);      // row-batch i lives at rstage + i * (2048 | 1024)
         }
@@ -99,18 +105,24 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += bb[j];
             }
+            float w[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};      // second output: the pre-activation, or (ACT 5) gelu' of it
+            if (act == 5) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) gelu_both2(v[j], v[j + 1], w[j], w[j + 1]);
+            }
             if (has_c2) {
                 if (c2_f32) {
                     float* p = reinterpret_cast<float*>(d.C2) + off;
-                    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<float4*>(p) = make_float4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<float4*>(p + 4) = make_float4(w[4], w[5], w[6], w[7]);
                 } else {
                     bf16_t* p = reinterpret_cast<bf16_t*>(d.C2) + off;
-                    if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                    else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
+                    if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+                    else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7])); }
                 }
             }
-            if (act == 1) {
+            if (act == 5) {
+            } else if (act == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) gelu2(v[j], v[j + 1]);
             } else if (act) {
@@ -138,6 +150,9 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
             if (rmode == 2 && ract == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) { gelu_grad2(rr[j], rr[j + 1]); v[j] *= rr[j]; v[j + 1] *= rr[j + 1]; }
+            } else if (rmode == 2 && ract == 4) {      // R holds the derivative itself (ACT 5 forward): no per-element switch
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= rr[j];
             } else if (rmode == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= act_grad_f(ract, rr[j]);

@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import ops
-from .lib import ACT_GELU, FLAT
+from .lib import ACT_GELU, ACT_GELU_DC2, FLAT, RACT_STORED
 from .ops import Op
 
 # fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
@@ -27,6 +27,9 @@ WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "0") != "0"
 BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
 POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
+# fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
+# epilogue multiplies by the stored number; 0 = store the pre-activation and re-evaluate gelu' in the backward epilogue (rounds 1-2)
+GELU_DC2 = os.environ.get("SCL_GELU_DC2", "1") != "0"
 
 
 class W2VConfig:
@@ -399,7 +402,7 @@ class Encoder:
             ops.layernorm_fwd(d["x1"][n], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"),
                               d["h2"][n], None, d["m2"][n], d["r2"][n], M, E)
             dsc = ops.gemm(Op(d["h2"][n], E), self.W(pn + "fc1.weight", E), d["a"][n], M, Fd, E, bias=self.b(pn + "fc1.bias"),
-                           act=ACT_GELU, c2=d["f"][n], drop_p=p_act, drop_seed=sseed(n, self.SITE_2))                         # dropout2 (activation)
+                           act=ACT_GELU_DC2 if GELU_DC2 else ACT_GELU, c2=d["f"][n], drop_p=p_act, drop_seed=sseed(n, self.SITE_2))                         # dropout2 (activation)
             if p_act > 0 and recording:
                 self._slot(slots, dsc, None, n, self.SITE_2)
             dsc = ops.gemm(Op(d["a"][n], Fd), self.W(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"),
@@ -529,7 +532,7 @@ class Encoder:
             with self._side():
                 self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
             # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
-            fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
+            fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=RACT_STORED if GELU_DC2 else ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
             nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
             if nrows * Fd > d["cs_fused"].numel():
                 nrows = 0

@@ -58,6 +58,8 @@ GEMM_NO_X2 = 0x10000000
 GEMM_AB_F32 = 0x40000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
+ACT_GELU_DC2 = 5      # gelu whose second output is gelu'(pre-activation); the matching backward epilogue is rmode 2 with ract = RACT_STORED
+RACT_STORED = 4
 KID_GEMM = 0
 KID_AUG = 1
 KID_GEMM_F32 = 2

@@ -340,6 +340,8 @@ def test_two_blocks_per_cu_kernel_epilogues_and_conv_rows(dev):
         (dict(R=Rb, rmode=2, ract=1), torch.bfloat16, False),                # fc2 data gradient
         (dict(bias=bias, R=Rf, rmode=1), torch.float32, False),              # out-proj / fc2 forward: f32 residual stream
         (dict(bias=bias, act=3, drop_p=0.5, drop_seed=1234), torch.bfloat16, True),
+        (dict(bias=bias, act=5, drop_p=0.25, drop_seed=77), torch.bfloat16, True),   # fc1 forward, round 3: second output = gelu'(pre-activation)
+        (dict(R=Rb, rmode=2, ract=4), torch.bfloat16, False),                # fc2 data gradient, round 3: x stored derivative
     ]
     for kw, cdt, c2 in cases:
         for b_t, opB in ((False, ops.Op(W, K)), (True, ops.Op(Wt, N))):
@@ -412,6 +414,8 @@ def test_persistent_wide_kernel_epilogues_column_sums_and_conv_rows(dev, monkeyp
         (dict(bias=bias, R=Rb, rmode=1), torch.float32, False),
         (dict(R=Rf, rmode=2, ract=1), torch.bfloat16, False),
         (dict(bias=bias, act=3, drop_p=0.5, drop_seed=1234), torch.bfloat16, True),
+        (dict(bias=bias, act=5), torch.bfloat16, True),
+        (dict(R=Rb, rmode=2, ract=4), torch.bfloat16, False),
     ]
     for kw, cdt, c2 in cases:
         for b_t, opB in ((False, ops.Op(W, K)), (True, ops.Op(Wt, N))):
@@ -616,3 +620,42 @@ def test_auto_split_k_with_fused_finish_matches_the_single_launch(dev, case, mon
         tol = 2e-5 * scale if case in ("bias_resid_f32", "ragged") else scale * 2 ** -7
         assert (a - b).abs().max().item() <= tol, (case, (a - b).abs().max().item(), scale)
         assert ((a - b).abs() > 1e-6 * scale).float().mean().item() < 0.5
+
+
+def test_gelu_with_stored_derivative_epilogues(dev):
+    """ACT 5 (forward: C = gelu(x + b), C2 = gelu'(x + b)) and RMODE 2 / RACT 4 (backward: C = acc x R, R = the stored derivative) against
+    torch: the GELU output must equal the ACT 1 epilogue's bit for bit, the stored derivative must be torch's erf-GELU derivative of the
+    f32 pre-activation within bf16 rounding, and the backward product must equal the plain GEMM times R rounded once; 128 x 128 tiles,
+    wide tiles and the split-K finishing pass all agree bit for bit."""
+    M, N, K = 2 * 208 + 33, 512, 256
+    A = _rand((M, K), dev, 201, 0.5); W = _rand((N, K), dev, 202, 0.1)
+    bias = torch.randn(N, device=dev)
+    pre = A.float() @ W.float().t() + bias
+    outs = {}
+    for name, sel in (("t128", dict(no_w8=True, no_p8=True, no_big=True, no_x2=True)), ("w8", dict(force_w8=True))):
+        C1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev); P1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(W, K), C1, M, N, K, bias=bias, act=1, c2=P1, **sel)
+        C5 = torch.empty(M, N, dtype=torch.bfloat16, device=dev); D5 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(W, K), C5, M, N, K, bias=bias, act=5, c2=D5, **sel)
+        assert torch.equal(C1, C5)
+        outs[name] = (C5, D5)
+    assert torch.equal(outs["t128"][0], outs["w8"][0]) and torch.equal(outs["t128"][1], outs["w8"][1])
+    x = pre.double()
+    ref_d = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    _close(outs["w8"][1], ref_d, 6e-3, "stored gelu'")
+    # backward: dY @ W2 (x) stored derivative
+    dY = _rand((M, K), dev, 203, 0.5)
+    D = outs["w8"][1]
+    plain = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(ops.Op(dY, K), ops.Op(W, K), plain, M, N, K, no_w8=True, no_p8=True, no_big=True, no_x2=True)
+    want = (plain * D.float()).to(torch.bfloat16)
+    for sel in (dict(no_w8=True, no_p8=True, no_big=True, no_x2=True), dict(force_w8=True)):
+        G = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(dY, K), ops.Op(W, K), G, M, N, K, R=D, rmode=2, ract=4, **sel)
+        assert torch.equal(G, want)
+    slabs = torch.empty(2, M, N, device=dev)
+    ops.gemm(ops.Op(dY, K), ops.Op(W, K), slabs, M, N, K, splitk=2, c_split_stride=M * N, no_w8=True, no_p8=True, no_big=True, no_x2=True)
+    G = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    dsc = ops._gemm_desc(ops.Op(dY, K), ops.Op(W, K), G, M, N, K, R=D, rmode=2, ract=4)
+    ops._call("scl_gemm_splitk_finish", ops.ctypes.byref(dsc), ops._ptr(slabs), 2, M * N, ops._stream(), keep=dsc)
+    assert torch.equal(G, ((slabs[0] + slabs[1]) * D.float()).to(torch.bfloat16))
