@@ -113,7 +113,18 @@ __global__ __launch_bounds__(512, 4) void posconv_mfma_kernel(const bf16_t* __re
     else pc_loop<3>(acc, smem, rw, voffw, K, 16 * wm, wn, lane, wave);              // row tiles wm, wm + 4, wm + 8
 
     // ---- epilogue through LDS: f32 [208 rows][64 columns], 16-byte chunks XOR-swizzled with row & 15 (as gemm_w8_epi.h), then whole
-    // 256-byte rows per 16 lanes
+    // 256-byte rows per 16 lanes.  The residual values of all seven passes are requested first: their round trip runs under the
+    // barriers and the LDS transposition instead of once per pass.
+    constexpr int PC_PASSES = (16 * PC_TILES) / 32 + 1;
+    const int ch = tid & 15;
+    const int col = g * PC_CG + 4 * ch;
+    float4 rres[PC_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PC_PASSES; ++ps) {
+        const int row = 32 * ps + (tid >> 4);
+        rres[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < T) rres[ps] = *reinterpret_cast<const float4*>(R + ((long long)b * T + row) * E + col);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
@@ -130,12 +141,10 @@ __global__ __launch_bounds__(512, 4) void posconv_mfma_kernel(const bf16_t* __re
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int ch = tid & 15;
-    const int col = g * PC_CG + 4 * ch;
     float bb[4] = {0.f, 0.f, 0.f, 0.f};
     if (FWD) { const float4 t4 = *reinterpret_cast<const float4*>(bias + col); bb[0] = t4.x; bb[1] = t4.y; bb[2] = t4.z; bb[3] = t4.w; }
 #pragma unroll
-    for (int ps = 0; ps < (16 * PC_TILES) / 32 + 1; ++ps) {
+    for (int ps = 0; ps < PC_PASSES; ++ps) {
         const int row = 32 * ps + (tid >> 4);
         if (row < T) {
             // the GEMM epilogues evaluate gelu(x) = x * cdf and the residual add in separate basic blocks (run-time flags): no FMA
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(512, 4) void posconv_mfma_kernel(const bf16_t* __re
 #pragma clang fp contract(off)
             const f32x4 a = *reinterpret_cast<const f32x4*>(smem + row * 256 + ((ch ^ (row & 15)) << 4));
             const long long off = ((long long)b * T + row) * E + col;
-            const float4 rr = *reinterpret_cast<const float4*>(R + off);
+            const float4 rr = rres[ps];
             float v[4] = {1.0f * a[0], 1.0f * a[1], 1.0f * a[2], 1.0f * a[3]};
             if (FWD) {
 #pragma unroll
