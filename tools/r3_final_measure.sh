@@ -46,7 +46,6 @@ rm -rf gpurun_out/prof_aasist
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_aasist -o bench -- python3 bench.py --no-cpu-baseline --model wav2vec2_aasist --batch 64 --rawboost 0 --steps 4 --warmup 2 > gpurun_out/prof_aasist.log 2>&1
 find gpurun_out/prof_aasist -name "*kernel_stats.csv" -exec cp {} gpurun_out/r3_bench_wav2vec2_aasist_b64_kernel_stats.csv \;
 rm -rf gpurun_out/prof_aasist
-python3 tools/x2_probe.py > gpurun_out/r3_gemm_x2_vs_wide.txt 2>&1
-python3 tools/x2_probe.py 6368 >> gpurun_out/r3_gemm_x2_vs_wide.txt 2>&1
-python3 tools/fir_probe.py > gpurun_out/r3_fir_probe.txt 2>&1
+python3 tools/attn_probe.py 64 32 2>&1 | grep -v amdgpu > gpurun_out/r3_attn_probe.txt
+python3 tools/posconv_probe.py 2>&1 | grep -v amdgpu > gpurun_out/r3_posconv_probe.txt
 for f in gpurun_out/r3_bench_default.json gpurun_out/r3_bench_b32_norawboost.json gpurun_out/r3_bench_wav2vec2_aasist_b64.json gpurun_out/r3_bench_wav2vec2_aasist_b32.json gpurun_out/r3_bench_wav2vec2_resnet_nll_b32.json; do echo $f; cut -c1-330 $f; echo; done
