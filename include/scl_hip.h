@@ -146,6 +146,11 @@ int scl_gemm_colsum_rows(const SclGemmDesc* desc);
  * (bias / c2 unused).  C, R: f32 [B * T][G * Cg].  Bit-identical to the same contraction through scl_gemm_bf16.
  * scl_posconv_supported: 1 when the shape can take this kernel (Cg = 64, T <= 208, even K <= 128), else the caller uses the GEMM. */
 int scl_posconv_supported(int T, int K, int G, int Cg);
+/* Weight gradient of the same convolution: dw[g][o][tap * Cg + c] = sum_b sum_t dypad[b][dy_row0 + t][g * Cg + o] * xpad[b][t + tap][g * Cg + c]
+ * (f32, overwritten; both inputs bf16 [B][T + K][G * Cg]; rows dy_row0 .. dy_row0 + T - 1 of dypad hold the output gradient).  One
+ * workgroup per (group, 8 taps) walks the utterances with the accumulators resident.  supported: Cg = 64, T <= 224, K % 8 == 0. */
+int scl_posconv_wgrad_supported(int T, int K, int G, int Cg);
+int scl_posconv_wgrad(const void* dypad, int dy_row0, const void* xpad, float* dw, int B, int T, int K, int G, int Cg, void* stream);
 int scl_posconv_mfma(const void* xpad, const void* w, float* C, const float* bias, void* c2, const float* R, int B, int T, int K, int G,
                      int Cg, int fwd, void* stream);
 

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
                 fa[i] = AT ? frag_t_raw(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
                 fb[i] = BT ? frag_t_raw(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
             }
-            if (AT || BT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (AT || BT) lds_wait_frags(fa, fb);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
                 fa[i] = AT ? frag_t_raw(tA + (wr >> 1) * TILE_BYTES, (wr & 1) * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
                 fb[i] = BT ? frag_t_raw(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
             }
-            if (AT || BT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (AT || BT) lds_wait_frags(fa, fb);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -113,6 +113,14 @@ __device__ __forceinline__ bf16x8 frag_t_raw(const char* tile, int colblk, int k
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// The wait that belongs to frag_t_raw reads.  A bare `asm volatile("s_waitcnt lgkmcnt(0)")` orders memory operations only: an MFMA has
+// none, so the scheduler may lift one ABOVE the wait (found in the ISA of scl_gemm_dma_kernel<*, *>: one MFMA of the second k sub-step
+// read a fragment ~25 instructions after its ds_read_b64_tr_b16 and before the wait — right almost always, a stale operand when LDS is
+// slow).  Here the fragments are read-write operands of the wait, so every use of them depends on it.
+__device__ __forceinline__ void lds_wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+}
+
 // element-wise epilogue for edge tiles / unaligned outputs (rare path, kept out of line)
 struct EpiArgs { void* C; void* C2; const void* R; int N, flags; unsigned drop_seed; float drop_p; };
 static __device__ __noinline__ void epi_scalar(EpiArgs d, float t, long long o, int col, const float* bias) {

@@ -166,10 +166,145 @@ __global__ __launch_bounds__(512, 4) void posconv_mfma_kernel(const bf16_t* __re
     }
 }
 
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------
+// dW[g][o][tap * 64 + c] = sum_b sum_t dY[b][t][g*64 + o] * X[b][t + tap][g*64 + c].  As a GEMM (both operands transposed, M = 64,
+// N = 8192, K = B*T rows, 16 groups) it ran on the 128 x 128 kernel at ~540 TFLOP/s (400 us), re-fetching the X rows once per tap.
+// Here a workgroup owns (group, block of 8 taps), one wave per tap, and walks the utterances: dY [T][64] and the 8-tap window of
+// X [T + 7][64] are staged per utterance (double-buffered LDS-DMA, one barrier per utterance), every wave keeps its [64 o][64 c] block
+// in 64 accumulator registers across all utterances and writes it once.  Both operands are read with ds_read_b64_tr_b16 from
+// [t][channel] images (32-byte chunk index ^= bits 1 and 3 of the row: the 8 rows of a half-wave read land in distinct bank groups).
+constexpr int PW_TAPS = 8;
+constexpr int PW_TROWS = 224;                        // 7 k steps of 32 rows: T <= 224, rows >= T are zero-filled
+constexpr int PW_XROWS = PW_TROWS + PW_TAPS;         // 232
+constexpr int PW_BUF = (PW_TROWS + PW_XROWS) * 128;  // 58368 B per utterance
+constexpr int PW_LDS = 2 * PW_BUF;                   // 116736 B
+
+__device__ __forceinline__ int pw_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+// the two 64-bit halves of the fragment [16 channels (block cb)][32 rows t0 .. t0+31] of a [row][64 ch] image as an MFMA operand
+// (lane: channel lane & 15, 8 consecutive rows).  Inline asm (see frag_t_raw): the builtin would be fenced with s_waitcnt vmcnt(0)
+// against the LDS-DMA of the next utterance.  The reads are asynchronous and the compiler does not know it: the caller passes every
+// half through PW_WAIT_FRAGS (s_waitcnt lgkmcnt(0) with the halves as read-write operands) before anything may copy or use them.
+__device__ __forceinline__ void pw_read(const char* img, int t0, int cb, int lane, s16x4& lo, s16x4& hi) {
+    const int i = lane & 15, g = lane >> 4;
+    const int ra = t0 + 8 * g + (i >> 2), rb = ra + 4;
+    const unsigned aa = (unsigned)(uintptr_t)(lds_void*)(img + ra * 128 + ((cb ^ pw_f(ra)) << 5) + ((i & 3) << 3));
+    const unsigned ab = (unsigned)(uintptr_t)(lds_void*)(img + rb * 128 + ((cb ^ pw_f(rb)) << 5) + ((i & 3) << 3));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(aa) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ab) : "memory");
+}
+#define PW_WAIT_FRAGS(A, B, C, D)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), \
+                                          "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3])  \
+                 :: "memory")
+__device__ __forceinline__ bf16x8 pw_join(s16x4 lo, s16x4 hi) {
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 2) void posconv_wgrad_kernel(const bf16_t* __restrict__ dypad, const bf16_t* __restrict__ xpad, float* __restrict__ dw,
+                                                               int Bn, int T, int K, int G, int dy_row0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntb = K / PW_TAPS;
+    const int g = blockIdx.x / ntb, tb = blockIdx.x % ntb;
+    const int E = G * PC_CG, Tp = T + K;
+    const int tap = tb * PW_TAPS + wave;
+    // per-lane source offsets of the staging pieces (8 rows x 128 B each): dest chunk q = lane & 7 of row r holds the logical 16-byte
+    // chunk (((q >> 1) ^ f(r)) * 2 + (q & 1))
+    const int q = lane & 7, rl = lane >> 3;
+    constexpr int NPIECE = (PW_TROWS + PW_XROWS) / 8;      // 57
+    unsigned voff[(NPIECE + 7) / 8];
+    bool isdy[(NPIECE + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
+        const int p = wave + 8 * i;
+        voff[i] = OOB; isdy[i] = p < PW_TROWS / 8;
+        if (p < NPIECE) {
+            const int r = (p < PW_TROWS / 8 ? 8 * p : 8 * (p - PW_TROWS / 8)) + rl;      // row inside its image
+            const int ch = (((q >> 1) ^ pw_f(r)) << 1) | (q & 1);
+            if (p < PW_TROWS / 8) { if (r < T) voff[i] = (unsigned)(dy_row0 + r) * (unsigned)(E * 2) + (unsigned)(ch << 4); }
+            else { if (tb * PW_TAPS + r < Tp) voff[i] = (unsigned)(tb * PW_TAPS + r) * (unsigned)(E * 2) + (unsigned)(ch << 4); }
+        }
+    }
+    const long long ubytes = (long long)Tp * E * 2;      // one utterance of either padded tensor
+    const char* dyb = reinterpret_cast<const char*>(dypad + g * PC_CG);
+    const char* xb = reinterpret_cast<const char*>(xpad + g * PC_CG);
+    auto stage = [&](int b, char* buf) {
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dyb + b * ubytes), rx = make_rsrc(xb + b * ubytes);
+#pragma unroll
+        for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
+            const int p = wave + 8 * i;
+            if (p < NPIECE) __builtin_amdgcn_raw_ptr_buffer_load_lds(isdy[i] ? rdy : rx, (lds_void*)(buf + p * 1024), 16, voff[i], 0, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage(0, smem);
+    for (int b = 0; b < Bn; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of utterance b
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everyone's; everyone is past its reads of utterance b-1 (the other buffer)
+        char* buf = smem + (b & 1) * PW_BUF;
+        if (b + 1 < Bn) stage(b + 1, smem + ((b + 1) & 1) * PW_BUF);
+        const char* dyi = buf;
+        const char* xi = buf + PW_TROWS * 128;      // X rows tb*8 ..: this wave's tap reads row t + wave
+#pragma unroll
+        for (int ks = 0; ks < PW_TROWS / 32; ++ks) {
+            s16x4 alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw_read(dyi, 32 * ks, i, lane, alo[i], ahi[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw_read(xi, 32 * ks + wave, j, lane, blo[j], bhi[j]);
+            PW_WAIT_FRAGS(alo, ahi, blo, bhi);
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[i] = pw_join(alo[i], ahi[i]); fb[i] = pw_join(blo[i], bhi[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // lane holds dW[o = 16 i + (lane & 15)][c = 16 j + 4 (lane >> 4) .. + 3] of its tap
+    const int lc = lane & 15, gq = lane >> 4;
+    float* dst = dw + ((long long)g * PC_CG) * ((long long)K * PC_CG) + (long long)tap * PC_CG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(dst + (long long)(16 * i + lc) * (K * PC_CG) + 16 * j + 4 * gq) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+}
+
 }  // namespace
 
 extern "C" int scl_posconv_supported(int T, int K, int G, int Cg) {
     return (Cg == PC_CG && T >= 1 && T <= 16 * PC_TILES && K >= 2 && K <= 128 && (K & 1) == 0 && G >= 1) ? 1 : 0;
+}
+
+extern "C" int scl_posconv_wgrad_supported(int T, int K, int G, int Cg) {
+    return (Cg == PC_CG && T >= 1 && T <= PW_TROWS && K >= PW_TAPS && (K % PW_TAPS) == 0 && G >= 1) ? 1 : 0;
+}
+
+extern "C" int scl_posconv_wgrad(const void* dypad, int dy_row0, const void* xpad, float* dw, int B, int T, int K, int G, int Cg, void* stream) {
+    SCL_REQUIRE(dypad && xpad && dw && B > 0 && dy_row0 >= 0 && dy_row0 <= K, "posconv_wgrad: bad arguments");
+    SCL_REQUIRE(scl_posconv_wgrad_supported(T, K, G, Cg), "posconv_wgrad: needs 64 channels per group, T <= 224, K a multiple of 8 (got T=%d K=%d Cg=%d)", T, K, Cg);
+    SCL_REQUIRE(((uintptr_t)dypad & 15) == 0 && ((uintptr_t)xpad & 15) == 0 && ((uintptr_t)dw & 15) == 0, "posconv_wgrad: operands must be 16-byte aligned");
+    SCL_REQUIRE((long long)(T + K) * G * Cg * 2 < 0x7FFFFFFFll, "posconv_wgrad: utterance slab too large for 32-bit offsets");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)posconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SclProfScope prof(SCL_KID_GEMM, s, 2.0 * B * T * (double)Cg * K * Cg * G, true);
+    SCL_LAUNCH(posconv_wgrad_kernel, dim3((unsigned)(G * (K / PW_TAPS))), dim3(512), PW_LDS, s, (const bf16_t*)dypad, (const bf16_t*)xpad, dw, B, T, K, G,
+               dy_row0);
+    return scl_check_launch("scl_posconv_wgrad");
 }
 
 extern "C" int scl_posconv_mfma(const void* xpad, const void* w, float* C, const float* bias, void* c2, const float* R, int B, int T, int K,

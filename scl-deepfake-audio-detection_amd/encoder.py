@@ -630,9 +630,12 @@ class Encoder:
         ops.pad_rows(dx, d["dcpad"], B, T, E, T + K, pb, pre=d["pc_pre"], ract=ACT_GELU)
         ops.colsum_reduce(d["dcpad"], d["cs_part"], P.g(self.n("encoder.pos_conv.0.bias")), B * (T + K), E)
         dwf = d["dwf"]
-        self._wgrad(d, Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=pb * E),
-                    Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), dwf, Cg, K * Cg, M,
-                    nb2=G, c_bs2=Cg * K * Cg, ldc=K * Cg)
+        if POSCONV_MFMA and ops.posconv_wgrad_supported(T, K, G, Cg):      # accumulators resident over the utterances, one wave per tap
+            ops.posconv_wgrad(d["dcpad"], pb, d["xpad"], dwf, B, T, K, G, Cg)
+        else:
+            self._wgrad(d, Op(d["dcpad"], E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=pb * E),
+                        Op(d["xpad"], E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg), dwf, Cg, K * Cg, M,
+                        nb2=G, c_bs2=Cg * K * Cg, ldc=K * Cg)
         ops.posconv_weight_bwd(dwf, self.b("encoder.pos_conv.0.weight_v"), self.b("encoder.pos_conv.0.weight_g"), self.pos_norm,
                                self.ws_small, P.g(self.n("encoder.pos_conv.0.weight_v")), P.g(self.n("encoder.pos_conv.0.weight_g")),
                                E, Cg, K)

@@ -81,6 +81,8 @@ def _protos():
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
         "scl_posconv_supported": ([_i32, _i32, _i32, _i32], _i32),
+        "scl_posconv_wgrad_supported": ([_i32, _i32, _i32, _i32], _i32),
+        "scl_posconv_wgrad": ([_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_posconv_mfma": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_debug_gemm_stamps": ([_vp, _i32], _i32),
         "scl_debug_gemm_persistent_launches": ([], ctypes.c_longlong),

@@ -342,6 +342,15 @@ def posconv_mfma(xpad, w, C, R, B, T, K, G, Cg, bias=None, c2=None):
     return _call("scl_posconv_mfma", _p(xpad), _p(w), _p(C), _p(bias), _p(c2), _p(R), B, T, K, G, Cg, 1 if bias is not None else 0, _stream())
 
 
+def posconv_wgrad_supported(T, K, G, Cg):
+    return bool(L.load().scl_posconv_wgrad_supported(T, K, G, Cg))
+
+
+def posconv_wgrad(dypad, dy_row0, xpad, dw, B, T, K, G, Cg):
+    """dw[g][o][tap * Cg + c] (f32, overwritten) = sum over utterances and frames of dY x shifted X (csrc/posconv.hip)."""
+    return _call("scl_posconv_wgrad", _p(dypad), dy_row0, _p(xpad), _p(dw), B, T, K, G, Cg, _stream())
+
+
 def col2im(dcol, dz, B, Tin, Tout, C, k, s):
     _call("scl_col2im_bf16", _p(dcol), _p(dz), B, Tin, Tout, C, k, s, _stream())
 

@@ -396,3 +396,38 @@ def test_posconv_mfma_equals_the_grouped_gemm(dev, B, T, K, G):
         assert torch.equal(outs[i][0], outs[2 + i][0]), ("fwd" if i == 0 else "dgrad", (outs[i][0] - outs[2 + i][0]).abs().max().item())
     assert torch.equal(outs[0][1], outs[2][1])
     assert not ops.posconv_supported(209, 128, 16, 64) and not ops.posconv_supported(199, 128, 16, 32) and not ops.posconv_supported(199, 127, 16, 64)
+
+
+@pytest.mark.parametrize("B,T,K,G", [(5, 199, 128, 16), (2, 224, 128, 2), (3, 49, 128, 16), (1, 7, 16, 1), (3, 100, 32, 3)])
+def test_posconv_wgrad_equals_the_transposed_gemm(dev, B, T, K, G):
+    """csrc/posconv.hip's weight gradient (one wave per tap, accumulators resident over the utterances) against the same contraction
+    through scl_gemm_bf16 (both operands transposed, f32 output) and against torch in f64: the summation orders differ (utterance by
+    utterance here, one pass over all rows there), so 2e-5 of the largest entry; buffers are followed by NaN and the rows of the
+    gradient image outside [dy_row0, dy_row0 + T) hold NaN-free garbage that must not be read as gradient."""
+    from scl_amd.ops import Op
+    Cg = 64
+    E, M = G * Cg, B * T
+    pb = K // 2 - 1
+    gen = torch.Generator().manual_seed(7)
+    def nan_tail(t, extra=65536):
+        buf = torch.full((t.numel() + extra,), float("nan"), dtype=t.dtype, device=dev)
+        buf[:t.numel()] = t.reshape(-1).to(dev)
+        return buf
+    x = torch.zeros(B, T + K, E); x[:, K // 2: K // 2 + T] = torch.randn(B, T, E, generator=gen) * 0.5
+    dy = torch.zeros(B, T + K, E); dy[:, pb: pb + T] = torch.randn(B, T, E, generator=gen) * 0.1
+    xb, dyb = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+    xpad, dypad = nan_tail(xb), nan_tail(dyb)
+    assert ops.posconv_wgrad_supported(T, K, G, Cg)
+    got = torch.full((G, Cg, K * Cg), float("nan"), device=dev)
+    ops.posconv_wgrad(dypad, pb, xpad, got, B, T, K, G, Cg)
+    ref = torch.full((G, Cg, K * Cg), float("nan"), device=dev)
+    ops.gemm(Op(dypad, E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=pb * E), Op(xpad, E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg),
+             ref, Cg, K * Cg, M, a_t=True, b_t=True, nb2=G, c_bs2=Cg * K * Cg, ldc=K * Cg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale, ((got - ref).abs().max().item(), scale)
+    # torch, f64: dw[g][o][tap][c] = sum_{b,t} dy[b][pb+t][g,o] x[b][t+tap][g,c]
+    xd, dyd = xb.double().view(B, T + K, G, Cg), dyb.double().view(B, T + K, G, Cg)[:, pb: pb + T]
+    want = torch.stack([torch.einsum("btgo,btgc->goc", dyd, xd[:, tap: tap + T]) for tap in range(K)], dim=2).reshape(G, Cg, K * Cg)
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()

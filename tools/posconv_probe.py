@@ -24,6 +24,28 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 32]:
                      R=R, rmode=1, **kw)
         else:
             ops.posconv_mfma(xpad, w, C, R, B, T, K, G, Cg, bias=bias if fwd else None, c2=c2 if fwd else None)
+    dy = torch.zeros(B, T + K, E, device=dev); dy[:, K // 2 - 1: K // 2 - 1 + T] = 0.1 * torch.randn(B, T, E, device=dev)
+    dyp = torch.cat([dy.bfloat16().reshape(-1), torch.zeros(65536, dtype=torch.bfloat16, device=dev)])
+    dw = torch.empty(G, Cg, K * Cg, device=dev)
+    slab = torch.empty(4, G * Cg * K * Cg, device=dev)
+    def wg(kernel, i):
+        xpad = sets[i % 3][0]
+        if kernel == "gemm":
+            ops.gemm(Op(dyp, E, rpb=T, rbstride=(T + K) * E, bs2=Cg, offset=(K // 2 - 1) * E), Op(xpad, E, rpb=T, rbstride=(T + K) * E, cin=Cg, cout=E, bs2=Cg),
+                     dw, Cg, K * Cg, M, a_t=True, b_t=True, nb2=G, c_bs2=Cg * K * Cg, ldc=K * Cg)
+        else:
+            ops.posconv_wgrad(dyp, K // 2 - 1, xpad, dw, B, T, K, G, Cg)
+    res = {}
+    for rnd in range(3):
+        for kernel in ("gemm", "mfma"):
+            for i in range(3): wg(kernel, i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for i in range(20): wg(kernel, i)
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(kernel, []).append(e0.elapsed_time(e1) * 1000 / 20)
+    fl = 2.0 * M * Cg * K * Cg * G
+    print("B=%d weight gradient: " % B + " | ".join("%s %.1f us %.0f TF" % (k, sorted(v)[1], fl / sorted(v)[1] / 1e6) for k, v in res.items()), flush=True)
     for fwd in (True, False):
         res = {}
         for rnd in range(3):
