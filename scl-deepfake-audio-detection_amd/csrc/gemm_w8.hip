@@ -73,13 +73,20 @@ struct W8K {
         }
     }
     __device__ __forceinline__ static unsigned kstep(const OpK& o) { return o.cin == 64 ? o.cout_bytes : 128u; }
+    __device__ __forceinline__ void rows(const OpK&, int, int, int) {}
+    __device__ __forceinline__ void set_batched(bool) {}
+    __device__ __forceinline__ unsigned step(const OpK& o) const { return kstep(o); }
 };
 // transposed operand, 2 sub-tiles of [64 k rows][128 contiguous]: piece p -> sub-tile p >> 4, k rows 4*(p & 15) .. +3
 struct W8T {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned voff[4];
+    int col0_, collimit_;
+    bool batched;      // K rows are utterance-batched (rpb < K: conv weight gradients): no scalar K advance, offsets per K step (rows())
+    __device__ __forceinline__ void set_batched(bool b) { batched = b; }
     __device__ __forceinline__ void init(const OpK& o, const char* base, int col0, int collimit, int lane, int wave) {
         rsrc = make_rsrc(base);
+        col0_ = col0; collimit_ = collimit;
         const int s16 = lane & 15;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -88,6 +95,19 @@ struct W8T {
             const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
             const int col = col0 + (p >> 4) * 128 + 8 * ((((s16 >> 1) ^ sw) << 1) | (s16 & 1));
             voff[i] = col < collimit ? (unsigned)kr * o.ld_bytes + col_off(o, (unsigned)col) : OOB;
+        }
+    }
+    // batched rows: the offsets of the K step whose first row is krow (row_off divides by the rows per utterance); nothing otherwise
+    __device__ __forceinline__ void rows(const OpK& o, int krow, int lane, int wave) {
+        if (!batched) return;
+        const int s16 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            const int kr = 4 * (p & 15) + (lane >> 4);
+            const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
+            const int col = col0_ + (p >> 4) * 128 + 8 * ((((s16 >> 1) ^ sw) << 1) | (s16 & 1));
+            voff[i] = col < collimit_ ? row_off(o, (unsigned)(krow + kr)) + col_off(o, (unsigned)col) : OOB;
         }
     }
     template <int I0>
@@ -99,6 +119,7 @@ struct W8T {
         }
     }
     __device__ __forceinline__ static unsigned kstep(const OpK& o) { return 64u * o.ld_bytes; }
+    __device__ __forceinline__ unsigned step(const OpK& o) const { return batched ? 0u : kstep(o); }
 };
 template <bool T> struct W8Sel { typedef W8K type; };
 template <> struct W8Sel<true> { typedef W8T type; };
@@ -127,10 +148,10 @@ __device__ __forceinline__ bf16x8 w8_frag(const char* img, int gb, int ks, int l
 
 // main loop + epilogue of one wave whose row blocks are ab .. ab + 4 + NH - 1 of the A image
 template <bool AT, bool BT, int NH>
-__device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typename W8Sel<AT>::type& la, const typename W8Sel<BT>::type& lb,
+__device__ __forceinline__ void w8_body(const GemmK& d, char* smem, typename W8Sel<AT>::type& la, typename W8Sel<BT>::type& lb,
                                         int nk, unsigned soffA, unsigned soffB, int ab, int m0, int n0, int mlimit,
-                                        int z1, int z2, int ksplit, int lane, int wave, int wc) {
-    const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
+                                        int z1, int z2, int ksplit, int lane, int wave, int wc, int krow0) {
+    const unsigned stepA = la.step(d.A), stepB = lb.step(d.B);
     f32x4 acc[2][4][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -162,6 +183,7 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i][ks] = w8_frag<AT>(tA, ab + i, ks, lane);
         }
+        la.rows(d.A, krow0 + (kt + 2) * BK, lane, wave);      // utterance-batched K rows: this step's offsets (no-op otherwise)
         la.template issue2<0>(a_fill, wave, soffA, live2);
         W8_MFMA_PHASE(0, 0, fb0, 4)
         // ---- p1
@@ -178,6 +200,7 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, const typena
 #pragma unroll
             for (int i = 0; i < NH; ++i) fa[i][ks] = w8_frag<AT>(tA, ab + 4 + i, ks, lane);
         }
+        lb.rows(d.B, krow0 + (kt + 2) * BK, lane, wave);
         lb.template issue2<0>(tB, wave, soffB, live2);
         W8_MFMA_PHASE(1, 1, fb1, NH)
         // ---- p3
@@ -233,13 +256,18 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     typename W8Sel<BT>::type lb;
     la.init(d.A, Ab, m0, mlimit, lane, wave);
     lb.init(d.B, Bb, n0, d.N, lane, wave);
-    const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
+    la.set_batched(AT && (d.debug & 4));      // conv weight gradients: K rows batched per utterance (host: scl_gemm_w8_launch)
+    lb.set_batched(BT && (d.debug & 8));
+    const unsigned stepA = la.step(d.A), stepB = lb.step(d.B);
     unsigned soffA = (unsigned)kt0 * stepA, soffB = (unsigned)kt0 * stepB;
+    const int krow0 = kt0 * BK;
 
     // prologue: tiles 0 and 1 (16 pieces per wave)
+    la.rows(d.A, krow0, lane, wave); lb.rows(d.B, krow0, lane, wave);
     la.template issue2<0>(smem, wave, soffA, nk > 0); la.template issue2<2>(smem, wave, soffA, nk > 0);
     lb.template issue2<0>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0); lb.template issue2<2>(smem + W8_NA * W8_OPB, wave, soffB, nk > 0);
     soffA += stepA; soffB += stepB;
+    la.rows(d.A, krow0 + BK, lane, wave); lb.rows(d.B, krow0 + BK, lane, wave);
     la.template issue2<0>(smem + W8_OPB, wave, soffA, nk > 1); la.template issue2<2>(smem + W8_OPB, wave, soffA, nk > 1);
     lb.template issue2<0>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1); lb.template issue2<2>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -248,11 +276,11 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     if (wr == 1) __builtin_amdgcn_s_barrier();          // wave row 1 runs half a phase behind wave row 0
 
     if (RB0 == RB1) {
-        w8_body<AT, BT, RB0 - 4>(d, smem, la, lb, nk, soffA, soffB, wr * RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+        w8_body<AT, BT, RB0 - 4>(d, smem, la, lb, nk, soffA, soffB, wr * RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc, krow0);
     } else if (wr == 0) {
-        w8_body<AT, BT, RB0 - 4>(d, smem, la, lb, nk, soffA, soffB, 0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+        w8_body<AT, BT, RB0 - 4>(d, smem, la, lb, nk, soffA, soffB, 0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc, krow0);
     } else {
-        w8_body<AT, BT, RB1 - 4>(d, smem, la, lb, nk, soffA, soffB, RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
+        w8_body<AT, BT, RB1 - 4>(d, smem, la, lb, nk, soffA, soffB, RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc, krow0);
     }
 }
 
@@ -377,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     typename W8Sel<BT>::type lb;
     la.init(d.A, Ab, m0, mlimit, lane, wave);
     lb.init(d.B, Bb, n0, d.N, lane, wave);
+    la.set_batched(false); lb.set_batched(false);
     const unsigned stepA = W8Sel<AT>::type::kstep(d.A), stepB = W8Sel<BT>::type::kstep(d.B);
     unsigned soffA = (unsigned)kt0 * stepA, soffB = (unsigned)kt0 * stepB;
     la.template issue2<0>(smem, wave, soffA, nk > 0); la.template issue2<2>(smem, wave, soffA, nk > 0);
@@ -436,6 +465,7 @@ __device__ __forceinline__ void w8p_body(const GemmK& d, W8KArg kp, char* smem, 
     LB lb;
     la.init(d.A, Ab, m0, mlimit, lane, wave);
     lb.init(d.B, Bb, n0, d.N, lane, wave);
+    la.set_batched(false); lb.set_batched(false);
     la.template issue2<0>(a_cur, wave, 0u, true); la.template issue2<2>(a_cur, wave, 0u, true);
     lb.template issue2<0>(bimg, wave, 0u, true); lb.template issue2<2>(bimg, wave, 0u, true);
     la.template issue2<0>(a_nxt, wave, stepA, true); la.template issue2<2>(a_nxt, wave, stepA, true);
@@ -612,8 +642,11 @@ namespace sclg {
 // `ncu` CUs; returns 0 when the wide kernel cannot address the operands (caller falls back to gemm.hip's kernels).
 bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan) {
     auto flat_rows = [](const SclOperand& o, long long rows) { return (long long)o.rpb >= rows; };
-    const bool a_ok = at ? flat_rows(d.A, d.K) : (d.A.cin == 0x7fffffff || d.A.cin == 64 || d.A.cin >= d.K);
-    const bool b_ok = bt ? flat_rows(d.B, d.K) : (d.B.cin == 0x7fffffff || d.B.cin == 64 || d.B.cin >= d.K);
+    // both operands transposed (weight gradients, ping-pong loop): K rows may be utterance-batched (conv layers: rpb = frames per
+    // utterance) — the loaders then compute their offsets per K step instead of advancing a scalar offset
+    const bool tt = at && bt;
+    const bool a_ok = at ? (flat_rows(d.A, d.K) || (tt && d.A.rpb >= 1)) : (d.A.cin == 0x7fffffff || d.A.cin == 64 || d.A.cin >= d.K);
+    const bool b_ok = bt ? (flat_rows(d.B, d.K) || (tt && d.B.rpb >= 1)) : (d.B.cin == 0x7fffffff || d.B.cin == 64 || d.B.cin >= d.K);
     if (!a_ok || !b_ok || (d.K % BK) != 0) return false;
     const long long tiles_n = (d.N + W8_BN - 1) / W8_BN;
     long long best = -1;
@@ -655,6 +688,10 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // read instructions per fragment)
     const char* me = getenv("SCL_W8_MODE");
     int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
+    if (at && bt) {      // utterance-batched K rows (see scl_gemm_w8_plan): only the ping-pong loop computes per-step offsets
+        if ((long long)k.A.rpb < (long long)k.K) { k.debug |= 4; mode = 0; }
+        if ((long long)k.B.rpb < (long long)k.K) { k.debug |= 8; mode = 0; }
+    }
     {
         const char* sg = getenv("SCL_W8_STAGGER");
         const int stg = sg ? atoi(sg) : 0;

@@ -30,6 +30,7 @@ POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
 # epilogue multiplies by the stored number; 0 = store the pre-activation and re-evaluate gelu' in the backward epilogue (rounds 1-2)
 GELU_DC2 = os.environ.get("SCL_GELU_DC2", "1") != "0"
+CONV_WGRAD_WIDE = os.environ.get("SCL_CONV_WGRAD_WIDE", "1") != "0"
 
 
 class W2VConfig:
@@ -292,7 +293,9 @@ class Encoder:
         sk = _splitk(tiles, ksteps)
         # wide tiles (gemm_w8.hip: 256 x 256 output tiles, one 8-wave block per CU): size the split for one round of the 256 CUs
         t256 = ((Mo + 255) // 256) * ((No + 255) // 256) * kw.get("nb2", 1)
-        if t256 >= 32 or (WGRAD_SMALL_SPLIT and t256 >= 12):
+        # 12-31 tiles with a very long reduction (conv-stack weight gradients: 12 tiles, 800-6400 K steps, utterance-batched K rows): 16 slabs
+        # of >= 50 steps each on the wide ping-pong kernel instead of the 128 x 128 one (SCL_CONV_WGRAD_WIDE=0: as before)
+        if t256 >= 32 or ((WGRAD_SMALL_SPLIT or (CONV_WGRAD_WIDE and ksteps >= 700)) and t256 >= 12):
             # 12-31 tiles (out-proj: 16): up to 16 slabs fill the 256 CUs once; the 128 x 128 sizing below left 160 blocks of 25 K steps
             skw = max(1, min(8 if t256 >= 32 else 16, (256 + t256 // 2) // t256, ksteps // 8))
             if ops.gemm_wide_kind(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, splitk=skw, c_split_stride=out.numel() if skw > 1 else 0, **kw):

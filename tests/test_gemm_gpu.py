@@ -659,3 +659,39 @@ def test_gelu_with_stored_derivative_epilogues(dev):
     dsc = ops._gemm_desc(ops.Op(dY, K), ops.Op(W, K), G, M, N, K, R=D, rmode=2, ract=4)
     ops._call("scl_gemm_splitk_finish", ops.ctypes.byref(dsc), ops._ptr(slabs), 2, M * N, ops._stream(), keep=dsc)
     assert torch.equal(G, ((slabs[0] + slabs[1]) * D.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("splitk", [1, 3, 16])
+def test_wide_tile_kernel_utterance_batched_reduction_rows(dev, splitk):
+    """Conv-stack weight gradient as a GEMM: both operands transposed with the K rows batched per utterance (A = the padded output-gradient
+    layout, rows at an offset; B = overlapping im2col rows with stride 2): the wide ping-pong kernel computes its LDS-DMA offsets per
+    K step (row_off divides by the frames per utterance) where flat operands advance a scalar offset.  Bit-identical to the 128 x 128
+    kernel, slab by slab; NaN behind both buffers."""
+    Bz, Tin, C, k, s = 8, 321, 512, 3, 2
+    Tout = (Tin - k) // s + 1            # 160 frames -> K = 1280 rows = 20 K steps, utterance edges inside K steps
+    Q, Rp = 2, Tout + 5
+    z = _rand((Bz * Tin * C,), dev, 301, 0.3)
+    dyp = torch.zeros(Bz, Rp, C)
+    dyp[:, Q: Q + Tout] = torch.randn(Bz, Tout, C, generator=torch.Generator().manual_seed(302)) * 0.1
+    dyp = dyp.to(torch.bfloat16).to(dev)
+    def nanpad(t):
+        buf = torch.full((t.numel() + 65536,), float("nan"), dtype=torch.bfloat16, device=dev)
+        buf[:t.numel()] = t.reshape(-1)
+        return buf
+    zb, dyb = nanpad(z), nanpad(dyp)
+    M, N, K = C, k * C, Bz * Tout
+    outs = []
+    for sel in (dict(no_w8=True, no_p8=True, no_big=True, no_x2=True), dict(force_w8=True), dict(force_w8=True)):
+        out = torch.full((splitk, M, N), float("nan"), device=dev)
+        ops.gemm(ops.Op(dyb, C, rpb=Tout, rbstride=Rp * C, offset=Q * C), ops.Op(zb, s * C, rpb=Tout, rbstride=Tin * C), out, M, N, K, a_t=True, b_t=True,
+                 splitk=splitk, c_split_stride=M * N if splitk > 1 else 0, **sel)
+        outs.append(out)
+    d = ops._gemm_desc(ops.Op(dyb, C, rpb=Tout, rbstride=Rp * C, offset=Q * C), ops.Op(zb, s * C, rpb=Tout, rbstride=Tin * C), outs[-1], M, N, K, a_t=True,
+                       b_t=True, splitk=splitk, c_split_stride=M * N if splitk > 1 else 0, force_w8=True)
+    assert ops.L.load().scl_gemm_uses_wide_tiles(ops.ctypes.byref(d)) in (1, 2)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # against torch: dW[co][tap*C + ci] = sum_{b,t} dy[b][t][co] x[b][t*s + tap][ci]
+    x = z.float().view(Bz, Tin, C).cpu(); dy = dyp.float()[:, Q: Q + Tout].cpu()
+    want = torch.cat([torch.einsum("bto,btc->oc", dy, x[:, tap: tap + s * Tout: s][:, :Tout]) for tap in range(k)], dim=1)
+    _close(outs[1].sum(0), want, 2e-3, "conv wgrad")
