@@ -297,7 +297,9 @@ class Encoder:
         # of >= 50 steps each on the wide ping-pong kernel instead of the 128 x 128 one (SCL_CONV_WGRAD_WIDE=0: as before)
         if t256 >= 32 or ((WGRAD_SMALL_SPLIT or (CONV_WGRAD_WIDE and ksteps >= 700)) and t256 >= 12):
             # 12-31 tiles (out-proj: 16): up to 16 slabs fill the 256 CUs once; the 128 x 128 sizing below left 160 blocks of 25 K steps
-            skw = max(1, min(8 if t256 >= 32 else 16, (256 + t256 // 2) // t256, ksteps // 8))
+            # slabs: one round of the 256 CUs; at most 8 (>= 32 tiles) / 16 (12-31 tiles) / 21 (12 tiles and >= 700 K steps: the conv layers;
+            # tools/_wg probe, us incl. the slab reduction, 16 -> 21 slabs: 766 -> 677, 400 -> 358, 207 -> 184, 116 -> 102)
+            skw = max(1, min(8 if t256 >= 32 else (21 if ksteps >= 700 else 16), (256 + t256 // 2) // t256, ksteps // 8))
             if ops.gemm_wide_kind(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, splitk=skw, c_split_stride=out.numel() if skw > 1 else 0, **kw):
                 sk = skw
         if sk == 1:
