@@ -22,7 +22,10 @@ from .ops import Op
 
 # fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
 FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
-WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "0") != "0"
+# 12-31-tile weight gradients (out-proj: 16 tiles of 256 x 256) in up to 16 split-K slabs on the wide kernel.  Round-3 re-measurement in one
+# call, three pairs: 47.78 / 47.59 / 47.66 ms per step off, 47.76 / 47.29 / 47.26 on (launch + slab reduction: 61.4 -> 53.8 us) — the earlier
+# "slower" verdict (53.7 vs 51.9 on different boxes) was box-to-box noise.
+WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "1") != "0"
 # the (up to) four small column reductions that close a layer's backward in ONE launch (SCL_BATCH_REDUCE=0: one launch each)
 BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
