@@ -702,7 +702,10 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // on MI355X against one-tile blocks (tools/persist_probe.py, profiles/r3_gemm_persistent_vs_one_tile.txt) it is equal within
     // +-2 % on the encoder's 3- and 4-round launches — the first K step of the next tile still waits (in-order vmcnt) for the
     // epilogue's stores, whose drain into HBM, with every CU storing at once, is what a block switch already overlapped — and the
-    // 256-row variant spills.
+    // 256-row variant spills.  In the full train step SCL_GEMM_PERSIST=1 is much SLOWER (84.8 vs 47.4 ms: +0.5 ms per persistent
+    // launch): the w8p kernels are the only ones in the step with a private segment (48-96 B of scratch from their register
+    // pressure), and a kernel that needs scratch between kernels that do not costs a queue-side scratch set-up per dispatch.  Kept
+    // as a tested, documented experiment; do not switch it on for training.
     const char* pe = getenv("SCL_GEMM_PERSIST");
     const int pv = pe ? atoi(pe) : 0;
     dim3 g = grid;
@@ -711,7 +714,8 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         const long long rounds = (plan.tiles + ncu - 1) / ncu;
         long long G = pv >= 8 ? (pv & ~7) : ((((plan.tiles + rounds - 1) / rounds) + 7) & ~7ll);      // equal rounds on every block, a multiple of 8
         if (G > (ncu & ~7ll) && pv < 8) G = ncu & ~7ll;
-        if ((pv >= 8 || rounds >= 2) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
+        // automatic mode (1): the 208-row variant only — the 256-row one spills under the persistent loop's register pressure (2 x slower)
+        if ((pv >= 8 || (rounds >= 2 && plan.variant == 0)) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
     }
     if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
     else w8_launch_rb<8, 8>(k, at, bt, g, s, mode);
