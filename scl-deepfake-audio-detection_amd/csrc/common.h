@@ -19,8 +19,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
     return __builtin_bit_cast(unsigned short, b);
 }
+// ONE v_cvt_pk_bf16_f32 for the pair: converting the halves separately and merging them cost four instructions (two conversions, a
+// shift and an or) in every bf16 store of every epilogue; same round-to-nearest-even bits.
+typedef __attribute__((ext_vector_type(2))) __bf16 scl_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float scl_f32x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const scl_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, scl_bf16x2));
 }
 
 // erf-GELU (torch.nn.functional.gelu default / fairseq "gelu") with erf by Abramowitz-Stegun 7.1.26:
