@@ -358,14 +358,14 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
         f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
         float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
-        w8_epilogue_pass(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        w8_epilogue_pass<4, (RBW < 8)>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            w8_epilogue_pass(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
+            w8_epilogue_pass<4, (RBW < 8)>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
         }
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
@@ -691,6 +691,10 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     if (at && bt) {      // utterance-batched K rows (see scl_gemm_w8_plan): only the ping-pong loop computes per-step offsets
         if ((long long)k.A.rpb < (long long)k.K) { k.debug |= 4; mode = 0; }
         if ((long long)k.B.rpb < (long long)k.K) { k.debug |= 8; mode = 0; }
+    }
+    {
+        static const bool epi_generic = [] { const char* e = getenv("SCL_W8_EPI_GENERIC"); return e && atoi(e) != 0; }();
+        if (epi_generic) k.debug |= 16;      // A/B: the generic (run-time flag) epilogue loop for every launch
     }
     {
         const char* sg = getenv("SCL_W8_STAGGER");

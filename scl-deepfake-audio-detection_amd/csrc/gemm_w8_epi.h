@@ -18,16 +18,34 @@ namespace sclg {
 // cs_carry (optional, 8 floats of the caller): the column sums START from it and are handed back in it instead of being reduced and
 // stored per pass (the caller finishes with w8_colsum_store): two 2-block passes then add a lane's rows in the order one 4-block pass does.
 // blk_stride: byte distance between the wave's 4-KiB (16-row) transposition blocks (4096: one contiguous block).
-template <int NMT>
-static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
-                                                 int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr,
-                                                 float* cs_carry = nullptr, const int blk_stride = 4096) {
+// EK: the epilogue KIND.  The flag word is a launch constant, yet the rolled row loop below re-tested ~20 of its bits for every 8 rows
+// (the ISA showed the loop body as a chain of ~40 small blocks ending in s_cbranch).  The encoder's five hot epilogues get the flags as
+// compile-time constants (their loop is straight-line code); everything else runs the generic form (EK 0).  Same arithmetic either way.
+//   1: bf16 C [+ bias]                      — QKV forward, the plain data gradients
+//   2: bf16 C = gelu(acc + bias), bf16 C2 = gelu'  — fc1 forward (ACT 5)
+//   3: bf16 C = acc x R, R bf16 the stored derivative (RMODE 2 / RACT 4)  — fc2 data gradient
+//   4: f32 C = acc [+ bias] + R, R f32      — out-proj / fc2 forward (residual stream)
+//   5: f32 C [+ bias]                       — split-K slabs of the weight gradients, conv layers
+// Kinds 1-5 also assume 8-element alignment of every row start (ldc, c_rbstride, cbase multiples of 8: checked by the dispatcher).
+template <int NMT, int EK>
+static __device__ __forceinline__ void w8_epilogue_pass_k(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
+                                                   int mlimit, long long cbase, const float* bias, int lane, float* csum_row,
+                                                   float* cs_carry, const int blk_stride) {
+    // The generic form evaluates every step of the chain (alpha, bias, activation, x R, + R, column sum) in its own basic block, so no
+    // multiply-add pair of DIFFERENT steps is ever fused; the straight-line kinds must not fuse them either (seen: the column sum
+    // cs += (acc x R) became one fma and the fc1 bias gradient changed in the last bits).
+#pragma clang fp contract(off)
     const int flags = d.flags;
-    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
-    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
-    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
-    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
-    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+    constexpr bool KN = EK != 0;
+    const bool c_f32 = KN ? (EK == 4 || EK == 5) : bool(flags & SCL_GEMM_C_F32);
+    const bool c2_f32 = KN ? false : bool(flags & SCL_GEMM_C2_F32);
+    const bool r_f32 = KN ? (EK == 4) : bool(flags & SCL_GEMM_R_F32);
+    const bool has_bias = EK == 2 ? true : (EK == 3 ? false : bool(flags & SCL_GEMM_HAS_BIAS));
+    const bool has_c2 = KN ? (EK == 2) : bool(flags & SCL_GEMM_HAS_C2);
+    const bool drop = KN ? false : bool(flags & SCL_GEMM_DROPOUT);
+    const int act = KN ? (EK == 2 ? 5 : 0) : ((flags >> SCL_GEMM_ACT_SHIFT) & 0xF);
+    const int rmode = KN ? (EK == 3 ? 2 : (EK == 4 ? 1 : 0)) : ((flags >> SCL_GEMM_RMODE_SHIFT) & 0xF);
+    const int ract = KN ? (EK == 3 ? 4 : 0) : ((flags >> SCL_GEMM_RACT_SHIFT) & 0xF);
     const int g = lane >> 4, lc = lane & 15;
     const int c = lane & 7, rsub = lane >> 3;
     const int col = nbase + 8 * c;
@@ -117,7 +135,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
                     *reinterpret_cast<float4*>(p + 4) = make_float4(w[4], w[5], w[6], w[7]);
                 } else {
                     bf16_t* p = reinterpret_cast<bf16_t*>(d.C2) + off;
-                    if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+                    if (KN || (off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
                     else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7])); }
                 }
             }
@@ -139,7 +157,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
                     const bf16_t* p = reinterpret_cast<const bf16_t*>(d.R) + off;
                     uint2 t0, t1;
                     if (r_dma) { const uint4 t = *reinterpret_cast<const uint4*>(rstage + i * 1024 + lane * 16); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
-                    else if ((off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
+                    else if (KN || (off & 7) == 0) { const uint4 t = *reinterpret_cast<const uint4*>(p); t0 = make_uint2(t.x, t.y); t1 = make_uint2(t.z, t.w); }
                     else { t0 = *reinterpret_cast<const uint2*>(p); t1 = *reinterpret_cast<const uint2*>(p + 4); }
                     rr[0] = __uint_as_float(t0.x << 16); rr[1] = __uint_as_float(t0.x & 0xFFFF0000u);
                     rr[2] = __uint_as_float(t0.y << 16); rr[3] = __uint_as_float(t0.y & 0xFFFF0000u);
@@ -175,7 +193,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
                 *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else {
                 bf16_t* p = reinterpret_cast<bf16_t*>(d.C) + off;
-                if ((off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                if (KN || (off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
                 else { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); *reinterpret_cast<uint2*>(p + 4) = make_uint2(pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
             }
         } else {
@@ -201,6 +219,28 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     }
 }
 
+
+// SPEC = false: always the generic form (the 256-row single-barrier kernels sit at the 256-register limit: the extra straight-line
+// copies pushed them into scratch, and a kernel with a private segment pays a queue-side set-up per dispatch)
+template <int NMT, bool SPEC = true>
+static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
+                                                 int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr,
+                                                 float* cs_carry = nullptr, const int blk_stride = 4096) {
+    constexpr int KEY = SCL_GEMM_C_F32 | SCL_GEMM_C2_F32 | SCL_GEMM_R_F32 | SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | SCL_GEMM_DROPOUT |
+                        (0xF << SCL_GEMM_ACT_SHIFT) | (0xF << SCL_GEMM_RMODE_SHIFT) | (0xF << SCL_GEMM_RACT_SHIFT);
+    const int f = d.flags & KEY, fb = f & ~SCL_GEMM_HAS_BIAS;
+    if (SPEC && !(d.debug & 16) && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B)
+        if (fb == 0) return w8_epilogue_pass_k<NMT, 1>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if (f == (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT)))
+            return w8_epilogue_pass_k<NMT, 2>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if (f == ((2 << SCL_GEMM_RMODE_SHIFT) | (4 << SCL_GEMM_RACT_SHIFT)))
+            return w8_epilogue_pass_k<NMT, 3>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if (fb == (SCL_GEMM_C_F32 | SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT)))
+            return w8_epilogue_pass_k<NMT, 4>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if (fb == SCL_GEMM_C_F32) return w8_epilogue_pass_k<NMT, 5>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+    }
+    w8_epilogue_pass_k<NMT, 0>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+}
 
 // finish a carried column sum: butterfly over the 8 row lanes that share a column group, lanes 0-7 store 8 columns each
 static __device__ __forceinline__ void w8_colsum_store(const GemmK& d, float (&cs)[8], float* csum_row, int nbase, int lane) {
