@@ -221,8 +221,8 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, typename W8S
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
         // optional column sums of the stored values: partial row (tile row * 4 + wave row * 2 + pass)
         float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
-        w8_epilogue_pass(d, acc[0], 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
-        w8_epilogue_pass(d, acc[1], NH, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
+        w8_epilogue_pass<4, 0>(d, acc[0], 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        w8_epilogue_pass<4, 0>(d, acc[1], NH, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
@@ -358,14 +358,14 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
         f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
         float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
-        w8_epilogue_pass<4, (RBW < 8)>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            w8_epilogue_pass<4, (RBW < 8)>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
+            w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
         }
     }
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
@@ -555,11 +555,11 @@ __device__ __forceinline__ void w8p_body(const GemmK& d, W8KArg kp, char* smem, 
                 }
                 if (2 * pr + 1 < RBW) {
                     f32x4 (&a2)[2][4] = *reinterpret_cast<f32x4 (*)[2][4]>(&acc[2 * pr]);
-                    w8_epilogue_pass<2>(d, a2, 2, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
+                    w8_epilogue_pass<2, 0>(d, a2, 2, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
                                         cs0 ? cs : nullptr, bstride);
                 } else {
                     f32x4 (&a1)[1][4] = *reinterpret_cast<f32x4 (*)[1][4]>(&acc[2 * pr]);
-                    w8_epilogue_pass<1>(d, a1, 1, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
+                    w8_epilogue_pass<1, 0>(d, a1, 1, wlds, wextra, m0 + (ab + 2 * pr) * 16, n0 + wc * 64, mlimit, 0ll, bias, lane, nullptr,
                                         cs0 ? cs : nullptr, bstride);
                 }
                 if (cs0 && (pr == 1 || pr == (RBW + 1) / 2 - 1)) w8_colsum_store(d, cs, cs0 + (pr >> 1) * d.N, n0 + wc * 64, lane);

@@ -220,24 +220,26 @@ static __device__ __forceinline__ void w8_epilogue_pass_k(const GemmK& d, f32x4 
 }
 
 
-// SPEC = false: always the generic form (the 256-row single-barrier kernels sit at the 256-register limit: the extra straight-line
-// copies pushed them into scratch, and a kernel with a private segment pays a queue-side set-up per dispatch)
-template <int NMT, bool SPEC = true>
+// SPEC: bit k set = kind k may be taken.  Kind 5 is compiled out by default: measured on one box it is 5-6 % SLOWER than the generic loop
+// (f32 slabs of the weight gradients 127 -> 135 us, conv forward 395 -> 416), unlike kinds 1-4 (plain bf16 41 -> 36, f32 residual 47 -> 45,
+// fc1 / fc2 above).  The 256-row single-barrier kernels sit at the 256-register limit (any extra copy pushed them into scratch, and a
+// kernel with a private segment pays a queue-side set-up per dispatch) and the ping-pong kernels only ever store f32 slabs: both pass 0.
+template <int NMT, int SPEC = 0x1E>
 static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&acc)[NMT][4], int nmt, char* wlds, char* wextra, int mbase, int nbase,
                                                  int mlimit, long long cbase, const float* bias, int lane, float* csum_row = nullptr,
                                                  float* cs_carry = nullptr, const int blk_stride = 4096) {
     constexpr int KEY = SCL_GEMM_C_F32 | SCL_GEMM_C2_F32 | SCL_GEMM_R_F32 | SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | SCL_GEMM_DROPOUT |
                         (0xF << SCL_GEMM_ACT_SHIFT) | (0xF << SCL_GEMM_RMODE_SHIFT) | (0xF << SCL_GEMM_RACT_SHIFT);
     const int f = d.flags & KEY, fb = f & ~SCL_GEMM_HAS_BIAS;
-    if (SPEC && !(d.debug & 16) && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B)
-        if (fb == 0) return w8_epilogue_pass_k<NMT, 1>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
-        if (f == (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT)))
+    if (SPEC != 0 && !(d.debug & 16) && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B)
+        if ((SPEC & 2) && fb == 0) return w8_epilogue_pass_k<NMT, 1>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if ((SPEC & 4) && f == (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT)))
             return w8_epilogue_pass_k<NMT, 2>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
-        if (f == ((2 << SCL_GEMM_RMODE_SHIFT) | (4 << SCL_GEMM_RACT_SHIFT)))
+        if ((SPEC & 8) && f == ((2 << SCL_GEMM_RMODE_SHIFT) | (4 << SCL_GEMM_RACT_SHIFT)))
             return w8_epilogue_pass_k<NMT, 3>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
-        if (fb == (SCL_GEMM_C_F32 | SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT)))
+        if ((SPEC & 16) && fb == (SCL_GEMM_C_F32 | SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT)))
             return w8_epilogue_pass_k<NMT, 4>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
-        if (fb == SCL_GEMM_C_F32) return w8_epilogue_pass_k<NMT, 5>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
+        if ((SPEC & 32) && fb == SCL_GEMM_C_F32) return w8_epilogue_pass_k<NMT, 5>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
     }
     w8_epilogue_pass_k<NMT, 0>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
 }

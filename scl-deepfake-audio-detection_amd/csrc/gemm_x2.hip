@@ -158,14 +158,14 @@ __device__ __forceinline__ void x2_body(const GemmK& d, char* smem, const typena
         char* wlds = smem + wave * 16384;
         char* wextra = smem + 4 * 16384 + wave * 4096;
         f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
-        w8_epilogue_pass(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+        w8_epilogue_pass<4, 0>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hi[i][j] = (4 + i < RBW) ? acc[(4 + i < RBW) ? 4 + i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            w8_epilogue_pass(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
+            w8_epilogue_pass<4, 0>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane);
         }
     }
 }
