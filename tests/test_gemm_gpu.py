@@ -695,3 +695,51 @@ def test_wide_tile_kernel_utterance_batched_reduction_rows(dev, splitk):
     x = z.float().view(Bz, Tin, C).cpu(); dy = dyp.float()[:, Q: Q + Tout].cpu()
     want = torch.cat([torch.einsum("bto,btc->oc", dy, x[:, tap: tap + s * Tout: s][:, :Tout]) for tap in range(k)], dim=1)
     _close(outs[1].sum(0), want, 2e-3, "conv wgrad")
+
+
+@pytest.mark.parametrize("M,N", [(3 * 208 + 57, 1024), (2 * 208 + 1, 2 * 256 + 72), (12736, 1024)])
+def test_wide_tile_epilogue_kinds_equal_the_128_tile_kernel(dev, monkeypatch, M, N):
+    """The compile-time epilogue kinds of the 208-row single-barrier kernels (gemm_w8_epi.h: 1 bf16 [+ bias], 2 fc1 forward with the
+    stored gelu', 3 fc2 data gradient x stored derivative [+ column sums], 4 f32 [+ bias] + f32 residual) against the 128 x 128
+    kernel and against the generic run-time-flag loop of the same kernel (SCL_W8_EPI_GENERIC is read once per process, so the
+    generic arm is reached through a flag combination no kind matches: dropout with p = 0), bit for bit — ragged last row tile,
+    a column edge inside a tile (the element-wise path inside a kind), both weight layouts."""
+    K = 512
+    A = _rand((M, K), dev, 401, 0.3); W = _rand((N, K), dev, 402, 0.05); Wt = W.t().contiguous()
+    bias = torch.randn(N, device=dev); Rb = _rand((M, N), dev, 403, 1.0); Rf = torch.randn(M, N, device=dev)
+    cases = [
+        (dict(), torch.bfloat16, False), (dict(bias=bias), torch.bfloat16, False),                                   # kind 1
+        (dict(bias=bias, act=5), torch.bfloat16, True),                                                             # kind 2
+        (dict(R=Rb, rmode=2, ract=4), torch.bfloat16, False),                                                       # kind 3
+        (dict(R=Rf, rmode=1), torch.float32, False), (dict(bias=bias, R=Rf, rmode=1), torch.float32, False),        # kind 4
+    ]
+    for kw, cdt, c2 in cases:
+        for b_t, opB in ((False, ops.Op(W, K)), (True, ops.Op(Wt, N))):
+            outs = []
+            for sel in (dict(no_w8=True, no_p8=True, no_big=True, no_x2=True), dict(force_w8=True), dict(force_w8=True, drop_p=0.0, drop_seed=0, _drop_flag=True)):
+                sel = dict(sel)
+                generic = sel.pop("_drop_flag", False)
+                C = torch.full((M, N), float("nan"), dtype=cdt, device=dev)
+                C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev) if c2 else None
+                d = ops._gemm_desc(ops.Op(A, K), opB, C, M, N, K, b_t=b_t, c2=C2, **kw, **sel)
+                if generic:
+                    d.flags |= 0x80          # SCL_GEMM_DROPOUT with p = 0: every keep factor is 1, and no kind matches the flag word
+                ops._call("scl_gemm_bf16", ops.ctypes.byref(d), ops._stream(), keep=d)
+                outs.append((C, C2))
+            for o in outs[1:]:
+                assert torch.equal(outs[0][0], o[0]), (kw.keys(), b_t)
+                if c2:
+                    assert torch.equal(outs[0][1], o[1]), (kw.keys(), b_t)
+    if N % 256 == 0:      # kind 3 with the per-tile column sums: partial rows equal the generic loop's
+        parts = []
+        for generic in (False, True):
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw = dict(b_t=True, R=Rb, rmode=2, ract=4, force_w8=True)
+            rows = ops.gemm_colsum_rows(ops.Op(A, K), ops.Op(Wt, N), C, M, N, K, **kw)
+            part = torch.full((rows, N), float("nan"), device=dev)
+            d = ops._gemm_desc(ops.Op(A, K), ops.Op(Wt, N), C, M, N, K, colsum_part=part, **kw)
+            if generic:
+                d.flags |= 0x80
+            ops._call("scl_gemm_bf16", ops.ctypes.byref(d), ops._stream(), keep=d)
+            parts.append((C, part))
+        assert torch.equal(parts[0][0], parts[1][0]) and torch.equal(parts[0][1], parts[1][1])
