@@ -773,7 +773,8 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
     k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
     static const int group_m_env = [] { const char* e = getenv("SCL_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();
-    k.group_m = group_m_env; k.tile_m = 0; k.debug = 0;
+    static const bool epi_generic = [] { const char* e = getenv("SCL_W8_EPI_GENERIC"); return e && atoi(e) != 0; }();
+    k.group_m = group_m_env; k.tile_m = 0; k.debug = epi_generic ? 16 : 0;      // bit 4: generic epilogue loops (A/B); the wide launch sets its own bits
     // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias
     auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p & (bytes - 1)) == 0; };
     const bool strides4 = !(d.ldc & 3) && !(d.c_bs1 & 3) && !(d.c_bs2 & 3) && !(d.c_rbstride & 3) && !(d.c_split_stride & 3) && !(d.bias_bs2 & 3);

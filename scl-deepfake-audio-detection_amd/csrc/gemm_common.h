@@ -147,15 +147,23 @@ static __device__ __noinline__ void epi_scalar(EpiArgs d, float t, long long o, 
 // Fused epilogue of one wave's [NMT x 16 rows] x [4 x 16 columns] accumulator block whose first element is C[mbase][nbase]:
 // lane holds C[row = mbase + mt*16 + (lane&15)][col = nbase + nt*16 + 4*(lane>>4) + 0..3].  Rows >= mlimit (the end of the
 // problem or of this tile's row range) and row blocks >= nmt are not written.
-template <int NMT>
-__device__ __forceinline__ void gemm_epilogue_blk(const GemmK& d, f32x4 (&acc)[NMT][4], int mbase, int nbase, int mlimit, int nmt,
-                                                  int z1, int z2, int ksplit, int lane) {
+// EK: epilogue kind, as in gemm_w8_epi.h (0 generic: every flag tested per 16 x 16 sub-block, 16 times per wave; 1 bf16 [+ bias],
+// 2 fc1 forward with the stored gelu', 3 x stored derivative, 4 f32 [+ bias] + f32 residual, 5 f32 [+ bias]: flags as constants).
+template <int NMT, int EK>
+__device__ __forceinline__ void gemm_epilogue_blk_k(const GemmK& d, f32x4 (&acc)[NMT][4], int mbase, int nbase, int mlimit, int nmt,
+                                                    int z1, int z2, int ksplit, int lane) {
+#pragma clang fp contract(off)      // as the generic form's basic blocks imply: no multiply-add of two different epilogue steps is fused
     const int flags = d.flags;
-    const bool c_f32 = flags & SCL_GEMM_C_F32, c2_f32 = flags & SCL_GEMM_C2_F32, r_f32 = flags & SCL_GEMM_R_F32;
-    const bool has_bias = flags & SCL_GEMM_HAS_BIAS, has_c2 = flags & SCL_GEMM_HAS_C2, drop = flags & SCL_GEMM_DROPOUT;
-    const int act = (flags >> SCL_GEMM_ACT_SHIFT) & 0xF;
-    const int rmode = (flags >> SCL_GEMM_RMODE_SHIFT) & 0xF;
-    const int ract = (flags >> SCL_GEMM_RACT_SHIFT) & 0xF;
+    constexpr bool KN = EK != 0;
+    const bool c_f32 = KN ? (EK == 4 || EK == 5) : bool(flags & SCL_GEMM_C_F32);
+    const bool c2_f32 = KN ? false : bool(flags & SCL_GEMM_C2_F32);
+    const bool r_f32 = KN ? (EK == 4) : bool(flags & SCL_GEMM_R_F32);
+    const bool has_bias = EK == 2 ? true : (EK == 3 ? false : bool(flags & SCL_GEMM_HAS_BIAS));
+    const bool has_c2 = KN ? (EK == 2) : bool(flags & SCL_GEMM_HAS_C2);
+    const bool drop = KN ? false : bool(flags & SCL_GEMM_DROPOUT);
+    const int act = KN ? (EK == 2 ? 5 : 0) : ((flags >> SCL_GEMM_ACT_SHIFT) & 0xF);
+    const int rmode = KN ? (EK == 3 ? 2 : (EK == 4 ? 1 : 0)) : ((flags >> SCL_GEMM_RMODE_SHIFT) & 0xF);
+    const int ract = KN ? (EK == 3 ? 4 : 0) : ((flags >> SCL_GEMM_RACT_SHIFT) & 0xF);
     const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
     const float* bias = has_bias ? d.bias + z2 * d.bias_bs2 : nullptr;
     const int g = lane >> 4, lc = lane & 15;
@@ -220,6 +228,22 @@ __device__ __forceinline__ void gemm_epilogue_blk(const GemmK& d, f32x4 (&acc)[N
         }
         }
     }
+}
+
+template <int NMT>
+__device__ __forceinline__ void gemm_epilogue_blk(const GemmK& d, f32x4 (&acc)[NMT][4], int mbase, int nbase, int mlimit, int nmt,
+                                                  int z1, int z2, int ksplit, int lane) {
+    constexpr int KEY = SCL_GEMM_C_F32 | SCL_GEMM_C2_F32 | SCL_GEMM_R_F32 | SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | SCL_GEMM_DROPOUT |
+                        (0xF << SCL_GEMM_ACT_SHIFT) | (0xF << SCL_GEMM_RMODE_SHIFT) | (0xF << SCL_GEMM_RACT_SHIFT);
+    const int f = d.flags & KEY, fb = f & ~SCL_GEMM_HAS_BIAS;
+    if (!(d.debug & 16)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B)
+        if (fb == 0) return gemm_epilogue_blk_k<NMT, 1>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
+        if (f == (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT))) return gemm_epilogue_blk_k<NMT, 2>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
+        if (f == ((2 << SCL_GEMM_RMODE_SHIFT) | (4 << SCL_GEMM_RACT_SHIFT))) return gemm_epilogue_blk_k<NMT, 3>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
+        if (fb == (SCL_GEMM_C_F32 | SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT))) return gemm_epilogue_blk_k<NMT, 4>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
+        if (fb == SCL_GEMM_C_F32) return gemm_epilogue_blk_k<NMT, 5>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
+    }
+    gemm_epilogue_blk_k<NMT, 0>(d, acc, mbase, nbase, mlimit, nmt, z1, z2, ksplit, lane);
 }
 
 // the 64x64 per-wave block of the 128x128 / 256x128 / 256x256 kernels
