@@ -28,7 +28,9 @@ __device__ __forceinline__ void conv0_stage(float* wT, float* xs, const float* _
     for (int i = threadIdx.x; i < nx; i += blockDim.x) xs[i] = (x0 + i) < L ? x[x0 + i] : 0.f;
 }
 
-template <bool ZF32>     // ZF32: fp32 output (the scoring path keeps activations in fp32), else bf16
+// KC: the kernel width as a compile-time constant (10 = wav2vec 2.0's layer 0; 0 = run time).  With a run-time width the tap loop stays
+// rolled — ten trips of (3 LDS reads, 8 FMAs, a branch) per frame.
+template <bool ZF32, int KC>     // ZF32: fp32 output (the scoring path keeps activations in fp32), else bf16
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ zv, float* __restrict__ stats,
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
             if (c < C) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) y[ch][i] = bia[ch][i];
-                for (int j = 0; j < k; ++j) {
+#pragma unroll
+                for (int j = 0; j < (KC ? KC : k); ++j) {
                     const float xv = xs[r * stride + j];
                     const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
                     const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 // wave reductions; the 4-wave combine buffer re-uses the tap / waveform LDS once the frame loop is done (30 KiB per block
 // instead of 57 KiB; the 104 accumulators per lane keep it at 2 waves per SIMD).
 // KT: compile-time bound of the tap loops (10 for wav2vec2's layer 0: exactly 13 accumulators per channel; 16 = generic)
-template <bool STATS, int KT>
+// FULLK: k == KT, so the per-tap `j < k` tests (30 uniform branches per frame in the ISA) are compiled out
+template <bool STATS, int KT, bool FULLK>
 __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const bf16_t* __restrict__ dz,
@@ -162,18 +166,20 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
             if (STATS) { mean_next = stats[2 * (row + 4)]; rstd_next = stats[2 * (row + 4) + 1]; }
         }
 #pragma unroll
-        for (int j = 0; j < KT; ++j) xr[j] = j < k ? xs[r * stride + j] : 0.f;
+        for (int j = 0; j < KT; ++j) xr[j] = (FULLK || j < k) ? xs[r * stride + j] : 0.f;
         if (act) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = bia[i];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
-                if (j < k) {
+                if (j < k) {      // kept as a run-time test even with FULLK: as straight-line code the 20 weight vectors are all requested
+                                  // first (80 registers on top of the 104 accumulators: spills and a private segment)
                     const float4 w0 = *reinterpret_cast<const float4*>(wT + j * C + c);
                     const float4 w1 = *reinterpret_cast<const float4*>(wT + j * C + c + 4);
                     y[0] += w0.x * xr[j]; y[1] += w0.y * xr[j]; y[2] += w0.z * xr[j]; y[3] += w0.w * xr[j];
                     y[4] += w1.x * xr[j]; y[5] += w1.y * xr[j]; y[6] += w1.z * xr[j]; y[7] += w1.w * xr[j];
                 }
+
             }
             const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
                 aw[i][KT] += dy;  // dbias
 #pragma unroll
                 for (int j = 0; j < KT; ++j)
-                    if (j < k) aw[i][j] += dy * xr[j];
+                    if (FULLK || j < k) aw[i][j] += dy * xr[j];
             }
         }
     }
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv0_bwd_kernel(const float* __restri
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int j = 0; j < KT; ++j)
-                    if (j < k) red[(c + i) * (k + 3) + j] += aw[i][j];
+                    if (FULLK || j < k) red[(c + i) * (k + 3) + j] += aw[i][j];
                 red[(c + i) * (k + 3) + k] += aw[i][KT];
                 red[(c + i) * (k + 3) + k + 1] += aw[i][KT + 1];
                 red[(c + i) * (k + 3) + k + 2] += aw[i][KT + 2];
@@ -296,7 +302,8 @@ extern "C" int scl_conv0_fwd(const float* x, const float* w, const float* bias, 
     const int rows = 128;
     dim3 grid((T0 + rows - 1) / rows, B), block(256);
     const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
-    hipLaunchKernelGGL(conv0_fwd_kernel<false>, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, z, stats, L, T0, C, k, stride, rows, eps);
+    if (k == 10) hipLaunchKernelGGL((conv0_fwd_kernel<false, 10>), grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, z, stats, L, T0, C, k, stride, rows, eps);
+    else hipLaunchKernelGGL((conv0_fwd_kernel<false, 0>), grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, z, stats, L, T0, C, k, stride, rows, eps);
     return scl_check_launch("scl_conv0_fwd");
 }
 
@@ -308,7 +315,8 @@ extern "C" int scl_conv0_fwd_f32(const float* x, const float* w, const float* bi
     const int rows = 128;
     dim3 grid((T0 + rows - 1) / rows, B), block(256);
     const size_t lds = (size_t)(k * C + rows * stride + k) * sizeof(float);
-    hipLaunchKernelGGL(conv0_fwd_kernel<true>, grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (void*)z, nullptr, L, T0, C, k, stride, rows, eps);
+    if (k == 10) hipLaunchKernelGGL((conv0_fwd_kernel<true, 10>), grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (void*)z, nullptr, L, T0, C, k, stride, rows, eps);
+    else hipLaunchKernelGGL((conv0_fwd_kernel<true, 0>), grid, block, lds, (hipStream_t)stream, x, w, bias, gamma, beta, (void*)z, nullptr, L, T0, C, k, stride, rows, eps);
     return scl_check_launch("scl_conv0_fwd_f32");
 }
 
@@ -329,10 +337,11 @@ extern "C" int scl_conv0_bwd(const float* x, const float* w, const float* bias, 
     const size_t a = (size_t)(k * C + rows * stride + k), r = (size_t)C * (k + 3);
     const size_t lds = (a > r ? a : r) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define CONV0_BWD(ST, KT) hipLaunchKernelGGL((conv0_bwd_kernel<ST, KT>), grid, block, lds, s, x, w, bias, gamma, beta, (const bf16_t*)dz, stats, \
-                                             part_ws, L, T0, C, k, stride, rows, eps)
-    if (k <= 10) { if (stats) CONV0_BWD(true, 10); else CONV0_BWD(false, 10); }
-    else { if (stats) CONV0_BWD(true, MAXK); else CONV0_BWD(false, MAXK); }
+#define CONV0_BWD(ST, KT, FK) hipLaunchKernelGGL((conv0_bwd_kernel<ST, KT, FK>), grid, block, lds, s, x, w, bias, gamma, beta, (const bf16_t*)dz, stats, \
+                                                 part_ws, L, T0, C, k, stride, rows, eps)
+    if (k == 10) { if (stats) CONV0_BWD(true, 10, true); else CONV0_BWD(false, 10, true); }
+    else if (k < 10) { if (stats) CONV0_BWD(true, 10, false); else CONV0_BWD(false, 10, false); }
+    else { if (stats) CONV0_BWD(true, MAXK, false); else CONV0_BWD(false, MAXK, false); }
 #undef CONV0_BWD
     int nparts = grid.x * grid.y;
     const int n = C * (k + 3);
