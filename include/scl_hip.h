@@ -247,6 +247,8 @@ int scl_colreduce_seg_f32(const float* part, float* out, int nparts, int C, int6
                           float* out2, int split, void* stream);
 /* bias gradients: part[p][n] = sum over row slab p of x[m][n]; nparts = scl_colsum_nparts(M) */
 int scl_colsum_nparts(int M);
+/* partial rows scl_colsum_reduce needs in `part` for an [M, N] input (>= scl_colsum_nparts(M) only for N <= 128, where it cuts finer) */
+int scl_colsum_reduce_nparts(int M, int N);
 int scl_colsum(const void* x, int x_f32, float* part, int M, int N, int64_t ld, void* stream);
 /* the same plus the final sum in one launch: out[n] = sum_m x[m][n] (the `.sum(0)` autograd runs for every nn.Linear / Conv1d bias,
  * e.g. fairseq fc1/fc2/q,k,v,out_proj reached from model/xlsr.py:41).  `counters`: SCL_COLSUM_MAX_GROUPS int32, zero before the

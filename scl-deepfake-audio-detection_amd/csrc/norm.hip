@@ -525,6 +525,20 @@ static int colsum_rows(int M) {
     return rows_per_block;
 }
 
+// The self-finishing form over a NARROW matrix (N <= 128: one column group, so the grid is its row slabs only — 44 blocks for the
+// [177408, 64] convolution outputs of the AASIST back-end, 1.6 TB/s): up to 512 slabs there; the finishing block reads 512 x N floats.
+static int colsum_reduce_rows(int M, int N) {
+    if (N > 128) return colsum_rows(M);
+    int rows_per_block = 256;
+    while ((M + rows_per_block - 1) / rows_per_block > 512) rows_per_block *= 2;
+    return rows_per_block;
+}
+
+extern "C" int scl_colsum_reduce_nparts(int M, int N) {
+    const int rows_per_block = colsum_reduce_rows(M, N);
+    return (M + rows_per_block - 1) / rows_per_block;
+}
+
 extern "C" int scl_colsum_nparts(int M) {
     const int rows_per_block = colsum_rows(M);
     return (M + rows_per_block - 1) / rows_per_block;
@@ -543,7 +557,7 @@ extern "C" int scl_colsum(const void* x, int x_f32, float* part, int M, int N, i
 extern "C" int scl_colsum_reduce(const void* x, int x_f32, float* part, int* counters, float* out, int M, int N, int64_t ld, void* stream) {
     SCL_REQUIRE(x && part && counters && out && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum_reduce: bad args (N, ld multiples of 8)");
     SCL_REQUIRE((N + 127) / 128 <= SCL_COLSUM_MAX_GROUPS, "colsum_reduce: N too large for the counter array (%d)", N);
-    const int rows_per_block = colsum_rows(M);
+    const int rows_per_block = colsum_reduce_rows(M, N);
     dim3 grid((N + 127) / 128, (M + rows_per_block - 1) / rows_per_block), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (x_f32) hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, s, x, part, M, N, ld, rows_per_block, counters, out);

@@ -55,7 +55,7 @@ def _colsum(x2d, M, N):
     if N % 8:
         return x2d.view(M, N).sum(0)          # the 2-class / 1-score layers (computed 4 wide): a handful of columns
     out = torch.empty(N, device=x2d.device)
-    part = torch.empty(ops.colsum_nparts(M) * N, device=x2d.device)
+    part = torch.empty(ops.colsum_reduce_nparts(M, N) * N, device=x2d.device)
     ops.colsum_reduce(x2d, part, out, M, N)
     return out
 

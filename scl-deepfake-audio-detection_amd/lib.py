@@ -105,6 +105,7 @@ def _protos():
                                _i64, _i32, _i32, _i32, _i64, _i64, _u32, _f32, _u32, _f32, _vp], _i32),
         "scl_colreduce_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp], _i32),
         "scl_colsum_nparts": ([_i32], _i32),
+        "scl_colsum_reduce_nparts": ([_i32, _i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
         "scl_colreduce_multi": ([P(SclReduceJob), _i32, _vp], _i32),
         "scl_colreduce_seg_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp], _i32),

@@ -160,7 +160,7 @@ class FrontHeadModel(nn.Module):
             f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
             self._states[key] = dict(T=T, x=f32(B, L), feats=f32(B, T, FEAT_DIM), d_feats=f32(B, T, FEAT_DIM),
-                                     dfe_bf=bf(M * FEAT_DIM + 1024), denc=bf(M * E), cs=f32(ops.colsum_nparts(M) * FEAT_DIM), plans={})
+                                     dfe_bf=bf(M * FEAT_DIM + 1024), denc=bf(M * E), cs=f32(ops.colsum_reduce_nparts(M, 8) * FEAT_DIM), plans={})
         return self._states[key]
 
     def _front_forward(self, x):

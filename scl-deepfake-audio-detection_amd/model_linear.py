@@ -182,7 +182,7 @@ class Model(nn.Module):
                                     h=[hd(M * HEAD_DIM + 1024) for _ in range(3)], dpre=[hd(M * HEAD_DIM + 1024) for _ in range(3)],
                                     dfe=f32(M * HEAD_DIM), dfe_bf=bf(M * HEAD_DIM + 1024), denc=bf(M * self.cfg.embed),
                                     demb=f32(B * HEAD_DIM), ws=f32(B * N_CLASS + 16),
-                                    cs=f32(ops.colsum_nparts(M) * max(HEAD_DIM, 8)), dW=f32(HEAD_DIM * max(HEAD_DIM, self.cfg.embed)))
+                                    cs=f32(ops.colsum_reduce_nparts(M, 8) * max(HEAD_DIM, 8)), dW=f32(HEAD_DIM * max(HEAD_DIM, self.cfg.embed)))
         return self._hbufs[key]
 
     def _state(self, B, L):

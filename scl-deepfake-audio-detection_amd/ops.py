@@ -286,6 +286,11 @@ def colsum_nparts(M):
     return L.load().scl_colsum_nparts(M)
 
 
+def colsum_reduce_nparts(M, N):
+    """Partial rows colsum_reduce writes for an [M, N] input (more than colsum_nparts(M) when N <= 128)."""
+    return L.load().scl_colsum_reduce_nparts(M, N)
+
+
 def colsum(x, part, M, N, ld=None):
     _call("scl_colsum", _p(x), _isf32(x), _p(part), M, N, ld or N, _stream())
 

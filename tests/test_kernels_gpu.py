@@ -431,3 +431,21 @@ def test_posconv_wgrad_equals_the_transposed_gemm(dev, B, T, K, G):
     xd, dyd = xb.double().view(B, T + K, G, Cg), dyb.double().view(B, T + K, G, Cg)[:, pb: pb + T]
     want = torch.stack([torch.einsum("btgo,btgc->goc", dyd, xd[:, tap: tap + T]) for tap in range(K)], dim=2).reshape(G, Cg, K * Cg)
     assert (got.cpu().double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N", [(64 * 42 * 66, 64), (70000, 32), (200000, 128), (5000, 8)])
+def test_self_finishing_column_sum_cuts_narrow_matrices_finer(dev, M, N):
+    """scl_colsum_reduce over a narrow matrix (N <= 128: a single column group) uses up to 512 row slabs instead of 64 — the AASIST
+    back-end's [177408, 64] bias-gradient sums ran on 44 workgroups.  Sum against torch in f64, repeatable bit for bit, and the
+    partial-row count is what scl_colsum_reduce_nparts promises (rows beyond it stay untouched)."""
+    x = torch.randn(M, N, generator=g(9)).to(dev)
+    n = ops.colsum_reduce_nparts(M, N)
+    assert n >= ops.colsum_nparts(M) and n <= 512
+    first = None
+    for _ in range(3):
+        part = torch.full((n + 1, N), float("nan"), device=dev); out = torch.full((N,), float("nan"), device=dev)
+        ops.colsum_reduce(x, part, out, M, N)
+        assert torch.isfinite(part[:n]).all() and torch.isnan(part[n]).all()
+        assert ((out.double().cpu() - x.double().sum(0).cpu()).abs() / x.double().abs().sum(0).cpu()).max().item() < 1e-6
+        first = out.clone() if first is None else first
+        assert torch.equal(out, first)
