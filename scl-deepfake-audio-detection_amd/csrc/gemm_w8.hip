@@ -72,6 +72,10 @@ struct W8K {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
         }
     }
+    __device__ __forceinline__ void issue1(char* img, int wave, unsigned soff, bool live, int i) const {   // piece i
+        const unsigned off = live ? voff[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
+    }
     __device__ __forceinline__ static unsigned kstep(const OpK& o) { return o.cin == 64 ? o.cout_bytes : 128u; }
     __device__ __forceinline__ void rows(const OpK&, int, int, int) {}
     __device__ __forceinline__ void set_batched(bool) {}
@@ -117,6 +121,10 @@ struct W8T {
             const unsigned off = live ? voff[i] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
         }
+    }
+    __device__ __forceinline__ void issue1(char* img, int wave, unsigned soff, bool live, int i) const {
+        const unsigned off = live ? voff[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(img + (wave * 4 + i) * 1024), 16, off, soff, 0, 0);
     }
     __device__ __forceinline__ static unsigned kstep(const OpK& o) { return 64u * o.ld_bytes; }
     __device__ __forceinline__ unsigned step(const OpK& o) const { return batched ? 0u : kstep(o); }
@@ -294,9 +302,9 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
 // all 22.9 us, MFMA only 17.6, LDS reads only 8.8, DMA only 11.1 (84 GB/s per CU), nothing 4.6 — the loop is MFMA-paced at the
 // 1.8-2.0 GHz the chip holds under this load; running wave row 1 half a step out of phase (read | MFMA swapped) measured +-2 %.
 // Per K step t:
-//     wait(set 0) | read set 1 <- tile t, k 32..63 | MFMA set 0 | DMA A(t+2) -> A ring | wait(set 1) | vmcnt(4): tile t+1 landed
-//     BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
-//     DMA B(t+2) -> B image of tile t | read set 0 <- tile t+1, k 0..31 | MFMA set 1
+//     wait(set 0) | 4 x { 1/4 of read set 1 <- tile t, k 32..63 | 1/4 of MFMA set 0 | 1 of 4 DMA pieces A(t+2) -> A ring }
+//     wait(set 1) | vmcnt(4): tile t+1 landed | BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
+//     4 x { 1/4 of read set 0 <- tile t+1, k 0..31 | 1/4 of MFMA set 1 | 1 of 4 DMA pieces B(t+2) -> B image of tile t }
 // A pieces have two K steps to land, B pieces one.  Same K order per output element: bit-identical to the other kernels.
 template <bool AT, bool BT, int RBW>
 __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typename W8Sel<AT>::type& la, const typename W8Sel<BT>::type& lb,
@@ -315,42 +323,102 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
 #define W8S_READ(FA, FB, TA, TB, KS)                                                        \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = w8_frag<BT>(TB, nbk + j, KS, lane); \
     _Pragma("unroll") for (int i = 0; i < RBW; ++i) FA[i] = w8_frag<AT>(TA, ab + i, KS, lane);
-#define W8S_MFMA(FA, FB)                                                                    \
-    _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                         \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[i], acc[i][j], 0, 0, 0);
+#ifdef W8S_STALL_PROBE
+    // diagnostic build (-DW8S_STALL_PROBE, tools/stall_probe.sh): shader-clock cycles every wave spends in the four waits of a K step,
+    // summed over the tile and stored in place of the time stamps: {LDS reads of set 0, LDS reads of set 1, vmcnt (tile kt+1 landed),
+    // barrier}.  Each sample costs one s_memtime round trip (calibrated here and subtracted).
+    unsigned long long pq0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long pq1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned pcal = (unsigned)(pq1 - pq0);
+    unsigned st_l0 = 0, st_l1 = 0, st_vm = 0, st_bar = 0;
+#define W8S_PROBE_T(v) unsigned long long v = __builtin_amdgcn_s_memtime();
+#define W8S_PROBE_ACC(dst, a, b) { const unsigned dd = (unsigned)((b) - (a)); dst += dd > pcal ? dd - pcal : 0u; }
+#else
+#define W8S_PROBE_T(v)
+#define W8S_PROBE_ACC(dst, a, b)
+#endif
     // tile 0 is visible (the caller's barrier); tiles 0 and 1 were staged, soffA / soffB point at tile 1
     W8S_READ(fa0, fb0, a_cur, bimg, 0)
     for (int kt = 0; kt < nk; ++kt) {
         char* tB = bimg + (kt & 1) * W8_OPB;
         const bool live2 = kt + 2 < nk;
         soffA += stepA; soffB += stepB;          // tile kt + 2
+        W8S_PROBE_T(q0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W8S_PROBE_T(q1)
         __builtin_amdgcn_sched_barrier(0);
-        W8S_READ(fa1, fb1, a_cur, tB, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        W8S_MFMA(fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        la.template issue2<0>(a_fill, wave, soffA, live2); la.template issue2<2>(a_fill, wave, soffA, live2);
+        // The sub-step's 28 (24) MFMAs go out in four quarters (one B fragment each); behind each quarter the wave issues a quarter of the
+        // OTHER sub-step's fragment reads and one of its four LDS-DMA pieces.  Issued as clusters outside the burst (round 2) the 8 DMA
+        // pieces and 22 reads of a K step cost both waves of a SIMD ~10 % of the step with the matrix pipe idle (same box, one call:
+        // plain store 122 -> 116 us per 4-round launch, roofline.frac +0.012).  Accumulators are independent: the order of the MFMAs
+        // does not change any sum.
+        constexpr int NRD = RBW + 4, RPQ = (NRD + 3) / 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = j * RPQ; r < (j + 1) * RPQ && r < NRD; ++r) {
+                if (r < 4) fb1[r] = w8_frag<BT>(tB, nbk + r, 1, lane);
+                else fa1[r - 4] = w8_frag<AT>(a_cur, ab + r - 4, 1, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            la.issue1(a_fill, wave, soffA, live2, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        W8S_PROBE_T(q2)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W8S_PROBE_T(q3)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // all but A(kt+2): tile kt+1 has landed (this wave's pieces)
+        W8S_PROBE_T(q4)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        lb.template issue2<0>(tB, wave, soffB, live2); lb.template issue2<2>(tB, wave, soffB, live2);
-        if (kt + 1 < nk) { W8S_READ(fa0, fb0, a_nxt, bimg + ((kt & 1) ^ 1) * W8_OPB, 0) }
-        __builtin_amdgcn_sched_barrier(0);
-        W8S_MFMA(fa1, fb1)
-        __builtin_amdgcn_sched_barrier(0);
+        W8S_PROBE_T(q5)
+#ifdef W8S_STALL_PROBE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        W8S_PROBE_ACC(st_l0, q0, q1) W8S_PROBE_ACC(st_l1, q2, q3) W8S_PROBE_ACC(st_vm, q3, q4) W8S_PROBE_ACC(st_bar, q4, q5)
+        {
+            const char* tBn = bimg + ((kt & 1) ^ 1) * W8_OPB;
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (more) {
+#pragma unroll
+                    for (int r = j * RPQ; r < (j + 1) * RPQ && r < NRD; ++r) {
+                        if (r < 4) fb0[r] = w8_frag<BT>(tBn, nbk + r, 0, lane);
+                        else fa0[r - 4] = w8_frag<AT>(a_nxt, ab + r - 4, 0, lane);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                lb.issue1(tB, wave, soffB, live2, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
     }
 #undef W8S_READ
-#undef W8S_MFMA
+#undef W8S_PROBE_T
+#undef W8S_PROBE_ACC
     // the tail iterations issued out-of-range pieces (zeros) into the rings: none may land in another wave's epilogue block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef W8S_STALL_PROBE
+    if ((d.flags & SCL_GEMM_STAMPS) && lane == 0 && blockIdx.x < 4096 && blockIdx.z == 0) {
+        auto c16 = [](unsigned v) { return (unsigned long long)(v > 0xFFFFu ? 0xFFFFu : v); };
+        scl_gemm_stamps[blockIdx.x * 8 + wave] = c16(st_l0 >> 2) | (c16(st_l1 >> 2) << 16) | (c16(st_vm >> 2) << 32) | (c16(st_bar >> 2) << 48);
+    }
+#else
     w8_stamp(d, 2, lane, wave);
+#endif
     {
         const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
@@ -368,10 +436,12 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
             w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
         }
     }
+#ifndef W8S_STALL_PROBE
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
         w8_stamp(d, 3, lane, wave);
     }
+#endif
 }
 
 template <bool AT, bool BT, int RB0, int RB1>
@@ -380,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
+#ifndef W8S_STALL_PROBE
     w8_stamp(d, 0, lane, wave);
+#endif
     // experiment (SCL_W8_STAGGER, units of s_sleep 127 ~ 3.9 us): the first-round blocks of every other XCD start late, so that the
     // epilogues of the two halves of the chip do not hit HBM at the same moment for the rest of the launch
     if ((d.debug >> 8) && (blockIdx.x & 1) && blockIdx.x < 256 && blockIdx.z == 0) {
@@ -414,7 +486,9 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     la.template issue2<0>(smem + W8_OPB, wave, soffA, nk > 1); la.template issue2<2>(smem + W8_OPB, wave, soffA, nk > 1);
     lb.template issue2<0>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1); lb.template issue2<2>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef W8S_STALL_PROBE
     w8_stamp(d, 1, lane, wave);
+#endif
     __builtin_amdgcn_s_barrier();
     if (RB0 == RB1) {
         w8s_body<AT, BT, RB0>(d, smem, la, lb, nk, soffA, soffB, wr * RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
