@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libscl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
-         "-fno-gpu-rdc"] + os.environ.get("SCL_BUILD_DEFINES", "").split()      # e.g. -DW8S_STALL_PROBE (diagnostic builds, tools/stall_probe.sh)
+         "-fno-gpu-rdc"] + os.environ.get("SCL_BUILD_DEFINES", "").split()      # extra -D switches for A/B builds of one kernel (same-box comparisons)
 
 
 def _sources():

@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_kernel(const GemmK d) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
 
     const int nk_total = (d.K + BK - 1) / BK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kbegin = ksplit * nk_per * BK;
     int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
@@ -295,10 +295,10 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
     tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = (d.K + BK - 1) / BK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kbegin = ksplit * nk_per * BK;
     int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_big_kernel(const GemmK d) {
     tile_coords(blockIdx.x, gridDim.x, (d.M + BIG_BM - 1) / BIG_BM, tiles_n, tm, tn);
     const int m0 = tm * BIG_BM, n0 = tn * BN;
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = (d.K + BK - 1) / BK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kbegin = ksplit * nk_per * BK;
     int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
@@ -544,10 +544,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_p8_kernel(const GemmK d) {
     tile_coords(blockIdx.x, gridDim.x, (d.M + P8_BM - 1) / P8_BM, tiles_n, tm, tn);
     const int m0 = tm * P8_BM, n0 = tn * P8_BN;
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = (d.K + BK - 1) / BK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kbegin = ksplit * nk_per * BK;
     int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;

@@ -69,8 +69,11 @@ __device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, in
     const int first_m = group * GROUP_M;
     const int gsize = min(tiles_m - first_m, GROUP_M);
     const int in_group = tile - group * per_group;
-    tm = first_m + in_group % gsize;
-    tn = in_group / gsize;
+    // block-uniform results, but the integer divisions above run on the vector ALU and the compiler keeps everything derived from them
+    // (K offsets of the LDS-DMA pieces, output bases) in VGPRs: a buffer load whose scalar offset sits in a VGPR becomes a waterfall loop
+    // (readfirstlane + compare + exec mask + branch, per instruction).  Hand the values back as SGPRs.
+    tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsize);
+    tn = __builtin_amdgcn_readfirstlane(in_group / gsize);
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -119,6 +122,32 @@ __device__ __forceinline__ bf16x8 frag_t_raw(const char* tile, int colblk, int k
 // slow).  Here the fragments are read-write operands of the wait, so every use of them depends on it.
 __device__ __forceinline__ void lds_wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+}
+
+// Counted LDS wait: at most n LDS operations (ds_read_b128 = 1, a frag_t_raw fragment = 2) still outstanding.  LDS operations retire in
+// order, so this releases the OLDEST reads while younger ones (the other sub-step's fragments) stay in flight.  n is a constant after
+// unrolling; the counter has 4 bits.
+__device__ __forceinline__ void lds_wait_upto(int n) {
+    // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; 0xC07F leaves vmcnt and expcnt unconstrained.
+    // The builtin (not inline asm) so that the compiler's own wait insertion sees it and adds nothing redundant behind it.
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0xC77F); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0xCB7F); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0xCC7F); break;
+        case 13: __builtin_amdgcn_s_waitcnt(0xCD7F); break;
+        case 14: __builtin_amdgcn_s_waitcnt(0xCE7F); break;
+        default: __builtin_amdgcn_s_waitcnt(0xCF7F); break;
+    }
 }
 
 // element-wise epilogue for edge tiles / unaligned outputs (rare path, kept out of line)

@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
     tile_coords(blockIdx.x, gridDim.x, (d.M + TM - 1) / TM, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * TM, n0 = tn * TM;
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = (d.K + FBK - 1) / FBK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kbegin = ksplit * nk_per * FBK;
     int kend = kbegin + nk_per * FBK; if (kend > d.K) kend = d.K;
     const int nk = kend > kbegin ? (kend - kbegin + FBK - 1) / FBK : 0;

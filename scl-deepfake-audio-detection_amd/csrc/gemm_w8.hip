@@ -251,10 +251,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
     const int m0 = tm * d.tile_m, n0 = tn * W8_BN;
     const int mlimit = min(d.M, m0 + d.tile_m);
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = d.K / BK;                                  // K % 64 == 0 (checked on the host)
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kt0 = ksplit * nk_per;
     const int nk = max(0, min(nk_per, nk_total - kt0));
     const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
@@ -306,6 +306,63 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
 //     wait(set 1) | vmcnt(4): tile t+1 landed | BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
 //     4 x { 1/4 of read set 0 <- tile t+1, k 0..31 | 1/4 of MFMA set 1 | 1 of 4 DMA pieces B(t+2) -> B image of tile t }
 // A pieces have two K steps to land, B pieces one.  Same K order per output element: bit-identical to the other kernels.
+// Fragment reads of the single-barrier loop with compile-time indices.  Kernels with a transposed operand read it with inline-asm
+// ds_read_b64_tr_b16 (frag_t_raw: the builtin would drain the LDS-DMA queue) which the compiler's lgkmcnt bookkeeping does not see; if
+// their K-contiguous operand used plain loads, the compiler would count only those and wait far too early (it believes fewer
+// operations are in flight than there are).  So in those kernels EVERY fragment read is inline asm and the loop's counted waits
+// (lds_wait_upto) are the only ones; the kernel without transposed operands keeps plain loads and the compiler's own (exact) waits.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128_raw(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <bool AT, bool BT, int RBW>
+struct W8SRead {
+    static constexpr bool RAW = AT || BT;
+    // LDS byte address of lane's 16 bytes of row block gb, 32-deep sub-step ks (frag_k's formula; + 2048 per further row block)
+    static __device__ __forceinline__ unsigned kaddr(const char* img, int gb, int ks, int lane) {
+        const int row = gb * 16 + (lane & 15);
+        const int c = 4 * ks + (lane >> 4);
+        return (unsigned)(uintptr_t)(lds_void*)(img + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    }
+    template <int R, int REND>
+    static __device__ __forceinline__ void step(bf16x8 (&FA)[RBW], bf16x8 (&FB)[4], const char* TA, const char* TB, unsigned ka, unsigned kb,
+                                                int ab, int nbk, int ks, int lane) {
+        if constexpr (R < REND) {
+            if constexpr (R == 0 || (R > RBW)) {
+                constexpr int j = R == 0 ? 0 : R - RBW;
+                if constexpr (BT) FB[j] = frag_t_raw(TB + ((nbk + j) >> 3) * TILE_BYTES, (nbk + j) & 7, ks, lane);
+                else if constexpr (RAW) FB[j] = lds_b128_raw<j * 2048>(kb);
+                else FB[j] = frag_k(TB, nbk + j, ks, lane);
+            } else {
+                constexpr int i = R - 1;
+                if constexpr (AT) FA[i] = frag_t_raw(TA + ((ab + i) >> 3) * TILE_BYTES, (ab + i) & 7, ks, lane);
+                else if constexpr (RAW) FA[i] = lds_b128_raw<i * 2048>(ka);
+                else FA[i] = frag_k(TA, ab + i, ks, lane);
+            }
+            if (RAW) __builtin_amdgcn_sched_barrier(0);
+            step<R + 1, REND>(FA, FB, TA, TB, ka, kb, ab, nbk, ks, lane);
+        }
+    }
+    // fragments R0 .. R1-1 of the set of sub-step ks of images TA / TB.  ORDERED: also the plain loads keep this order (prologue only)
+    template <int R0, int R1, bool ORDERED>
+    static __device__ __forceinline__ void go(bf16x8 (&FA)[RBW], bf16x8 (&FB)[4], const char* TA, const char* TB, int ab, int nbk, int ks, int lane) {
+        if constexpr (R0 < R1) {
+            unsigned ka = 0, kb = 0;
+            if constexpr (RAW && !AT) ka = kaddr(TA, ab, ks, lane);
+            if constexpr (RAW && !BT) kb = kaddr(TB, nbk, ks, lane);
+            if constexpr (ORDERED && !RAW) {
+                step<R0, R0 + 1>(FA, FB, TA, TB, ka, kb, ab, nbk, ks, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                go<R0 + 1, R1, true>(FA, FB, TA, TB, ab, nbk, ks, lane);
+            } else {
+                step<R0, R1>(FA, FB, TA, TB, ka, kb, ab, nbk, ks, lane);
+            }
+        }
+    }
+};
+
 template <bool AT, bool BT, int RBW>
 __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typename W8Sel<AT>::type& la, const typename W8Sel<BT>::type& lb,
                                          int nk, unsigned soffA, unsigned soffB, int ab, int m0, int n0, int mlimit,
@@ -320,105 +377,84 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
     const int nbk = wc * 4;
     char* const bimg = smem + W8_NA * W8_OPB;
     char *a_cur = smem, *a_nxt = smem + W8_OPB, *a_fill = smem + 2 * W8_OPB;
-#define W8S_READ(FA, FB, TA, TB, KS)                                                        \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) FB[j] = w8_frag<BT>(TB, nbk + j, KS, lane); \
-    _Pragma("unroll") for (int i = 0; i < RBW; ++i) FA[i] = w8_frag<AT>(TA, ab + i, KS, lane);
-#ifdef W8S_STALL_PROBE
-    // diagnostic build (-DW8S_STALL_PROBE, tools/stall_probe.sh): shader-clock cycles every wave spends in the four waits of a K step,
-    // summed over the tile and stored in place of the time stamps: {LDS reads of set 0, LDS reads of set 1, vmcnt (tile kt+1 landed),
-    // barrier}.  Each sample costs one s_memtime round trip (calibrated here and subtracted).
-    unsigned long long pq0 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    unsigned long long pq1 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned pcal = (unsigned)(pq1 - pq0);
-    unsigned st_l0 = 0, st_l1 = 0, st_vm = 0, st_bar = 0;
-#define W8S_PROBE_T(v) unsigned long long v = __builtin_amdgcn_s_memtime();
-#define W8S_PROBE_ACC(dst, a, b) { const unsigned dd = (unsigned)((b) - (a)); dst += dd > pcal ? dd - pcal : 0u; }
-#else
-#define W8S_PROBE_T(v)
-#define W8S_PROBE_ACC(dst, a, b)
-#endif
+    // Fragment r of a sub-step's set, in the order the MFMA quarters need them: B fragment 0, the RBW A fragments, B fragments 1..3
+    // (W8SRead).  A K-contiguous fragment is one ds_read_b128, a transposed one two ds_read_b64_tr_b16 (OPA / OPB LDS operations:
+    // lgkmcnt counts operations).
+    constexpr int NRD = RBW + 4, OPA = AT ? 2 : 1, OPB = BT ? 2 : 1;
+    // reads issued before quarter 0 / 1 / 2 (cumulative), none before quarter 3: the last read of a set has a quarter of MFMAs to
+    // complete before anything waits for it (3 / 3 / 3 / 2 measured equal)
+    constexpr int RQ0 = 4, RQ1 = 8, RQ2 = NRD;
+    typedef W8SRead<AT, BT, RBW> RD;
+    // LDS operations of the first n fragments of a set
+    auto ops_upto = [](int n) constexpr { return (n > 0 ? OPB : 0) + (n > 1 ? (n - 1 < RBW ? n - 1 : RBW) * OPA : 0) + (n > RBW + 1 ? (n - RBW - 1) * OPB : 0); };
     // tile 0 is visible (the caller's barrier); tiles 0 and 1 were staged, soffA / soffB point at tile 1
-    W8S_READ(fa0, fb0, a_cur, bimg, 0)
+    lds_wait_upto(0);      // no scalar load may be pending when the loop starts: the compiler would answer with lgkmcnt(0) inside it
+    __builtin_amdgcn_sched_barrier(0);
+    RD::template go<0, NRD, true>(fa0, fb0, a_cur, bimg, ab, nbk, 0, lane);
     for (int kt = 0; kt < nk; ++kt) {
         char* tB = bimg + (kt & 1) * W8_OPB;
         const bool live2 = kt + 2 < nk;
+#ifdef W8S_FAKE_A      // timing experiments only (results are wrong): the loop's pieces of one operand are out of range = no memory latency
+        const bool live2a = false;
+#else
+        const bool live2a = live2;
+#endif
+#ifdef W8S_FAKE_B
+        const bool live2b = false;
+#else
+        const bool live2b = live2;
+#endif
         soffA += stepA; soffB += stepB;          // tile kt + 2
-        W8S_PROBE_T(q0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W8S_PROBE_T(q1)
-        __builtin_amdgcn_sched_barrier(0);
-        // The sub-step's 28 (24) MFMAs go out in four quarters (one B fragment each); behind each quarter the wave issues a quarter of the
-        // OTHER sub-step's fragment reads and one of its four LDS-DMA pieces.  Issued as clusters outside the burst (round 2) the 8 DMA
+        // The sub-step's 28 (24) MFMAs go out in four quarters (one B fragment each); ahead of each quarter the wave issues part of the
+        // OTHER sub-step's fragment reads, behind it one LDS-DMA piece.  Issued as clusters outside the burst (round 2) the 8 DMA
         // pieces and 22 reads of a K step cost both waves of a SIMD ~10 % of the step with the matrix pipe idle (same box, one call:
         // plain store 122 -> 116 us per 4-round launch, roofline.frac +0.012).  Accumulators are independent: the order of the MFMAs
         // does not change any sum.
-        constexpr int NRD = RBW + 4, RPQ = (NRD + 3) / 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int r = j * RPQ; r < (j + 1) * RPQ && r < NRD; ++r) {
-                if (r < 4) fb1[r] = w8_frag<BT>(tB, nbk + r, 1, lane);
-                else fa1[r - 4] = w8_frag<AT>(a_cur, ab + r - 4, 1, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < RBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            la.issue1(a_fill, wave, soffA, live2, j);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        W8S_PROBE_T(q2)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W8S_PROBE_T(q3)
+        // Waits are COUNTED (LDS operations retire in order): quarter j of this half needs B fragment j of set 0 (quarter 0 also the
+        // A fragments), i.e. everything but the 3 - j last B fragments of the set read during the previous half, and none of the
+        // reads of set 1 issued since.
+#define W8S_Q_FIRST(j, R0, R1)                                                                                               \
+        RD::template go<R0, R1, false>(fa1, fb1, a_cur, tB, ab, nbk, 1, lane);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        lds_wait_upto((3 - (j)) * OPB + ops_upto(R1));                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        la.issue1(a_fill, wave, soffA, live2a, j);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);
+        W8S_Q_FIRST(0, 0, RQ0) W8S_Q_FIRST(1, RQ0, RQ1) W8S_Q_FIRST(2, RQ1, RQ2) W8S_Q_FIRST(3, RQ2, NRD)
+#undef W8S_Q_FIRST
+        lds_wait_upto(0);                                   // set 1 complete, and with it this wave's last read of tile kt
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // all but A(kt+2): tile kt+1 has landed (this wave's pieces)
-        W8S_PROBE_T(q4)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        W8S_PROBE_T(q5)
-#ifdef W8S_STALL_PROBE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        W8S_PROBE_ACC(st_l0, q0, q1) W8S_PROBE_ACC(st_l1, q2, q3) W8S_PROBE_ACC(st_vm, q3, q4) W8S_PROBE_ACC(st_bar, q4, q5)
-        {
-            const char* tBn = bimg + ((kt & 1) ^ 1) * W8_OPB;
-            const bool more = kt + 1 < nk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (more) {
-#pragma unroll
-                    for (int r = j * RPQ; r < (j + 1) * RPQ && r < NRD; ++r) {
-                        if (r < 4) fb0[r] = w8_frag<BT>(tBn, nbk + r, 0, lane);
-                        else fa0[r - 4] = w8_frag<AT>(a_nxt, ab + r - 4, 0, lane);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < RBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                lb.issue1(tB, wave, soffB, live2, j);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        const char* tBn = bimg + ((kt & 1) ^ 1) * W8_OPB;
+        // (on the last K step these reads fetch whatever the next images hold and nothing uses them: cheaper than a branch per quarter)
+        // B(kt+2) -> the B image the barrier just retired, two pieces behind each of quarters 0 and 1: it has to land by the NEXT barrier
+        // (one K step; A pieces have 1.5) and a piece per quarter, the last one 0.6 step before that barrier, cost 4 % (same box, one
+        // call: plain store 120.6 -> 116.2 us, roofline.frac 0.355 -> 0.366).  All four behind quarter 0, two of them ahead of it, or
+        // A(kt+3) moved into quarters 2 and 3 of this half (two steps of lead): equal or slower.
+#define W8S_B_ISSUE(j) if ((j) < 2) { lb.issue1(tB, wave, soffB, live2b, 2 * (j)); lb.issue1(tB, wave, soffB, live2b, 2 * (j) + 1); }
+#define W8S_Q_SECOND(j, R0, R1)                                                                                              \
+        RD::template go<R0, R1, false>(fa0, fb0, a_nxt, tBn, ab, nbk, 0, lane);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        W8S_B_ISSUE(j)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);
+        W8S_Q_SECOND(0, 0, RQ0) W8S_Q_SECOND(1, RQ0, RQ1) W8S_Q_SECOND(2, RQ1, RQ2) W8S_Q_SECOND(3, RQ2, NRD)
+#undef W8S_Q_SECOND
+#undef W8S_B_ISSUE
         char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
     }
-#undef W8S_READ
-#undef W8S_PROBE_T
-#undef W8S_PROBE_ACC
     // the tail iterations issued out-of-range pieces (zeros) into the rings: none may land in another wave's epilogue block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#ifdef W8S_STALL_PROBE
-    if ((d.flags & SCL_GEMM_STAMPS) && lane == 0 && blockIdx.x < 4096 && blockIdx.z == 0) {
-        auto c16 = [](unsigned v) { return (unsigned long long)(v > 0xFFFFu ? 0xFFFFu : v); };
-        scl_gemm_stamps[blockIdx.x * 8 + wave] = c16(st_l0 >> 2) | (c16(st_l1 >> 2) << 16) | (c16(st_vm >> 2) << 32) | (c16(st_bar >> 2) << 48);
-    }
-#else
     w8_stamp(d, 2, lane, wave);
-#endif
     {
         const long long cbase = z1 * d.c_bs1 + z2 * d.c_bs2 + (long long)ksplit * d.c_split_stride;
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
@@ -436,12 +472,10 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
             w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, hi, RBW - 4, wlds, wextra, m0 + (ab + 4) * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0 ? cs0 + d.N : nullptr);
         }
     }
-#ifndef W8S_STALL_PROBE
     if (d.flags & SCL_GEMM_STAMPS) {      // only the diagnostic stamp needs the stores drained: a block retires with them in flight,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // and the next block's prologue on this CU overlaps the drain
         w8_stamp(d, 3, lane, wave);
     }
-#endif
 }
 
 template <bool AT, bool BT, int RB0, int RB1>
@@ -450,9 +484,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
-#ifndef W8S_STALL_PROBE
     w8_stamp(d, 0, lane, wave);
-#endif
     // experiment (SCL_W8_STAGGER, units of s_sleep 127 ~ 3.9 us): the first-round blocks of every other XCD start late, so that the
     // epilogues of the two halves of the chip do not hit HBM at the same moment for the rest of the launch
     if ((d.debug >> 8) && (blockIdx.x & 1) && blockIdx.x < 256 && blockIdx.z == 0) {
@@ -464,10 +496,10 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     const int m0 = tm * d.tile_m, n0 = tn * W8_BN;
     const int mlimit = min(d.M, m0 + d.tile_m);
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = d.K / BK;
-    const int nk_per = (nk_total + d.splitk - 1) / d.splitk;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
     const int kt0 = ksplit * nk_per;
     const int nk = max(0, min(nk_per, nk_total - kt0));
     const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
@@ -486,9 +518,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     la.template issue2<0>(smem + W8_OPB, wave, soffA, nk > 1); la.template issue2<2>(smem + W8_OPB, wave, soffA, nk > 1);
     lb.template issue2<0>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1); lb.template issue2<2>(smem + (W8_NA + 1) * W8_OPB, wave, soffB, nk > 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#ifndef W8S_STALL_PROBE
     w8_stamp(d, 1, lane, wave);
-#endif
     __builtin_amdgcn_s_barrier();
     if (RB0 == RB1) {
         w8s_body<AT, BT, RB0>(d, smem, la, lb, nk, soffA, soffB, wr * RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
@@ -683,17 +713,21 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        if constexpr (RB0 == 7) {
+            (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+            (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+            (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        }
         attr_set = true;
     }
     const dim3 block(512);
-    if (mode == 2) {      // persistent: grid = resident blocks (never both operands transposed: those launches take the ping-pong loop)
-        if (!at && !bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-        else if (!at && bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
-        else SCL_LAUNCH((scl_gemm_w8p_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
-        return;
+    if constexpr (RB0 == 7) {      // the persistent loop exists for the 208-row tile only (scl_gemm_w8_launch never asks for it with 256 rows)
+        if (mode == 2) {      // grid = resident blocks (never both operands transposed: those launches take the ping-pong loop)
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
+            else SCL_LAUNCH((scl_gemm_w8p_kernel<true, false, RB0, RB1>), grid, block, W8_LDS, s, k);
+            return;
+        }
     }
     if (mode == 1) {
         if (!at && !bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
@@ -792,8 +826,8 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         const long long rounds = (plan.tiles + ncu - 1) / ncu;
         long long G = pv >= 8 ? (pv & ~7) : ((((plan.tiles + rounds - 1) / rounds) + 7) & ~7ll);      // equal rounds on every block, a multiple of 8
         if (G > (ncu & ~7ll) && pv < 8) G = ncu & ~7ll;
-        // automatic mode (1): the 208-row variant only — the 256-row one spills under the persistent loop's register pressure (2 x slower)
-        if ((pv >= 8 || (rounds >= 2 && plan.variant == 0)) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
+        // the 208-row variant only — the 256-row one spilled under the persistent loop's register pressure (2 x slower) and is not built
+        if (plan.variant == 0 && (pv >= 8 || rounds >= 2) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
     }
     if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
     else w8_launch_rb<8, 8>(k, at, bt, g, s, mode);

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_x2_kernel(const GemmK d) {
     const int m0 = tm * d.tile_m, n0 = tn * X2_BN;
     const int mlimit = min(d.M, m0 + d.tile_m);
     int z = blockIdx.z;
-    const int ksplit = z % d.splitk; z /= d.splitk;
-    const int z1 = z / d.nb2, z2 = z - z1 * d.nb2;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = d.K / 32;                                  // K % 32 == 0 (checked on the host)
     // split-K slabs begin where the 64-deep kernels' slabs begin, so that a slab holds the same partial sum whichever kernel wrote it
     const int nk_per = 2 * (((d.K + 63) / 64 + d.splitk - 1) / d.splitk);

@@ -111,29 +111,7 @@ int main(int argc, char** argv) {
             printf(" %s %7.1f us %6.0f TF |", vars[v].name, med[v], fl / med[v] / 1e6);
         }
         printf(" w8/t128 x%.2f  bitwise p8:%d w8:%d\n", med[0] / med[2], (int)same[1], (int)same[2]);
-        if (getenv("STALLS")) {   // library built with -DW8S_STALL_PROBE (tools/stall_probe.sh): per-wave cycles in the K loop's waits
-            SclGemmDesc d = desc(1, SCL_GEMM_FORCE_W8 | SCL_GEMM_STAMPS);
-            scl_gemm_bf16(&d, st); CK(hipStreamSynchronize(st));
-            const long long tn_ = (c.N + 255) / 256, n208 = (c.M + 207) / 208;
-            const int nb = (int)std::min(4096ll, n208 * tn_);
-            std::vector<unsigned long long> sp(8 * (size_t)nb);
-            if (scl_debug_gemm_stamps(sp.data(), nb) == 0) {
-                const char* nm[4] = {"lds0", "lds1", "vmcnt", "barrier"};
-                printf("    stalls(%d blocks, %d K steps; cycles per K step, median over blocks [p90]):\n", nb, c.K / 64);
-                for (int w = 0; w < 8; ++w) {
-                    printf("      wave %d:", w);
-                    double tot = 0;
-                    for (int f = 0; f < 4; ++f) {
-                        std::vector<double> v;
-                        for (int b = 0; b < nb; ++b) v.push_back(4.0 * ((sp[8 * (size_t)b + w] >> (16 * f)) & 0xFFFF) / (c.K / 64));
-                        std::sort(v.begin(), v.end());
-                        printf(" %s %6.0f [%6.0f]", nm[f], v[v.size() / 2], v[(size_t)(0.9 * (v.size() - 1))]);
-                        tot += v[v.size() / 2];
-                    }
-                    printf("  sum %6.0f\n", tot);
-                }
-            }
-        } else if (getenv("STAMPS")) {   // one stamped launch of the wide kernel: where a block's time goes
+        if (getenv("STAMPS")) {   // one stamped launch of the wide kernel: where a block's time goes
             SclGemmDesc d = desc(1, SCL_GEMM_FORCE_W8 | SCL_GEMM_STAMPS);
             scl_gemm_bf16(&d, st); CK(hipStreamSynchronize(st));
             const long long tn_ = (c.N + 255) / 256, z_ = c.splitk;

@@ -1,7 +1,7 @@
 """ISA audit for kernels that read MFMA fragments with inline-asm `ds_read_b64_tr_b16` (frag_t_raw, csrc/gemm_common.h; pw_read,
 csrc/posconv.hip): those reads are asynchronous and invisible to the compiler's lgkmcnt bookkeeping, so nothing may touch their
 destination registers before an explicit `s_waitcnt lgkmcnt(0)`.  The script compiles the given .hip files to gfx950 assembly and walks
-every kernel linearly: a vector instruction that names a register with a raw tr-read still pending is reported.
+every kernel (loops twice): a vector instruction that names the destination of an LDS read still in flight is reported.
 (Round 3: it found an MFMA of scl_gemm_dma_kernel / scl_gemm_big_kernel that the scheduler had lifted above a bare
 `asm volatile("s_waitcnt lgkmcnt(0)")`; the wait now takes the fragments as read-write operands.)  Kernels that use the BUILTIN tr read
 (attention.hip) are tracked by the compiler, wait with counted lgkmcnt(N), and are reported as false positives here.
@@ -22,31 +22,71 @@ def regs(tok):
 
 
 def audit(asm_text):
+    """LDS operations retire in order, so `s_waitcnt lgkmcnt(N)` guarantees everything but the N youngest operations (scalar loads share
+    the counter and return out of order: every one still in flight is assumed to be among the completed ones — the conservative side).
+    Every kernel is walked in program order, and every backward branch is followed once more with the state at the branch, so that
+    what a loop iteration leaves in flight meets the waits at the top of the next one."""
     bad = 0
     for km in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
         name, body = km.group(1), km.group(2)
         if "ds_read_b64_tr_b16" not in body:
             continue
-        pending, hazards, n_tr, examples = set(), 0, 0, []
+        prog, labels = [], {}
         for line in body.splitlines():
             line = line.split(";")[0].strip()
-            if not line or line.endswith(":") or line.startswith("."):
+            if not line or line.startswith("."):
+                if line.endswith(":"):
+                    labels[line[:-1]] = len(prog)
                 continue
+            if line.endswith(":"):
+                labels[line[:-1]] = len(prog)
+                continue
+            prog.append(line)
+        queue, hazards, n_tr, examples, taken = [], 0, 0, [], set()      # queue: (kind, registers) oldest first
+        pc = 0
+        while pc < len(prog):
+            line = prog[pc]
             parts = line.replace(",", " ").split()
             op, args = parts[0], parts[1:]
-            if op == "ds_read_b64_tr_b16":
-                n_tr += 1
-                pending |= regs(args[0])
+            pc += 1
+            if op.startswith("ds_"):
+                dst = regs(args[0]) if op.startswith("ds_read") else set()
+                if op == "ds_read_b64_tr_b16":
+                    n_tr += 1
+                queue.append(("lds", dst))
+                continue
+            if op.startswith("s_load") or op.startswith("s_buffer_load") or op in ("s_memtime", "s_memrealtime"):
+                queue.append(("smem", set()))
                 continue
             if op == "s_waitcnt":
-                if "lgkmcnt(0)" in line:
-                    pending = set()
+                m = re.search(r"lgkmcnt\((\d+)\)", line)
+                if m:
+                    n = int(m.group(1))
+                    if n == 0:
+                        queue = []
+                    else:
+                        done = len(queue) - n - sum(1 for k, _ in queue if k == "smem")
+                        while done > 0 and queue:
+                            k = next((x for x, e in enumerate(queue) if e[0] == "lds"), None)
+                            if k is None:
+                                break
+                            queue.pop(k)
+                            done -= 1
+                continue
+            if op.startswith("s_cbranch") or op == "s_branch":
+                tgt = args[-1]
+                if tgt in labels and labels[tgt] < pc and (pc, tgt) not in taken:
+                    taken.add((pc, tgt))
+                    pc = labels[tgt]
                 continue
             if op.startswith("s_"):
                 continue
             used = set()
             for t in args:
                 used |= regs(t)
+            pending = set()
+            for k, r in queue:
+                pending |= r
             if used & pending:
                 hazards += 1
                 if len(examples) < 2:
