@@ -177,7 +177,11 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, typename W8S
     for (int kt = 0; kt < nk; ++kt) {
         const char* tA = a_cur;
         char* tB = bimg + (kt & 1) * W8_OPB;
+#ifdef W8_FAKE_AB      // timing experiment only (wrong results): the loop's pieces go out of range = no memory latency
+        const bool live2 = false;
+#else
         const bool live2 = kt + 2 < nk;
+#endif
         soffA += stepA; soffB += stepB;          // tile kt + 2
         // ---- p0
 #pragma unroll
@@ -212,7 +216,7 @@ __device__ __forceinline__ void w8_body(const GemmK& d, char* smem, typename W8S
         lb.template issue2<0>(tB, wave, soffB, live2);
         W8_MFMA_PHASE(1, 1, fb1, NH)
         // ---- p3
-        lb.template issue2<2>(tB, wave, soffB, live2);
+        lb.template issue2<2>(tB, wave, soffB, live2);      // (both B pairs at p2: 3-6 % slower on the weight-gradient shapes, same box)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but tile kt+2's 8 pieces: tile kt+1 has landed (this wave's pieces)
         W8_MFMA_PHASE(1, 0, fb0, NH)
         char* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
