@@ -795,11 +795,14 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         if (maxoff * ((k.flags & SCL_GEMM_R_F32) ? 4 : 2) >= 0xFFFFFF00ll) k.debug |= 2;
     }
     const dim3 grid((unsigned)plan.tiles, 1, (unsigned)zdim);
-    // 1: single barrier per K step, 0: two-barrier ping-pong.  A/B on MI355X (profiles/r2_gemm_ab.txt): equal within 3 % on the forward
-    // and dgrad shapes (single barrier ahead), the ping-pong 2-9 % ahead when both operands are transposed (wgrads: twice the LDS
-    // read instructions per fragment)
+    // 1: single barrier per K step (default), 0: two-barrier ping-pong.  Round 2 measured the ping-pong 2-9 % ahead when both operands
+    // are transposed (weight gradients: twice the LDS read instructions per fragment); with the single-barrier loop's MFMA quarters,
+    // counted waits and early B pieces (round 3) it is the other way round — one call, tools/gemm_bench "wgrad sk4", ping-pong ->
+    // single barrier: qkv 110.4 -> 109.0, out 81.2 -> 72.2, fc1 111.9 -> 109.0, fc2 109.1 -> 102.5 us; whole step 49.2 -> 47.1 ms.
+    // The ping-pong loop stays for utterance-batched K rows (below) and as SCL_W8_MODE=0.
     const char* me = getenv("SCL_W8_MODE");
-    int mode = me ? atoi(me) : ((at && bt) ? 0 : 1);
+    int mode = (me && *me) ? atoi(me) : 1;
+    if (at && bt) { const char* mt = getenv("SCL_W8_MODE_TT"); if (mt && *mt) mode = atoi(mt); }      // A/B of the weight-gradient loop alone
     if (at && bt) {      // utterance-batched K rows (see scl_gemm_w8_plan): only the ping-pong loop computes per-step offsets
         if ((long long)k.A.rpb < (long long)k.K) { k.debug |= 4; mode = 0; }
         if ((long long)k.B.rpb < (long long)k.K) { k.debug |= 8; mode = 0; }
@@ -825,7 +828,7 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     const char* pe = getenv("SCL_GEMM_PERSIST");
     const int pv = pe ? atoi(pe) : 0;
     dim3 g = grid;
-    if (mode == 1 && pv > 0 && zdim == 1 && k.splitk == 1 && k.K / BK >= 3 && !(k.flags & SCL_GEMM_STAMPS)) {
+    if (mode == 1 && pv > 0 && !(at && bt) && zdim == 1 && k.splitk == 1 && k.K / BK >= 3 && !(k.flags & SCL_GEMM_STAMPS)) {
         const long long ncu = plan.ncu >= 8 ? plan.ncu : 256;
         const long long rounds = (plan.tiles + ncu - 1) / ncu;
         long long G = pv >= 8 ? (pv & ~7) : ((((plan.tiles + rounds - 1) / rounds) + 7) & ~7ll);      // equal rounds on every block, a multiple of 8

@@ -269,11 +269,14 @@ def test_gemm_speed_report(dev, capsys):
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K,splitk", [(12736, 1024, 1024, 1), (5128, 1288, 256, 1), (2184, 3072, 1024, 1), (1024, 4096, 12736, 4),
                                           (520, 776, 4096, 3), (200, 256, 64, 1), (1000, 200, 512, 1)])
-def test_wide_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
-    """The wide-tile ping-pong kernel (gemm_w8.hip: runtime row pitch, 7+6 / 8+8 row blocks per wave row, scalar-offset K
-    advance): same K order per output element as the 128x128 kernels => bit-identical, on ragged M / N edges, row pitches that
-    are not multiples of 16, split-K slabs with an uneven last slab, repeated to give a mis-ordered LDS read a chance to show.
+@pytest.mark.parametrize("loop", ["1", "0"])
+def test_wide_tile_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_t, M, N, K, splitk, loop):
+    """The wide-tile kernels (gemm_w8.hip: runtime row pitch, 7+6 / 8+8 row blocks per wave row, scalar-offset K advance), both K
+    loops (SCL_W8_MODE 1 = single barrier with counted LDS waits, the default for every layout; 0 = two-barrier ping-pong): same K
+    order per output element as the 128x128 kernels => bit-identical, on ragged M / N edges, row pitches that are not multiples of
+    16, split-K slabs with an uneven last slab, repeated to give a mis-ordered LDS read a chance to show.
     Memory behind the operands is NaN: a fetch past a row limit that is not range-checked to zero would poison the output."""
+    monkeypatch.setenv("SCL_W8_MODE", loop)
     A = _rand((M, K), dev, 51, 0.3); B = _rand((N, K), dev, 52, 0.3)
     def nanpad(mat):
         buf = torch.full((mat.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=dev)
