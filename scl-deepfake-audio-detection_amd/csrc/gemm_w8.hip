@@ -9,8 +9,12 @@
 //     fetched as zeros by the hardware range check (no memory traffic) and not stored.
 //   * 8 waves as 2 (M) x 4 (N).  Wave row 0 owns RB0 16-row blocks, wave row 1 owns RB1 (7 + 6 for the 208-row tile: the
 //     two waves that share a SIMD are one of each row, so every SIMD issues the same 13 x 4 MFMAs per 32-deep step; 8 + 8
-//     for the 256-row tile).  The two wave rows run half a phase apart (ping-pong): while one issues its MFMA burst under
-//     s_setprio(1), the other does its LDS fragment reads and LDS-DMA issues.
+//     for the 256-row tile).
+//   * Two K loops over the same LDS images, bit-identical results.  The DEFAULT for every layout is the single-barrier loop
+//     (w8s_body, further down: one barrier per 64-deep step, MFMA bursts in quarters with the other sub-step's fragment reads and
+//     the LDS-DMA pieces between them, counted LDS waits).  The two-barrier ping-pong (w8_body, described here) serves the
+//     utterance-batched K rows of the conv-stack weight gradients and SCL_W8_MODE=0: its two wave rows run half a phase apart —
+//     while one issues its MFMA burst under s_setprio(1), the other does its LDS fragment reads and LDS-DMA issues.
 //   * Staging is global -> LDS directly (buffer_load_dwordx4 ... lds), swizzles applied to the per-lane source address as in
 //     gemm.hip.  The per-lane byte offset is computed ONCE per tile; the K advance is the instruction's scalar offset (one
 //     s_add per K step; soffset is not part of the range check, so out-of-range lanes stay out of range).
@@ -305,11 +309,16 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8_kernel(const GemmK d) {
 // while the first fragments of tile t+1 are read.  Ablation of THIS loop (16 K steps, 208 x 256 tile, profiles/r2_gemm_ablation.txt):
 // all 22.9 us, MFMA only 17.6, LDS reads only 8.8, DMA only 11.1 (84 GB/s per CU), nothing 4.6 — the loop is MFMA-paced at the
 // 1.8-2.0 GHz the chip holds under this load; running wave row 1 half a step out of phase (read | MFMA swapped) measured +-2 %.
-// Per K step t:
-//     wait(set 0) | 4 x { 1/4 of read set 1 <- tile t, k 32..63 | 1/4 of MFMA set 0 | 1 of 4 DMA pieces A(t+2) -> A ring }
+// Per K step t (round 3; measurements of every step in profiles/r3_gemm_kloop_feed.txt):
+//     4 x { 4 / 4 / 3 / 0 reads of set 1 <- tile t, k 32..63 | counted wait: B fragment j of set 0 (j = 0: and the A fragments) |
+//           1/4 of MFMA set 0 | 1 of 4 DMA pieces A(t+2) -> A ring }
 //     wait(set 1) | vmcnt(4): tile t+1 landed | BARRIER (tile t+1 visible to all; every wave has retired its reads of tile t)
-//     4 x { 1/4 of read set 0 <- tile t+1, k 0..31 | 1/4 of MFMA set 1 | 1 of 4 DMA pieces B(t+2) -> B image of tile t }
-// A pieces have two K steps to land, B pieces one.  Same K order per output element: bit-identical to the other kernels.
+//     4 x { 4 / 4 / 3 / 0 reads of set 0 <- tile t+1, k 0..31 | 1/4 of MFMA set 1 | 2 / 2 / 0 / 0 DMA pieces B(t+2) -> B image of tile t }
+// A pieces have 1.5 K steps to land, B pieces one (the B image retires at this step's barrier and is needed at the next).  With the
+// loop's pieces issued out of range (no memory access, -DW8S_FAKE_A / _B) a 4-round launch takes 95 instead of 112 us: the L2 -> LDS
+// latency that 2 A tiles + 1 B tile in flight cannot cover is what separates this loop from its MFMA pace.
+// Same K order per output element: bit-identical to the other kernels.
+//
 // Fragment reads of the single-barrier loop with compile-time indices.  Kernels with a transposed operand read it with inline-asm
 // ds_read_b64_tr_b16 (frag_t_raw: the builtin would drain the LDS-DMA queue) which the compiler's lgkmcnt bookkeeping does not see; if
 // their K-contiguous operand used plain loads, the compiler would count only those and wait far too early (it believes fewer
