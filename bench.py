@@ -193,8 +193,9 @@ def main():
     n_launch, gemm_ms, gemm_flops = ops.prof_read(KID_GEMM)
     aug_launch, aug_ms, _ = ops.prof_read(KID_AUG)
     loss_val = float(last.item())
-    # seeded random init, labels 5:6: CE/bz + 2 x SupCon/bz is a few tenths; the resnet plugin's loss has no 1/bz (x batch)
-    hi = 2.0 * (B if args.model == "wav2vec2_resnet_nll" else 1.0)
+    # seeded random init, labels 5:6: CE/bz + 2 x SupCon/bz is a few tenths at batch 64 and grows as the batch shrinks (AASIST after 5 steps:
+    # 0.58 / 0.92 / 2.4 at batch 64 / 32 / 16); the resnet plugin's loss has no 1/bz (x batch)
+    hi = 2.0 * (B if args.model == "wav2vec2_resnet_nll" else max(1.0, 48.0 / B))
     assert loss_val == loss_val and 0.0 < loss_val < hi, "final loss %r outside the band of a seeded-random-init step" % loss_val
     if dp:
         t = torch.tensor([dt], device=dev)
