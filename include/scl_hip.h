@@ -170,6 +170,17 @@ int scl_gemm_splitk_finish(const SclGemmDesc* desc, const float* slabs, int nsla
 
 /* out[i] = sum_s slabs[s*stride + i]  (deterministic split-K combine). */
 int scl_reduce_slabs_f32(const float* slabs, float* out, int64_t n, int nslabs, int64_t stride, void* stream);
+/* up to SCL_SLAB_MAX_JOBS such combines in ONE launch, each with the summation order of scl_reduce_slabs_f32 (bit-identical): the four
+ * split-K weight gradients of an encoder layer (fc2, fc1, out_proj, q/k/v of the fairseq layer reached from model/xlsr.py:41) are
+ * combined by one launch at the end of the layer's backward instead of one launch behind every weight-gradient GEMM. */
+#define SCL_SLAB_MAX_JOBS 8
+typedef struct SclSlabJob {
+    const float* slabs;
+    float*       out;
+    int64_t      n, stride;
+    int32_t      nslabs, _pad;
+} SclSlabJob;
+int scl_reduce_slabs_multi(const SclSlabJob* jobs, int njobs, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* AASIST / ResNet back-end pieces over channels-last fp32 maps (csrc/nn.hip)                  */

@@ -319,6 +319,35 @@ __global__ __launch_bounds__(256) void colreduce_seg_kernel(const float* __restr
 // gradients + the residual linear's bias, twice; fc1 bias; q/k/v bias) were four ~10 us launches of 64-800 blocks each, latency-bound.
 // Block = 32 columns x 32 row lanes of one job; fixed summation order (row lane r adds rows r, r + 32, ...; the lanes are combined
 // 0..31) => deterministic.
+// Several split-K slab combines in one launch (scl_reduce_slabs_multi): every job keeps the grid, the element-to-thread map and the
+// summation order (slab 0, 1, 2, ...) it has alone in scl_reduce_slabs_f32 => the same bits; what goes away is three kernel boundaries
+// per encoder layer (~5 us each between dependent kernels on this GPU, tools/graph_gap_probe.py).
+struct SlabJobs { SclSlabJob job[SCL_SLAB_MAX_JOBS]; int first_block[SCL_SLAB_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(const SlabJobs J) {
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+    const SclSlabJob jb = J.job[j];
+    const int nb = J.first_block[j + 1] - J.first_block[j];
+    const int64_t i0 = ((int64_t)((int)blockIdx.x - J.first_block[j]) * blockDim.x + threadIdx.x) * 4;
+    const int64_t step = (int64_t)nb * blockDim.x * 4;
+    for (int64_t i = i0; i < jb.n; i += step) {
+        if (i + 4 <= jb.n) {
+            float4 s = *reinterpret_cast<const float4*>(jb.slabs + i);
+            for (int k = 1; k < jb.nslabs; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(jb.slabs + k * jb.stride + i);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            *reinterpret_cast<float4*>(jb.out + i) = s;
+        } else {
+            for (int64_t q = i; q < jb.n; ++q) {
+                float s = jb.slabs[q];
+                for (int k = 1; k < jb.nslabs; ++k) s += jb.slabs[k * jb.stride + q];
+                jb.out[q] = s;
+            }
+        }
+    }
+}
+
 struct ReduceJobs { SclReduceJob job[SCL_REDUCE_MAX_JOBS]; int first_block[SCL_REDUCE_MAX_JOBS + 1]; int njobs; };
 __global__ __launch_bounds__(1024) void colreduce_multi_kernel(const ReduceJobs J) {
     __shared__ float red[32][33];
@@ -497,6 +526,25 @@ extern "C" int scl_colreduce_seg_f32(const float* part, float* out, int nparts, 
     hipLaunchKernelGGL(colreduce_seg_kernel, dim3((C + 31) / 32, nseg), dim3(256), 0, (hipStream_t)stream, part, out, nparts, C, pstride,
                        accumulate, scratch, counters, out2, split);
     return scl_check_launch("scl_colreduce_seg_f32");
+}
+
+extern "C" int scl_reduce_slabs_multi(const SclSlabJob* jobs, int njobs, void* stream) {
+    SCL_REQUIRE(jobs && njobs >= 1 && njobs <= SCL_SLAB_MAX_JOBS, "reduce_slabs_multi: 1 .. %d jobs", SCL_SLAB_MAX_JOBS);
+    SlabJobs J;
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SclSlabJob& b = jobs[i];
+        SCL_REQUIRE(b.slabs && b.out && b.n > 0 && b.nslabs >= 1, "reduce_slabs_multi: job %d: bad arguments", i);
+        SCL_REQUIRE(((uintptr_t)b.slabs & 15) == 0 && ((uintptr_t)b.out & 15) == 0 && (b.stride & 3) == 0, "reduce_slabs_multi: job %d: alignment", i);
+        J.job[i] = b;
+        J.first_block[i] = blocks;
+        int nb = (int)((b.n / 4 + 255) / 256); if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;      // the grid scl_reduce_slabs_f32 gives the job
+        blocks += nb;
+    }
+    J.first_block[njobs] = blocks;
+    J.njobs = njobs;
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+    return scl_check_launch("scl_reduce_slabs_multi");
 }
 
 extern "C" int scl_colreduce_multi(const SclReduceJob* jobs, int njobs, void* stream) {

@@ -28,6 +28,10 @@ FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
 WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "1") != "0"
 # the (up to) four small column reductions that close a layer's backward in ONE launch (SCL_BATCH_REDUCE=0: one launch each)
 BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
+# the split-K slabs of a layer's four weight gradients are combined by ONE launch at the end of the layer's backward (each gradient keeps
+# its own slab buffer until then) instead of one launch behind every weight-gradient GEMM: 72 kernel boundaries per step less
+# (SCL_BATCH_SLABS=0: as before; bit-identical either way)
+BATCH_SLABS = os.environ.get("SCL_BATCH_SLABS", "1") != "0"
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
 POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
@@ -289,8 +293,9 @@ class Encoder:
         if self.wstream is not None:
             ops.stream_wait(torch.cuda.current_stream(), self.wstream)
 
-    def _wgrad(self, d, A, B_, out, Mo, No, Kr, **kw):
-        """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small."""
+    def _wgrad(self, d, A, B_, out, Mo, No, Kr, slot=None, **kw):
+        """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small.
+        slot (0..3, BATCH_SLABS): the slabs stay in their own buffer and the combine is queued for _flush_slabs (end of the layer)."""
         ksteps = (Kr + 63) // 64
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128) * kw.get("nb2", 1)
         sk = _splitk(tiles, ksteps)
@@ -309,11 +314,27 @@ class Encoder:
             ops.gemm(A, B_, out, Mo, No, Kr, a_t=True, b_t=True, **kw)
             return
         n = out.numel()
+        if BATCH_SLABS and slot is not None:
+            bufs = d.setdefault("slab_slots", {})
+            if slot not in bufs or bufs[slot].numel() < sk * n:
+                d.setdefault("slabs_keep", []).append(bufs.get(slot))   # recorded launch plans may still point into the old buffer
+                bufs[slot] = torch.empty(sk * n, dtype=torch.float32, device=self.dev)
+            ops.gemm(A, B_, bufs[slot], Mo, No, Kr, a_t=True, b_t=True, splitk=sk, c_split_stride=n, **kw)
+            d.setdefault("slab_jobs", []).append((bufs[slot], out, n, sk, n))
+            return
         if d["slab"] is None or d["slab"].numel() < sk * n:
             d.setdefault("slabs_keep", []).append(d["slab"])   # recorded launch plans may still point into the old slab
             d["slab"] = torch.empty(sk * n, dtype=torch.float32, device=self.dev)
         ops.gemm(A, B_, d["slab"], Mo, No, Kr, a_t=True, b_t=True, splitk=sk, c_split_stride=n, **kw)
         ops.reduce_slabs(d["slab"], out, n, sk, n)
+
+    def _flush_slabs(self, d):
+        """The queued split-K combines of this layer, one launch (on the stream the weight gradients ran on)."""
+        jobs = d.get("slab_jobs")
+        if jobs:
+            with self._side():
+                ops.reduce_slabs_multi(jobs)
+            d["slab_jobs"] = []
 
     def _bias_grad(self, d, dy, Mrows, N, gname):
         ops.colsum_reduce(dy, d["cs_part"], self.P.g(self.n(gname)), Mrows, N)
@@ -538,7 +559,7 @@ class Encoder:
             xin = d["xin"][n]
             # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
             with self._side():
-                self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M)
+                self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M, slot=0)
             # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
             fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=RACT_STORED if GELU_DC2 else ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
             nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
@@ -556,7 +577,7 @@ class Encoder:
             with self._side():
                 if not nrows:
                     self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
-                self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M)
+                self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M, slot=1)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
             # dres = d(xout): fc2.bias.grad = colsum(dres x dropout3 mask); the bf16 output d(x1) feeds out_proj's gradients: dropout1 mask
@@ -574,7 +595,7 @@ class Encoder:
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
             with self._side():
-                self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M)
+                self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M, slot=2)
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
             qkv, dqkv = d["qkv"][n], d["dqkv"]
             if d["fused_attn"]:
@@ -606,7 +627,7 @@ class Encoder:
             with self._side():
                 if not (FUSED_BIAS_GRAD and d["fused_attn"]):
                     ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
-                self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M)
+                self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M, slot=3)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             # dx (= d x1) is the gradient of out_proj's output: out_proj.bias.grad rides on this LayerNorm backward
             # dres = d(x1): out_proj.bias.grad = colsum(dres x dropout1 mask); the bf16 output d(xin) feeds the fc2 gradients of the next
@@ -628,6 +649,7 @@ class Encoder:
                                resid_bias=pn + "self_attn.out_proj.bias")
             cur = (cur + 1) % 3
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d xin
+            self._flush_slabs(d)
             self._join_side()          # d_f / dqkv / the bf16 residual gradients of this layer are free again; its gradients are final
             if self.on_grads_ready is not None:
                 ops.host_callback(self.on_grads_ready, P.off(self.n(pn + "self_attn_layer_norm.weight")))

@@ -31,6 +31,11 @@ class SclReduceJob(ctypes.Structure):
                 ("nparts", ctypes.c_int32), ("C", ctypes.c_int32), ("split", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
+class SclSlabJob(ctypes.Structure):
+    _fields_ = [("slabs", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_int64), ("stride", ctypes.c_int64),
+                ("nslabs", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
 class SclGemmDesc(ctypes.Structure):
     _fields_ = [("A", SclOperand), ("B", SclOperand), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
                 ("R", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -108,6 +113,7 @@ def _protos():
         "scl_colsum_reduce_nparts": ([_i32, _i32], _i32),
         "scl_colsum": ([_vp, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
         "scl_colreduce_multi": ([P(SclReduceJob), _i32, _vp], _i32),
+        "scl_reduce_slabs_multi": ([P(SclSlabJob), _i32, _vp], _i32),
         "scl_colreduce_seg_f32": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp], _i32),
         "scl_colsum_reduce": ([_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp], _i32),
         # elementwise.hip

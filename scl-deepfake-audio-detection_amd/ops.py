@@ -462,6 +462,14 @@ def adamw_flat(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, grad_scal
                                     _stream())
 
 
+def reduce_slabs_multi(jobs):
+    """jobs: list of (slabs, out, n, nslabs, stride) — up to 8 split-K combines in one launch, each bit-identical to reduce_slabs."""
+    arr = (L.SclSlabJob * len(jobs))()
+    for i, (slabs, out, n, nslabs, stride) in enumerate(jobs):
+        arr[i].slabs, arr[i].out, arr[i].n, arr[i].stride, arr[i].nslabs = _p(slabs), _p(out), n, stride, nslabs
+    _call("scl_reduce_slabs_multi", arr, len(jobs), _stream(), keep=arr)
+
+
 def fir_nblocks(Lout):
     return L.load().scl_fir_nblocks(Lout)
 

@@ -449,3 +449,25 @@ def test_self_finishing_column_sum_cuts_narrow_matrices_finer(dev, M, N):
         assert ((out.double().cpu() - x.double().sum(0).cpu()).abs() / x.double().abs().sum(0).cpu()).max().item() < 1e-6
         first = out.clone() if first is None else first
         assert torch.equal(out, first)
+
+
+def test_reduce_slabs_multi_equals_the_single_launches(dev):
+    """scl_reduce_slabs_multi (one launch for the split-K combines of an encoder layer's four weight gradients, csrc/norm.hip) keeps every
+    job's grid, element-to-thread map and slab order: bit-identical to scl_reduce_slabs_f32 per job — ragged tails, a stride larger than
+    n, one slab, sixteen slabs, more elements than the 2048-block grid covers in one sweep."""
+    specs = [(4096 * 1024, 4, 4096 * 1024), (1024 * 1024, 16, 1024 * 1024), (3072 * 1024, 5, 3072 * 1024), (1003, 3, 1004),
+             (8, 1, 8), (2048 * 256 * 4 * 3 + 7, 2, 2048 * 256 * 4 * 3 + 8)]
+    jobs, refs = [], []
+    for i, (n, sk, stride) in enumerate(specs):
+        slabs = torch.randn(sk * stride, generator=g(70 + i)).to(dev)
+        out = torch.full((n,), float("nan"), device=dev)
+        ref = torch.full((n,), float("nan"), device=dev)
+        ops.reduce_slabs(slabs, ref, n, sk, stride)
+        jobs.append((slabs, out, n, sk, stride)); refs.append(ref)
+    ops.reduce_slabs_multi(jobs)
+    for (slabs, out, n, sk, stride), ref in zip(jobs, refs):
+        assert torch.equal(out, ref), (n, sk)
+        acc = slabs.view(sk, stride)[:, :n].double().sum(0)
+        assert rel(out, acc.float()) < 1e-6
+    with pytest.raises(Exception):
+        ops.reduce_slabs_multi(jobs + jobs)      # more than 8 jobs
