@@ -2,7 +2,10 @@
 """bench.py — train-step throughput of the MI355X hot path on BASELINE.json's metric.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either way: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in
+    the environment: this process IS a rank), or as plain `python bench.py --gpus N ...` — then this process makes no GPU call at all,
+    starts N child ranks of itself (the reference goes multi-GPU in-process: main.py:350-355), relays rank 0's JSON line and exits
+    non-zero if any rank did.
 
 A step = one optimizer step of `wav2vec2_linear_nll` at XLS-R-300M shape on a synthetic batch that is
 already resident in HBM: [RawBoost on the GPU if the config says so ->] forward -> NLL + SupCon losses
@@ -32,8 +35,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0
 FLOP_PER_UTT_STEP_64000 = 444e9  # 74.0 GMAC forward x 2 x 3
 
@@ -54,6 +55,58 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N child processes of this file, one per GPU, rendezvous on 127.0.0.1.
+    The parent has not imported torch and never touches HIP (a process that initialised the GPU must not be replaced, and has no
+    business holding a context on GPU 0 while rank 0 is timed).  stdout of rank 0 is relayed; its last line is the JSON line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out = procs[0].stdout.read().decode("utf-8", "replace")
+    # a rank that dies before the rendezvous leaves the others blocked in it: once one child has failed, the rest get a grace period
+    codes = [None] * len(procs)
+    deadline = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes) and deadline is None:
+            deadline = time.time() + 30.0
+        if deadline is not None and time.time() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()                      # exactly the children started above
+                    codes[i] = p.wait()
+        time.sleep(0.05)
+    lines = [l for l in out.splitlines() if l.strip()]
+    for l in lines[:-1]:
+        print(l)
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        if lines:
+            print(lines[-1])
+        print("bench.py: ranks failed (rank, exit code): %r" % bad, file=sys.stderr)
+        sys.exit(1)
+    if not lines:
+        print("bench.py: rank 0 printed nothing", file=sys.stderr)
+        sys.exit(1)
+    sys.stdout.flush()
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
 def gemm_source_sha():
     """Fingerprint of the GEMM kernel sources: a committed PMC pass is quoted only for the sources it was taken with."""
     import glob
@@ -71,6 +124,7 @@ def cpu_baseline(args):
     length — RawBoost per clip with the reference's own call sequence (one clip after the other, as a DataLoader worker
     does), then one DISCARDED train step (thread pool, allocator and oneDNN primitive caches warm) and one timed train step."""
     import numpy as np
+    import torch
     from oracle import head as OH
     from oracle import rawboost as RB
     from oracle import wav2vec2 as W
@@ -98,6 +152,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                      # never returns
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,14 +232,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ops.prof_reserve(KID_GEMM, 1024)      # event pairs of the profiled (last timed) step exist before the timed region starts
-    ops.prof_reserve(KID_AUG, 64)
+    # roofline: every GEMM launch of the LAST n_prof timed steps (5, or all of a shorter run) carries two HIP events on its launch stream
+    # (one step = ~320 launches; the kernel's own dispatch packet takes the time stamps).  The event pairs exist before the timed
+    # region starts; `frac` is the mean over those steps, not one step on one box.
+    n_prof = max(1, min(5, args.steps))
+    ops.prof_reserve(KID_GEMM, 1024 * n_prof)
+    ops.prof_reserve(KID_AUG, 64 * n_prof)
     fence()
-    # roofline: every GEMM launch of the LAST timed step is bracketed by two HIP events on its launch stream (one step = 259
-    # launches; bracketing all K steps costs ~0.5 us x 2 events x 259 per step of extra queue packets inside the timed region)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1:
+        if i == args.steps - n_prof:
             ops.prof_enable(KID_GEMM, True)
             ops.prof_enable(KID_AUG, True)
         last = step()
@@ -231,20 +290,22 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "scl_gemm_{w8,w8s,dma}_kernel + posconv_mfma_kernel family (bf16 MFMA 16x16x32, all layouts)", "achieved": achieved,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch from the committed rocprofv3 PMC pass, not live" if traffic else None,
-                     "launches": n_launch, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
+                     "launches": n_launch, "profiled_steps": n_prof, "launches_per_step": n_launch / n_prof, "avg_launch_us": (gemm_ms * 1e3 / n_launch) if n_launch else None,
                      "avg_flops_per_launch": (gemm_flops / n_launch) if n_launch else None,
-                     "gemm_share_of_step_time": gemm_ms * 1e-3 / (dt / args.steps)},   # events bracket the last timed step only
+                     "gemm_share_of_step_time": gemm_ms * 1e-3 / n_prof / (dt / args.steps)},
     }
     if args.rawboost and aug_ms > 0:
         # 8 B/sample (fp32 in + out) per fused chain = 512 kB per 64000-sample clip; arithmetic = 2 * sum(taps) per
         # sample of the five LnL branches (+ a few FLOP/sample for the powers and the ISD / normalise passes)
+        aug_ms /= n_prof                                   # per step (chain_ms = one chain over the batch)
+        aug_launch //= n_prof
         aug_bytes = 8.0 * B * L
         aug_flops = 2.0 * augment.last_tap_total() * L
         gbs = aug_bytes / (aug_ms * 1e-3) / 1e9
         res["roofline_aug"] = {"bound": "hbm", "kernel": "RawBoost algo %d chain: fir_kernel (LnL, 5 power branches fused) + clip_affine + "
                                "isd_scatter + clip_stats + clip_affine" % args.rawboost, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
                                "frac": gbs / 8000.0, "traffic": None, "launches": aug_launch, "chain_ms": aug_ms,
-                               "clips_per_s_kernel_only": B / (aug_ms * 1e-3),
+                               "clips_per_s_kernel_only": B / (aug_ms * 1e-3), "profiled_steps": n_prof,
                                "achieved_fp32_tflops": aug_flops / (aug_ms * 1e-3) / 1e12, "fp32_vector_peak_tflops": 157.3,
                                "note": "direct-form FIR, ~2.7 kFLOP/sample: VALU-bound, HBM traffic is the minimal 8 B/sample"}
     if sync is not None:
