@@ -355,6 +355,61 @@ int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const f
                       int B, int N, int D, int Do, int n1, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* AASIST RawNet2-style encoder: the six Residual_blocks (model/wav2vec2_aasist.py:377-433,     */
+/* stacked at :470-476) on zero-bordered flat maps, exact fp32 on the f32 matrix cores           */
+/* ------------------------------------------------------------------------------------------ */
+/* A map of the stack: utterance b owns H + 2 rows of W + 2 positions of C channels (f32, channels last); flat position
+ * g = (b * (H + 2) + r) * (W + 2) + c.  Rows r_lo..r_hi and columns 1..W hold values, everything else is zero (the convolutions'
+ * padding).  Buffers carry >= W + 132 positions of slack on either side of [0, G) (finite values; never part of a valid result). */
+typedef struct SclRsGeom { int32_t B, H, W, r_lo, r_hi, _pad; } SclRsGeom;
+/* out[g][n] = mask(g) * (bias[n] + addend[g][n] + sum_t sum_c in[g + shift[t]][c] * Wt[t][c][n])   — a (kh, kw) tap of a stride-1
+ * convolution over a bordered map is ONE flat shift; the data gradient is the same call with negated shifts and transposed weights.
+ * wpk: scl_rs_pack_weights image.  (cin, cout, ntaps) in {(16|32,32,6), (32|64,64,6), (16,32,3), (32,64,3), (32,16,3|6), (64,32,3|6)}.
+ * stat_mode 1: per-channel sum / sum of squares of the stored values; the last block turns them into BatchNorm statistics
+ *   stats_out[4][cout] = mean, rstd, gamma * rstd, beta - mean * gamma * rstd (biased variance, eps) and, when run_mean is given, updates
+ *   running_mean / running_var (momentum, unbiased) and num_batches_tracked exactly as nn.BatchNorm2d in training does.
+ * stat_mode 2 (BatchNorm + SELU backward, first half): out = mask * conv * selu'(act_a) = dz; sums of dz and dz * xhat with
+ *   xhat = (y1 - mean) * rstd from bnstats; the last block adds them to dbeta / dgamma and stores stats_out[2][cout] = their means
+ *   (zeros when training == 0) for scl_rs_bn_bwd_apply.
+ * acc: 2 * cout zeroed doubles, ticket: one zeroed uint32 (both are left zeroed).  nvalid = number of unmasked positions. */
+typedef struct SclRsConv {
+    const float* in; const float* wpk; const float* bias; const float* addend; float* out;
+    const float* act_a; const float* y1; const float* bnstats;
+    double* acc; uint32_t* ticket;
+    const float* gamma; const float* beta; float* run_mean; float* run_var; int64_t* nbt;
+    float* stats_out; float* dgamma; float* dbeta;
+    double nvalid;
+    SclRsGeom geom;
+    int32_t shift[6];
+    int32_t cin, cout, ntaps, stat_mode, training, _pad;
+    float eps, momentum;
+} SclRsConv;
+int scl_rs_conv(const SclRsConv* c, void* stream);
+/* torch [Co, Ci, KH, KW] (ntaps = KH * KW, tap t = kh * KW + kw) -> register image for scl_rs_conv (out: COUTp * ntaps * CINp floats);
+ * CINp / COUTp: the kernel's channel counts (multiples of 16, zero-filled); transposed != 0: the data-gradient image (the convolution's
+ * Co becomes the contraction).  One launch packs up to SCL_RS_MAX_PACK_JOBS images. */
+#define SCL_RS_MAX_PACK_JOBS 32
+typedef struct SclRsPackJob { const float* w; float* out; int32_t Co, Ci, ntaps, CINp, COUTp, transposed; } SclRsPackJob;
+int scl_rs_pack_weights(const SclRsPackJob* jobs, int njobs, void* stream);
+/* part[scl_rs_wgrad_nslabs(cout)][ntaps * cin * cout] f32 partial slabs of dW[t][c][n] = sum_g in[g + shift[t]][c] * dout[g][n]
+ * (dout zero off the valid positions); dbias[n] += sum_g dout[g][n] when dbias != NULL (bacc: cout zeroed doubles, ticket as above) */
+int scl_rs_wgrad_nslabs(int cout);
+int scl_rs_wgrad(const float* in, const float* dout, int cin, int cout, int ntaps, const int* shift, const SclRsGeom* geom, float* part,
+                 double* bacc, uint32_t* ticket, float* dbias, void* stream);
+/* dw (torch layout [Co, Ci, ntaps]) += the slabs, summed in index order */
+int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, float* dw, void* stream);
+/* a = mask * selu(y * stats[2] + stats[3]) (BatchNorm + SELU, model/wav2vec2_aasist.py:423-424) */
+int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, const SclRsGeom* geom, void* stream);
+/* in place: dz := mask * stats[2] * (dz - bstats[0] - (y - stats[0]) * stats[1] * bstats[1]) — the input gradient of that BatchNorm */
+int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, const SclRsGeom* geom, void* stream);
+/* eval mode: stats[4][C] from the running statistics */
+int scl_rs_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                         float* stats, void* stream);
+/* to_dense == 0: dense [B * H' * W, Cs] -> bordered [G, Cd] (rows r_lo..r_hi, H' = r_hi - r_lo + 1; other channels and positions zero);
+ * to_dense != 0: bordered [G, Cs] -> dense [B * H' * W, Cd] (the first Cd channels) */
+int scl_rs_copy(const float* src, float* dst, int Cs, int Cd, int to_dense, const SclRsGeom* geom, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
 /* ------------------------------------------------------------------------------------------ */
 /* Buffers: ws = scl_supcon_nchunks(K) * bz * bz floats; G = 2 * bz * bz floats — [0, bz*bz) receives dL/dS from the forward and is

@@ -12,13 +12,17 @@ containers under the reference's state-dict names; their torch forwards are neve
 Reference quirks kept on purpose: Residual_block applies conv1 to its INPUT (the bn1+SELU result is discarded, :414-420; in training
 that BatchNorm still updates its running statistics); the temporal / spectral attention pools share one 1x1-conv score map.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hipnn
+from . import hipnn, resstack
 from .gat import gat_score
 from .resnet_head import ConvWeight
+
+FUSED_STACK = os.environ.get("SCL_AASIST_FUSED", "1") == "1"      # 0: one autograd Function per layer (the round-2 composition)
 
 UPSTREAM_AASIST = {"filts": [128, [1, 32], [32, 32], [32, 64], [64, 64]], "gat_dims": [64, 32],
                    "pool_ratios": [0.5, 0.5, 0.5, 0.5], "temperatures": [2.0, 2.0, 100.0, 100.0], "nclasses": 2}
@@ -163,8 +167,12 @@ class AasistHead(nn.Module):
         # [B, T, 128] -> the single-channel map [B, 128 (frequency bins), T] -> 3x3 max pool -> [B, 42, T/3, 1] channels last
         x = hipnn.max_pool3(feats.transpose(1, 2)).unsqueeze(-1)
         x = hipnn.batch_norm(x, self.first_bn, hipnn.ACT_SELU)
-        for blk in self.encoder:
-            x = blk[0].run(x)
+        blocks = [blk[0] for blk in self.encoder]
+        if FUSED_STACK and resstack.supported(blocks):
+            x = resstack.res_stack(x, blocks)          # the six Residual_blocks as one autograd node (csrc/resstack.hip)
+        else:
+            for blk in blocks:
+                x = blk.run(x)
         x = hipnn.batch_norm(x, self.first_bn1, hipnn.ACT_SELU)                    # [B, 42, T/3, 64]
         a0, a2, a3 = self.attention[0], self.attention[2], self.attention[3]
         w = hipnn.linear(x, a0.weight.view(a0.weight.shape[0], -1), a0.bias)

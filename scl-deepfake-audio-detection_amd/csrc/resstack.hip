@@ -1,0 +1,595 @@
+// resstack.hip — the RawNet2-style encoder of the AASIST back-end (six Residual_blocks, model/wav2vec2_aasist.py:377-433, stacked at
+// :470-476) as hand-scheduled gfx950 kernels, forward and backward.
+//
+// Layout.  Every map of the stack lives ZERO-BORDERED and FLAT: utterance b owns RPU = H + 2 rows of Wp = W + 2 positions of C
+// channels (fp32, channels last); position g = (b * RPU + r) * Wp + c.  With the borders in the buffer a (kh, kw) tap of a stride-1
+// convolution is ONE flat shift: out[g] = sum_t sum_c in[g + s_t][c] * W[t][c][n] for every g, garbage only where g is a border
+// position — and those are written as zeros (they ARE the next convolution's padding).  No im2col, no padded copy per call, and
+// the data gradient of a convolution is the same kernel with the shifts negated and the weights transposed.
+//
+// Kernels (all exact fp32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD = the f32 roof of the chip, 157 TFLOP/s):
+//   rs_conv_kernel<CIN, COUT, NT>   persistent blocks; a wave keeps its 16 output channels' weights (NT * CIN values per lane) in
+//                                   REGISTERS for the whole launch, 128-position input tiles (+ halo) stream through LDS, each
+//                                   ds_read_b128 feeds four MFMAs.  Epilogue through LDS: + bias, + addend (identity / down-sample
+//                                   branch), border mask, optional x selu'(a) (BatchNorm backward input), per-channel statistics
+//                                   (sum, sum of squares | sum dz, sum dz * xhat) — combined over blocks with fp64 atomics and finished by
+//                                   the last block: BatchNorm mean / rstd / running statistics, or dgamma / dbeta and the two means of
+//                                   the BatchNorm backward.
+//   rs_wgrad_kernel<CIN, COUT, NT>  dW[t][c][n] = sum_g in[g + s_t][c] * dout[g][n]: the whole [NT * CIN, COUT] gradient stays in the
+//                                   accumulators (96 registers per lane at 64 -> 64 channels, six taps) while 64-position chunks of
+//                                   both maps stream through LDS; one partial slab per block and wave group, summed in a fixed order
+//                                   by rs_wgrad_reduce_kernel straight into the torch-layout gradient; bias gradient alongside.
+//   rs_bn_act / rs_bn_bwd_apply     the two element-wise passes BatchNorm's batch statistics force between the convolutions.
+//   rs_scatter_c1 / rs_gather_c1 / rs_unpad / rs_pad    dense <-> bordered copies at the two ends of the stack.
+#include "common.h"
+
+namespace {
+
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+constexpr int RS_MT = 128;      // output positions per tile of the convolution kernel
+constexpr int RS_PC = 64;       // positions per chunk of the weight-gradient kernel
+
+struct RsGeom { int G, Wp, RPU, W, r_lo, r_hi; };
+
+__device__ __forceinline__ bool rs_valid(const RsGeom& q, unsigned g) {
+    if (g >= (unsigned)q.G) return false;
+    const unsigned row = g / (unsigned)q.Wp;
+    const int c = (int)(g - row * (unsigned)q.Wp);
+    const int r = (int)(row % (unsigned)q.RPU);
+    return r >= q.r_lo && r <= q.r_hi && c >= 1 && c <= q.W;
+}
+
+struct RsConvK {
+    const float* in; const float* wpk; const float* bias; const float* addend; float* out;
+    const float* act_a; const float* y1; const float* bnstats;     // stat_mode 2: out = conv * selu'(act_a); xhat = (y1 - mean) * rstd
+    double* acc; unsigned* ticket;                                   // [2 * COUT] fp64 accumulators (zero between launches) + arrival counter
+    const float* gamma; const float* beta; float* run_mean; float* run_var; long long* nbt;
+    float* stats_out; float* dgamma; float* dbeta;
+    RsGeom q;
+    int shift[6];
+    int smin, span, stat_mode, training;
+    float eps, momentum;
+    double nvalid;
+};
+
+__device__ __forceinline__ float selu_f(float v) { return v > 0.f ? SELU_SCALE * v : SELU_SCALE * SELU_ALPHA * (__expf(v) - 1.0f); }
+__device__ __forceinline__ float selu_grad_from_y(float y) { return y > 0.f ? SELU_SCALE : y + SELU_SCALE * SELU_ALPHA; }
+
+// Every block adds its n fp64 partials to acc[0..n) with atomics; the LAST block to arrive (ticket) sees the totals, hands them to `fin`
+// thread by thread and leaves accumulators and ticket zeroed for the next launch.  fp64 addition order varies from run to run, i.e. the
+// totals carry an order-dependent error of ~1e-16 relative — invisible after the rounding to fp32 that every consumer applies.
+template <class F>
+__device__ __forceinline__ void rs_finish(double* acc, unsigned* ticket, int n, const double* mine, double* lds_tot, F fin) {
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    if (tid < n) atomicAdd(&acc[tid], mine[tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid < n) {
+        lds_tot[tid] = __hip_atomic_load(&acc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    fin(lds_tot);
+}
+
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
+    constexpr int NCB = COUT / 16;            // 16-channel output blocks: one per wave (64), two waves per block (32), four (16)
+    constexpr int NRG = 4 / NCB;              // wave groups that split the tile's eight 16-position row blocks
+    constexpr int RPW = 8 / NRG;              // row blocks per wave
+    constexpr int RBG = RPW < 4 ? RPW : 4;    // row blocks in flight (independent accumulators: >= 2 covers the 40-cycle MFMA latency)
+    constexpr int NGRP = RPW / RBG;
+    constexpr int NJJ = CIN / 16;
+    constexpr int PITCH = CIN + 4;            // 16 rows x 16-byte reads hit 64 distinct banks: (CIN / 4 + 1) is odd
+    constexpr int OPITCH = COUT + 4;
+    constexpr int C4 = CIN / 4, N4 = COUT / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave % NCB, rg = wave / NCB, g4 = lane >> 4, li = lane & 15;
+
+    f32x4 w[NT][NJJ];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(d.wpk) + (size_t)cb * NT * NJJ * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int jj = 0; jj < NJJ; ++jj) w[t][jj] = wp[(t * NJJ + jj) * 64];
+    }
+    const int ch4 = tid % N4;                 // the four output channels this thread owns in every epilogue pass (256 % N4 == 0)
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, mean4 = bias4, rstd4 = bias4;
+    if (d.bias) bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * ch4);
+    if (d.stat_mode == 2) {
+        mean4 = *reinterpret_cast<const f32x4*>(d.bnstats + 4 * ch4);
+        rstd4 = *reinterpret_cast<const f32x4*>(d.bnstats + COUT + 4 * ch4);
+    }
+    double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = (d.q.G + RS_MT - 1) / RS_MT;
+    const int nrows = RS_MT + d.span;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * RS_MT;
+        {   // input tile + halo: one contiguous range of the flat map
+            const float* src = d.in + ((long long)g0 + d.smin) * CIN;
+            for (int f = tid; f < nrows * C4; f += 256) {
+                const int pos = f / C4, c4 = f - pos * C4;
+                *reinterpret_cast<f32x4*>(lds + pos * PITCH + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+            }
+        }
+        __syncthreads();
+        f32x4 acc[NGRP][RBG];
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp) {
+#pragma unroll
+            for (int r = 0; r < RBG; ++r) acc[gp][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float* tb = lds + ((rg * RPW + gp * RBG) * 16 + li + (d.shift[t] - d.smin)) * PITCH + 4 * g4;
+#pragma unroll
+                for (int jj = 0; jj < NJJ; ++jj) {
+                    f32x4 b4[RBG];
+#pragma unroll
+                    for (int r = 0; r < RBG; ++r) b4[r] = *reinterpret_cast<const f32x4*>(tb + r * 16 * PITCH + 16 * jj);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < RBG; ++r)
+                            acc[gp][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][jj][j], b4[r][j], acc[gp][r], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();      // every wave is done with the input tile: the same LDS now stages the outputs
+#pragma unroll
+        for (int gp = 0; gp < NGRP; ++gp)
+#pragma unroll
+            for (int r = 0; r < RBG; ++r)
+                *reinterpret_cast<f32x4*>(lds + (((rg * RPW + gp * RBG + r) * 16) + li) * OPITCH + 16 * cb + 4 * g4) = acc[gp][r];
+        __syncthreads();
+#pragma unroll 2
+        for (int f = tid; f < RS_MT * N4; f += 256) {
+            const int pos = f / N4;
+            const unsigned g = (unsigned)(g0 + pos);
+            if (g >= (unsigned)d.q.G) continue;
+            const bool ok = rs_valid(d.q, g);
+            f32x4 v = *reinterpret_cast<const f32x4*>(lds + pos * OPITCH + 4 * ch4);
+            const size_t off = (size_t)g * COUT + 4 * ch4;
+            v += bias4;
+            if (d.addend) v += *reinterpret_cast<const f32x4*>(d.addend + off);
+            if (d.stat_mode == 2) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(d.act_a + off), y = *reinterpret_cast<const f32x4*>(d.y1 + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = ok ? v[e] * selu_grad_from_y(a[e]) : 0.f;
+                    const float xh = (y[e] - mean4[e]) * rstd4[e];
+                    st[e] += (double)v[e];
+                    st[4 + e] += ok ? (double)v[e] * (double)xh : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                if (d.stat_mode == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { st[e] += (double)v[e]; st[4 + e] += (double)v[e] * (double)v[e]; }
+                }
+            }
+            *reinterpret_cast<f32x4*>(d.out + off) = v;
+        }
+        __syncthreads();      // the staging area becomes the next input tile
+    }
+    if (d.stat_mode == 0) return;
+    // block totals: the 256 / N4 threads that share a channel quad, in a fixed order
+    double* ld = reinterpret_cast<double*>(lds);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ld[tid * 8 + e] = st[e];
+    __syncthreads();
+    double* mine = ld + 256 * 8;
+    if (tid < 2 * COUT) {
+        const int stat = tid / COUT, ch = tid - stat * COUT;
+        double s = 0.0;
+        for (int k = ch >> 2; k < 256; k += N4) s += ld[k * 8 + stat * 4 + (ch & 3)];
+        mine[tid] = s;
+    }
+    __syncthreads();
+    rs_finish(d.acc, d.ticket, 2 * COUT, mine, mine + 2 * COUT, [&](const double* tot) {
+        if (tid >= COUT) return;
+        const int c = tid;
+        if (d.stat_mode == 1) {
+            // BatchNorm forward statistics (nn.BatchNorm2d in training: biased variance to normalise, unbiased into the running buffer)
+            const double m = tot[c] / d.nvalid;
+            double var = tot[COUT + c] / d.nvalid - m * m;
+            if (var < 0.0) var = 0.0;
+            if (d.stats_out) {
+                const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+                const float sc = (d.gamma ? d.gamma[c] : 1.f) * rstd;
+                d.stats_out[c] = (float)m; d.stats_out[COUT + c] = rstd;
+                d.stats_out[2 * COUT + c] = sc; d.stats_out[3 * COUT + c] = (d.beta ? d.beta[c] : 0.f) - (float)m * sc;
+            }
+            if (d.run_mean) {
+                const double unb = d.nvalid > 1.0 ? var * d.nvalid / (d.nvalid - 1.0) : var;
+                d.run_mean[c] = (float)((1.0 - d.momentum) * d.run_mean[c] + d.momentum * m);
+                d.run_var[c] = (float)((1.0 - d.momentum) * d.run_var[c] + d.momentum * unb);
+            }
+            if (d.nbt && c == 0) *d.nbt += 1;
+        } else {
+            // BatchNorm backward: dbeta = sum dz, dgamma = sum dz * xhat; the two batch means the input gradient subtracts (none in eval mode)
+            if (d.dbeta) d.dbeta[c] += (float)tot[c];
+            if (d.dgamma) d.dgamma[c] += (float)tot[COUT + c];
+            d.stats_out[c] = d.training ? (float)(tot[c] / d.nvalid) : 0.f;
+            d.stats_out[COUT + c] = d.training ? (float)(tot[COUT + c] / d.nvalid) : 0.f;
+        }
+    });
+}
+
+// ---- element-wise passes ---------------------------------------------------------------------------------------------------------------
+// a = selu(y * sc + sh) on the valid positions, 0 on the borders (they are conv2's zero padding)
+__global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ a, int C, RsGeom q) {
+    const int c4n = C >> 2;
+    const long long n4 = (long long)q.G * c4n;
+    for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < n4; f += (long long)gridDim.x * 256) {
+        const unsigned g = (unsigned)(f / c4n);
+        const int c = (int)(f - (long long)g * c4n) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (rs_valid(q, g)) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + f * 4), sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c),
+                        sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = selu_f(v[e] * sc[e] + sh[e]);
+        }
+        *reinterpret_cast<f32x4*>(a + f * 4) = o;
+    }
+}
+// dy = sc * (dz - m1 - xhat * m2) on the valid positions (m1 = m2 = 0 in eval mode), 0 elsewhere; in place on dz
+__global__ __launch_bounds__(256) void rs_bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ stats,
+                                                             const float* __restrict__ bstats, int C, RsGeom q) {
+    const int c4n = C >> 2;
+    const long long n4 = (long long)q.G * c4n;
+    for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < n4; f += (long long)gridDim.x * 256) {
+        const unsigned g = (unsigned)(f / c4n);
+        const int c = (int)(f - (long long)g * c4n) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (rs_valid(q, g)) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dz + f * 4), yy = *reinterpret_cast<const f32x4*>(y + f * 4);
+            const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c), rstd = *reinterpret_cast<const f32x4*>(stats + C + c),
+                        sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(bstats + c), m2 = *reinterpret_cast<const f32x4*>(bstats + C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = sc[e] * (v[e] - m1[e] - (yy[e] - mean[e]) * rstd[e] * m2[e]);
+        }
+        *reinterpret_cast<f32x4*>(dz + f * 4) = o;
+    }
+}
+// eval mode: mean / rstd / sc / sh from the running statistics
+__global__ void rs_bn_eval_stats_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+    stats[c] = rm[c]; stats[C + c] = rstd; stats[2 * C + c] = sc; stats[3 * C + c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+// ---- dense <-> bordered copies ------------------------------------------------------------------------------------------------------------
+// mode 0: dense [B*H*W, Cs] -> bordered [G, Cd] (channels >= Cs and borders zero);  mode 1: bordered [G, Cs] -> dense [B*H*W, Cd] (first Cd channels)
+__global__ __launch_bounds__(256) void rs_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cs, int Cd, int H, int mode, RsGeom q) {
+    if (mode == 0) {
+        const long long n = (long long)q.G * Cd;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+            const unsigned g = (unsigned)(e / Cd);
+            const int c = (int)(e - (long long)g * Cd);
+            float v = 0.f;
+            if (c < Cs && rs_valid(q, g)) {
+                const unsigned row = g / (unsigned)q.Wp;
+                const unsigned b = row / (unsigned)q.RPU;
+                const int r = (int)(row - b * q.RPU), col = (int)(g - row * (unsigned)q.Wp);
+                v = src[(((long long)b * H + (r - q.r_lo)) * q.W + (col - 1)) * Cs + c];
+            }
+            dst[e] = v;
+        }
+    } else {
+        const long long n = (long long)(q.G / (q.RPU * q.Wp)) * H * q.W * Cd;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+            const long long p = e / Cd;
+            const int c = (int)(e - p * Cd);
+            const long long bh = p / q.W;
+            const int col = (int)(p - bh * q.W);
+            const long long b = bh / H;
+            const int r = (int)(bh - b * H);
+            dst[e] = src[(((b * q.RPU) + r + q.r_lo) * q.Wp + col + 1) * Cs + c];
+        }
+    }
+}
+
+// ---- weights: torch [Co, Ci, KH, KW] -> the register image of rs_conv_kernel --------------------------------------------------------------
+// wpk[cb][t][jj][lane][j] = Wt[t][c = 16 jj + 4 (lane >> 4) + j][n = 16 cb + (lane & 15)];  forward: Wt[t][c][n] = W[n][c][t];
+// data gradient (transposed): Wt[t][c][n] = W[c][n][t] (c runs over the convolution's OUTPUT channels); zero beyond the real channel counts.
+// One launch packs every image of the stack (blockIdx.y = job).
+struct RsPackJobs { SclRsPackJob j[SCL_RS_MAX_PACK_JOBS]; };
+__global__ __launch_bounds__(256) void rs_pack_kernel(const RsPackJobs jobs) {
+    const SclRsPackJob& q = jobs.j[blockIdx.y];
+    const int njj = q.CINp / 16;
+    const int n_el = (q.COUTp / 16) * q.ntaps * njj * 256;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_el; e += gridDim.x * 256) {
+        const int j = e & 3, lane = (e >> 2) & 63;
+        int rest = e >> 8;
+        const int jj = rest % njj; rest /= njj;
+        const int t = rest % q.ntaps; const int cb = rest / q.ntaps;
+        const int c = 16 * jj + 4 * (lane >> 4) + j, n = 16 * cb + (lane & 15);
+        float v = 0.f;
+        if (!q.transposed) { if (n < q.Co && c < q.Ci) v = q.w[((size_t)n * q.Ci + c) * q.ntaps + t]; }
+        else { if (c < q.Co && n < q.Ci) v = q.w[((size_t)c * q.Ci + n) * q.ntaps + t]; }
+        q.out[e] = v;
+    }
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------------------------
+struct RsWgradK {
+    const float* in; const float* dout; float* part;       // part: [gridDim.x * NPART][NT * CIN * COUT] f32 slabs
+    double* bacc; unsigned* ticket; float* dbias;          // bias gradient: fp64 accumulators [COUT] + arrival counter; dbias += total (may be NULL)
+    int G, smin, span;
+    int shift[6];
+};
+
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(const RsWgradK d) {
+    constexpr int NCB = COUT / 16, NPART = 4 / NCB, NCBK = CIN / 16;
+    constexpr int PA = CIN == 16 ? 16 : CIN + 16;          // 4 position rows x 16 channels of a 4-byte read hit 64 distinct banks
+    constexpr int PD = COUT == 16 ? 16 : COUT + 16;
+    constexpr int C4 = CIN / 4, N4 = COUT / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = wave % NCB, pp = wave / NCB, g4 = lane >> 4, li = lane & 15;
+    const int nrows = RS_PC + d.span;
+    float* la = lds;
+    float* ldo = lds + nrows * PA;
+    f32x4 acc[NT][NCBK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < NCBK; ++k) acc[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double bs[4] = {0, 0, 0, 0};
+    const int nchunks = (d.G + RS_PC - 1) / RS_PC;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int p0 = chunk * RS_PC;
+        {
+            const float* src = d.in + ((long long)p0 + d.smin) * CIN;
+            for (int f = tid; f < nrows * C4; f += 256) {
+                const int pos = f / C4, c4 = f - pos * C4;
+                *reinterpret_cast<f32x4*>(la + pos * PA + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+            }
+            const float* sd = d.dout + (long long)p0 * COUT;
+            for (int f = tid; f < RS_PC * N4; f += 256) {        // f % N4 is the same in every pass (256 % N4 == 0): bs[] stays on one channel quad
+                const int pos = f / N4, c4 = f - pos * N4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (p0 + pos < d.G) v = *reinterpret_cast<const f32x4*>(sd + (size_t)f * 4);      // past the map: zeros (garbage x 0 could be NaN)
+                *reinterpret_cast<f32x4*>(ldo + pos * PD + 4 * c4) = v;
+                bs[0] += v[0]; bs[1] += v[1]; bs[2] += v[2]; bs[3] += v[3];
+            }
+        }
+        __syncthreads();
+        for (int ks = pp; ks < RS_PC / 4; ks += NPART) {
+            const float b = ldo[(4 * ks + g4) * PD + 16 * nb + li];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float* ta = la + (4 * ks + g4 + (d.shift[t] - d.smin)) * PA + li;
+#pragma unroll
+                for (int k = 0; k < NCBK; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[16 * k], b, acc[t][k], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // slab [t][c][n]: lane holds n = 16 nb + li, c = 16 k + 4 g4 + i
+    float* slab = d.part + ((size_t)blockIdx.x * NPART + pp) * (NT * CIN * COUT);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < NCBK; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slab[((size_t)t * CIN + 16 * k + 4 * g4 + i) * COUT + 16 * nb + li] = acc[t][k][i];
+    // (NPART > 1: the wave groups split the chunk's positions; group pp's waves together fill every column of slab pp)
+    if (!d.dbias) return;
+    double* ld = reinterpret_cast<double*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ld[tid * 4 + e] = bs[e];
+    __syncthreads();
+    double* mine = ld + 256 * 4;
+    if (tid < COUT) {
+        double s = 0.0;
+        for (int k = tid >> 2; k < 256; k += N4) s += ld[k * 4 + (tid & 3)];
+        mine[tid] = s;
+    }
+    __syncthreads();
+    rs_finish(d.bacc, d.ticket, COUT, mine, mine + COUT, [&](const double* tot) {
+        if (tid < COUT) d.dbias[tid] += (float)tot[tid];
+    });
+}
+
+// dW[n][c][t] (torch layout [Co, Ci, NT]) += sum over slabs of part[slab][t][c][n], slabs in index order.  64 elements x 4 slab lanes per block.
+__global__ __launch_bounds__(256) void rs_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int NT, int CINp, int COUTp, int Co, int Ci, float* __restrict__ dw) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int n_el = NT * CINp * COUTp;
+    float s = 0.f;
+    if (e < n_el) {
+        const size_t stride = (size_t)n_el;
+        const float* p = part + e;
+        int k = sl;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; k + 12 < nslab; k += 16) {
+            s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 4) * stride]; s2 += p[(size_t)(k + 8) * stride]; s3 += p[(size_t)(k + 12) * stride];
+        }
+        for (; k < nslab; k += 4) s0 += p[(size_t)k * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && e < n_el) {
+        const float tot = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        const int n = e % COUTp, c = (e / COUTp) % CINp, t = e / (COUTp * CINp);
+        if (n < Co && c < Ci) dw[((size_t)n * Ci + c) * NT + t] += tot;
+    }
+}
+
+template <int CIN, int COUT, int NT>
+int rs_conv_launch_t(const RsConvK& k, int grid, hipStream_t s) {
+    const size_t lds_in = (size_t)(RS_MT + k.span) * (CIN + 4) * 4, lds_out = (size_t)RS_MT * (COUT + 4) * 4, lds_st = (size_t)(256 * 8 + 4 * COUT) * 8;
+    size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    if (lds_st > lds) lds = lds_st;
+    if (lds > 160 * 1024) { scl_set_error("rs_conv: tile + halo of %zu bytes exceeds the LDS", lds); return SCL_EINVAL; }
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_conv_kernel<CIN, COUT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SCL_LAUNCH((rs_conv_kernel<CIN, COUT, NT>), dim3(grid), dim3(256), lds, s, k);
+    return scl_check_launch("rs_conv");
+}
+template <int CIN, int COUT, int NT>
+int rs_wgrad_launch_t(const RsWgradK& k, int grid, hipStream_t s) {
+    constexpr int PA = CIN == 16 ? 16 : CIN + 16, PD = COUT == 16 ? 16 : COUT + 16;
+    size_t lds = ((size_t)(RS_PC + k.span) * PA + (size_t)RS_PC * PD) * 4;
+    const size_t lds_st = (size_t)(256 * 4 + 2 * COUT) * 8;
+    if (lds_st > lds) lds = lds_st;
+    if (lds > 160 * 1024) { scl_set_error("rs_wgrad: chunk + halo of %zu bytes exceeds the LDS", lds); return SCL_EINVAL; }
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_wgrad_kernel<CIN, COUT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SCL_LAUNCH((rs_wgrad_kernel<CIN, COUT, NT>), dim3(grid), dim3(256), lds, s, k);
+    return scl_check_launch("rs_wgrad");
+}
+
+bool rs_fill_geom(const SclRsGeom& g, RsGeom* q) {
+    if (g.B <= 0 || g.H <= 0 || g.W <= 0 || g.r_lo < 0 || g.r_hi > g.H + 1 || g.r_lo > g.r_hi) { scl_set_error("rs: bad geometry"); return false; }
+    q->Wp = g.W + 2; q->RPU = g.H + 2; q->W = g.W; q->r_lo = g.r_lo; q->r_hi = g.r_hi;
+    const long long G = (long long)g.B * q->RPU * q->Wp;
+    if (G >= (1LL << 31) / 64) { scl_set_error("rs: map too large for 32-bit element offsets"); return false; }
+    q->G = (int)G;
+    return true;
+}
+bool rs_shifts(const int* shift, int ntaps, int* dst, int* smin, int* span) {
+    if (ntaps != 3 && ntaps != 6) { scl_set_error("rs: ntaps must be 3 or 6"); return false; }
+    int lo = shift[0], hi = shift[0];
+    for (int t = 0; t < 6; ++t) { dst[t] = t < ntaps ? shift[t] : 0; if (t < ntaps) { lo = shift[t] < lo ? shift[t] : lo; hi = shift[t] > hi ? shift[t] : hi; } }
+    *smin = lo; *span = hi - lo;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int scl_rs_pack_weights(const SclRsPackJob* jobs, int njobs, void* stream) {
+    SCL_REQUIRE(jobs && njobs > 0 && njobs <= SCL_RS_MAX_PACK_JOBS, "rs_pack_weights: 1..%d jobs", SCL_RS_MAX_PACK_JOBS);
+    RsPackJobs pj;
+    int max_el = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SclRsPackJob& q = jobs[i];
+        SCL_REQUIRE(q.w && q.out && q.Co > 0 && q.Ci > 0 && (q.ntaps == 3 || q.ntaps == 6) && q.CINp % 16 == 0 && q.COUTp % 16 == 0, "rs_pack_weights: bad job %d", i);
+        SCL_REQUIRE(q.transposed ? (q.Co <= q.CINp && q.Ci <= q.COUTp) : (q.Co <= q.COUTp && q.Ci <= q.CINp), "rs_pack_weights: padded sizes below the real ones (job %d)", i);
+        pj.j[i] = q;
+        const int n_el = (q.COUTp / 16) * q.ntaps * (q.CINp / 16) * 256;
+        max_el = n_el > max_el ? n_el : max_el;
+    }
+    hipLaunchKernelGGL(rs_pack_kernel, dim3((max_el + 1023) / 1024, njobs), dim3(256), 0, (hipStream_t)stream, pj);
+    return scl_check_launch("rs_pack_weights");
+}
+
+extern "C" int scl_rs_conv(const SclRsConv* c, void* stream) {
+    SCL_REQUIRE(c && c->in && c->wpk && c->out, "rs_conv: null pointers");
+    RsConvK k;
+    if (!rs_fill_geom(c->geom, &k.q)) return SCL_EINVAL;
+    if (!rs_shifts(c->shift, c->ntaps, k.shift, &k.smin, &k.span)) return SCL_EINVAL;
+    SCL_REQUIRE(c->stat_mode >= 0 && c->stat_mode <= 2, "rs_conv: stat_mode %d", c->stat_mode);
+    SCL_REQUIRE(c->stat_mode == 0 || (c->acc && c->ticket && c->nvalid > 0), "rs_conv: statistics need accumulators, a ticket and the valid count");
+    SCL_REQUIRE(c->stat_mode != 2 || (c->act_a && c->y1 && c->bnstats && c->stats_out), "rs_conv: stat_mode 2 needs a, y1, the forward statistics and stats_out");
+    k.in = c->in; k.wpk = c->wpk; k.bias = c->bias; k.addend = c->addend; k.out = c->out; k.act_a = c->act_a; k.y1 = c->y1; k.bnstats = c->bnstats;
+    k.acc = c->acc; k.ticket = c->ticket; k.gamma = c->gamma; k.beta = c->beta; k.run_mean = c->run_mean; k.run_var = c->run_var;
+    k.nbt = (long long*)c->nbt; k.stats_out = c->stats_out; k.dgamma = c->dgamma; k.dbeta = c->dbeta;
+    k.stat_mode = c->stat_mode; k.training = c->training; k.eps = c->eps; k.momentum = c->momentum; k.nvalid = c->nvalid;
+    const int ntiles = (k.q.G + RS_MT - 1) / RS_MT;
+    const int grid = ntiles < 512 ? ntiles : 512;
+    hipStream_t s = (hipStream_t)stream;
+    const int key = c->cin * 10000 + c->cout * 10 + c->ntaps;
+    switch (key) {
+        case 160326: return rs_conv_launch_t<16, 32, 6>(k, grid, s);
+        case 320326: return rs_conv_launch_t<32, 32, 6>(k, grid, s);
+        case 320646: return rs_conv_launch_t<32, 64, 6>(k, grid, s);
+        case 640646: return rs_conv_launch_t<64, 64, 6>(k, grid, s);
+        case 160323: return rs_conv_launch_t<16, 32, 3>(k, grid, s);
+        case 320643: return rs_conv_launch_t<32, 64, 3>(k, grid, s);
+        case 320166: return rs_conv_launch_t<32, 16, 6>(k, grid, s);
+        case 640326: return rs_conv_launch_t<64, 32, 6>(k, grid, s);
+        case 320163: return rs_conv_launch_t<32, 16, 3>(k, grid, s);
+        case 640323: return rs_conv_launch_t<64, 32, 3>(k, grid, s);
+        default: break;
+    }
+    scl_set_error("rs_conv: no instantiation for %d -> %d channels, %d taps", c->cin, c->cout, c->ntaps);
+    return SCL_EINVAL;
+}
+
+extern "C" int scl_rs_wgrad_nslabs(int cout) { return 512 * (cout >= 64 ? 1 : (cout == 32 ? 2 : 4)); }
+
+extern "C" int scl_rs_wgrad(const float* in, const float* dout, int cin, int cout, int ntaps, const int* shift, const SclRsGeom* geom, float* part,
+                            double* bacc, unsigned* ticket, float* dbias, void* stream) {
+    SCL_REQUIRE(in && dout && part && geom && shift, "rs_wgrad: null pointers");
+    SCL_REQUIRE(!dbias || (bacc && ticket), "rs_wgrad: the bias gradient needs accumulators and a ticket");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    RsWgradK k;
+    if (!rs_shifts(shift, ntaps, k.shift, &k.smin, &k.span)) return SCL_EINVAL;
+    k.in = in; k.dout = dout; k.part = part; k.bacc = bacc; k.ticket = ticket; k.dbias = dbias; k.G = q.G;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = 512;      // fixed: the slab count the reduction walks (blocks past the last chunk write zero slabs)
+    const int key = cin * 10000 + cout * 10 + ntaps;
+    switch (key) {
+        case 160326: return rs_wgrad_launch_t<16, 32, 6>(k, grid, s);
+        case 320326: return rs_wgrad_launch_t<32, 32, 6>(k, grid, s);
+        case 320646: return rs_wgrad_launch_t<32, 64, 6>(k, grid, s);
+        case 640646: return rs_wgrad_launch_t<64, 64, 6>(k, grid, s);
+        case 160323: return rs_wgrad_launch_t<16, 32, 3>(k, grid, s);
+        case 320643: return rs_wgrad_launch_t<32, 64, 3>(k, grid, s);
+        default: break;
+    }
+    scl_set_error("rs_wgrad: no instantiation for %d -> %d channels, %d taps", cin, cout, ntaps);
+    return SCL_EINVAL;
+}
+
+extern "C" int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, float* dw, void* stream) {
+    SCL_REQUIRE(part && dw && nslab > 0 && Co <= COUTp && Ci <= CINp, "rs_wgrad_reduce: bad arguments");
+    const int n_el = ntaps * CINp * COUTp;
+    hipLaunchKernelGGL(rs_wgrad_reduce_kernel, dim3((n_el + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nslab, ntaps, CINp, COUTp, Co, Ci, dw);
+    return scl_check_launch("rs_wgrad_reduce");
+}
+
+extern "C" int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, const SclRsGeom* geom, void* stream) {
+    SCL_REQUIRE(y && stats && a && geom && C % 4 == 0, "rs_bn_act: bad arguments");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    const long long n4 = (long long)q.G * (C / 4);
+    hipLaunchKernelGGL(rs_bn_act_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y, stats, a, C, q);
+    return scl_check_launch("rs_bn_act");
+}
+
+extern "C" int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, const SclRsGeom* geom, void* stream) {
+    SCL_REQUIRE(dz && y && stats && bstats && geom && C % 4 == 0, "rs_bn_bwd_apply: bad arguments");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    const long long n4 = (long long)q.G * (C / 4);
+    hipLaunchKernelGGL(rs_bn_bwd_apply_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dz, y, stats, bstats, C, q);
+    return scl_check_launch("rs_bn_bwd_apply");
+}
+
+extern "C" int scl_rs_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                                    float* stats, void* stream) {
+    SCL_REQUIRE(running_mean && running_var && stats && C > 0, "rs_bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(rs_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, stats);
+    return scl_check_launch("rs_bn_eval_stats");
+}
+
+extern "C" int scl_rs_copy(const float* src, float* dst, int Cs, int Cd, int to_dense, const SclRsGeom* geom, void* stream) {
+    SCL_REQUIRE(src && dst && geom && Cs > 0 && Cd > 0, "rs_copy: bad arguments");
+    SCL_REQUIRE(to_dense ? Cd <= Cs : Cs <= Cd, "rs_copy: channel counts");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    const int H = geom->r_hi - geom->r_lo + 1;
+    const long long n = to_dense ? (long long)geom->B * H * q.W * Cd : (long long)q.G * Cd;
+    hipLaunchKernelGGL(rs_copy_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, dst, Cs, Cd, H, to_dense ? 1 : 0, q);
+    return scl_check_launch("rs_copy");
+}

@@ -1,0 +1,280 @@
+"""The six Residual_blocks of the AASIST encoder (model/wav2vec2_aasist.py:377-433, stacked at :470-476) as ONE autograd node over the
+kernels of csrc/resstack.hip: forward = 3 launches per block (conv1 + BatchNorm statistics, BatchNorm + SELU, conv2 + residual [+ the
+1x3 down-sample convolution]), backward = 7-9 per block, no padded copies, no torch glue, parameter gradients written straight into
+`p.grad` (the flat gradient buffer of the model) by the reducing kernels.
+
+    res_stack(x0 [B, H, W, 1] f32 channels-last, blocks = [Residual_block, ...]) -> [B, H, W, C_last]
+
+Maps live zero-bordered and flat (see the header of resstack.hip): a (kh, kw) tap is a flat shift, so the stride-1 convolutions, their
+data gradients (negated shifts, transposed weights) and weight gradients all read the maps in place.
+
+Reference quirks kept: conv1 reads the block INPUT (the bn1 + SELU result is discarded, :414-420) while bn1's running statistics are
+still updated in training — here from the statistics the previous block's conv2 epilogue already gathers; conv1's bias gradient is
+computed (it is round-off around zero: BatchNorm cancels the bias) because the reference computes it.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from . import ops
+
+_SIZES = {(16, 32), (32, 32), (32, 64), (64, 64)}
+
+
+def supported(blocks):
+    """The instantiated channel steps: 1 (carried as 16) | 32 | 64 -> 32 | 64, kernels (2,3) / (2,3) / (1,3)."""
+    try:
+        for i, blk in enumerate(blocks):
+            co, ci, kh, kw = blk.conv1.weight.shape
+            if (kh, kw) != (2, 3) or tuple(blk.conv2.weight.shape) != (co, co, 2, 3) or (max(ci, 16), co) not in _SIZES:
+                return False
+            if ci not in (1, 16, 32, 64) or (ci == 1 and i != 0):
+                return False
+            if blk.downsample and tuple(blk.conv_downsample.weight.shape) != (co, ci, 1, 3):
+                return False
+            if not blk.downsample and ci != co:
+                return False
+        return len(blocks) > 0
+    except AttributeError:
+        return False
+
+
+def _grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class _Plan:
+    """Buffers of one (B, H, W, channel plan); a plan is busy from a grad-mode forward until its backward."""
+
+    def __init__(self, B, H, W, chans, dev):
+        self.key = (B, H, W, tuple(chans))
+        self.B, self.H, self.W, self.Wp = B, H, W, W + 2
+        self.G = B * (H + 2) * self.Wp
+        self.slack = self.Wp + 2 + 128 + 6          # positions on either side of [0, G): halo of the first / last tile
+        self.busy = False
+        self.dev = dev
+        z = lambda c: torch.zeros((self.G + 2 * self.slack) * c, device=dev)      # zero once: the slack is read, never written
+        cps = [max(16, chans[0])] + list(chans[1:])
+        self.cps = cps
+        n = len(cps) - 1
+        self.x = [z(c) for c in cps]
+        self.y1 = [z(c) for c in cps[1:]]
+        self.a = [z(c) for c in cps[1:]]
+        self.tmp = z(max(cps))
+        self.stats = [torch.zeros(4 * c, device=dev) for c in cps[1:]]
+        self.bstats = torch.zeros(2 * max(cps), device=dev)
+        self.acc = torch.zeros(2 * max(cps), dtype=torch.float64, device=dev)      # left zeroed by every finishing block
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dx = [z(c) for c in cps]
+        self.dz = z(max(cps))
+        self.dtmp = z(max(cps))
+        self.wpk = None
+        nsl = L.load().scl_rs_wgrad_nslabs
+        self.part = torch.empty(max(nsl(co) * 6 * ci * co for ci, co in zip(cps[:-1], cps[1:])) + max(nsl(c) * 6 * c * c for c in cps[1:]), device=dev)
+        self.gx = L.SclRsGeom(B, H, W, 1, H, 0)        # block inputs / outputs: rows 1..H
+        self.gy = L.SclRsGeom(B, H, W, 0, H, 0)        # conv1 outputs (H + 1 rows): rows 0..H
+        Wp = self.Wp
+        self.s1 = [kh * Wp + kw - 1 for kh in (0, 1) for kw in (0, 1, 2)]
+        self.s2 = [(kh - 1) * Wp + kw - 1 for kh in (0, 1) for kw in (0, 1, 2)]
+        self.sd = [kw - 1 for kw in (0, 1, 2)]
+
+    def p(self, t, c):
+        """Pointer to flat position 0 of a bordered map with c channels."""
+        return t.data_ptr() + 4 * self.slack * c
+
+
+_PLANS = []
+
+
+def _acquire(B, H, W, chans, dev, hold):
+    key = (B, H, W, tuple(chans))
+    for pl in _PLANS:
+        if pl.key == key and pl.dev == dev and not pl.busy:
+            pl.busy = hold
+            return pl
+    same = [pl for pl in _PLANS if pl.key == key and pl.dev == dev]
+    if len(same) >= 3:          # forwards whose backward never came (eval-style use under grad mode): recycle the oldest
+        pl = same[0]
+        _PLANS.remove(pl)
+        _PLANS.append(pl)
+        pl.busy = hold
+        return pl
+    if len(_PLANS) >= 8:
+        _PLANS.pop(0)
+    pl = _Plan(B, H, W, chans, dev)
+    pl.busy = hold
+    _PLANS.append(pl)
+    return pl
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv(pl, inp, wpk, out, cin, cout, shifts, geom, *, bias=None, addend=None, stat_mode=0, nvalid=0.0, act_a=None, y1=None, bnstats=None,
+          gamma=None, beta=None, run_mean=None, run_var=None, nbt=None, stats_out=None, dgamma=None, dbeta=None, training=True, eps=1e-5, momentum=0.1):
+    d = L.SclRsConv()
+    d.inp, d.wpk, d.out = inp, wpk, out
+    pt = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+    d.bias, d.addend, d.act_a, d.y1, d.bnstats = pt(bias), pt(addend), pt(act_a), pt(y1), pt(bnstats)
+    d.acc, d.ticket = pl.acc.data_ptr(), pl.ticket.data_ptr()
+    d.gamma, d.beta, d.run_mean, d.run_var, d.nbt = pt(gamma), pt(beta), pt(run_mean), pt(run_var), pt(nbt)
+    d.stats_out, d.dgamma, d.dbeta = pt(stats_out), pt(dgamma), pt(dbeta)
+    d.nvalid = float(nvalid)
+    d.geom = geom
+    for i, s in enumerate(shifts):
+        d.shift[i] = s
+    d.cin, d.cout, d.ntaps, d.stat_mode, d.training = cin, cout, len(shifts), stat_mode, 1 if training else 0
+    d.eps, d.momentum = eps, momentum
+    ops._call("scl_rs_conv", ctypes.byref(d), _stream(), keep=d)
+
+
+def _pack_all(pl, blocks):
+    """Register images of every convolution (forward and data gradient) in one launch, into plan-owned buffers."""
+    jobs, views, off = [], {}, 0
+    total = 0
+    spec = []
+    for i, blk in enumerate(blocks):
+        ci_p, co = pl.cps[i], pl.cps[i + 1]
+        spec.append((i, "c1", blk.conv1.weight, 6, ci_p, co, 0))
+        spec.append((i, "c2", blk.conv2.weight, 6, co, co, 0))
+        spec.append((i, "c1T", blk.conv1.weight, 6, co, ci_p, 1))
+        spec.append((i, "c2T", blk.conv2.weight, 6, co, co, 1))
+        if blk.downsample:
+            spec.append((i, "ds", blk.conv_downsample.weight, 3, ci_p, co, 0))
+            spec.append((i, "dsT", blk.conv_downsample.weight, 3, co, ci_p, 1))
+    sizes = [nt * cinp * coutp for (_, _, _, nt, cinp, coutp, _) in spec]
+    if pl.wpk is None or pl.wpk.numel() < sum(sizes):
+        pl.wpk = torch.empty(sum(sizes), device=pl.dev)
+    arr = (L.SclRsPackJob * len(spec))()
+    for k, ((i, name, w, nt, cinp, coutp, tr), n) in enumerate(zip(spec, sizes)):
+        wc = w.detach()
+        assert wc.is_contiguous() and wc.dtype == torch.float32
+        arr[k] = L.SclRsPackJob(wc.data_ptr(), pl.wpk.data_ptr() + 4 * off, wc.shape[0], wc.shape[1], nt, cinp, coutp, tr)
+        views[(i, name)] = pl.wpk.data_ptr() + 4 * off
+        off += n
+    assert len(spec) <= 32, "one pack launch holds 32 images (six Residual_blocks need 28)"
+    ops._call("scl_rs_pack_weights", arr, len(spec), _stream(), keep=arr)
+    return views
+
+
+def _bn_args(bn):
+    return dict(eps=float(bn.eps), momentum=0.1 if bn.momentum is None else float(bn.momentum))
+
+
+def _forward(pl, x0, blocks, training):
+    B, H, W = pl.B, pl.H, pl.W
+    S = _stream
+    wv = _pack_all(pl, blocks)
+    pl.wv = wv
+    ops._call("scl_rs_copy", x0.data_ptr(), pl.p(pl.x[0], pl.cps[0]), x0.shape[-1], pl.cps[0], 0, ctypes.byref(pl.gx), S(), keep=x0)
+    n_y, n_x = float(B * (H + 1) * W), float(B * H * W)
+    for i, blk in enumerate(blocks):
+        ci, co = pl.cps[i], pl.cps[i + 1]
+        xin, y1, a, xout = pl.p(pl.x[i], ci), pl.p(pl.y1[i], co), pl.p(pl.a[i], co), pl.p(pl.x[i + 1], co)
+        bn2 = blk.bn2
+        if training:
+            _conv(pl, xin, wv[(i, "c1")], y1, ci, co, pl.s1, pl.gy, bias=blk.conv1.bias, stat_mode=1, nvalid=n_y, gamma=bn2.weight, beta=bn2.bias,
+                  run_mean=bn2.running_mean, run_var=bn2.running_var, nbt=bn2.num_batches_tracked, stats_out=pl.stats[i], **_bn_args(bn2))
+        else:
+            _conv(pl, xin, wv[(i, "c1")], y1, ci, co, pl.s1, pl.gy, bias=blk.conv1.bias)
+            ops._call("scl_rs_bn_eval_stats", bn2.weight.data_ptr(), bn2.bias.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(),
+                      float(bn2.eps), co, pl.stats[i].data_ptr(), S())
+        ops._call("scl_rs_bn_act", y1, pl.stats[i].data_ptr(), a, co, ctypes.byref(pl.gy), S())
+        if blk.downsample:
+            tmp = pl.p(pl.tmp, co)
+            _conv(pl, xin, wv[(i, "ds")], tmp, ci, co, pl.sd, pl.gx, bias=blk.conv_downsample.bias)
+            addend = tmp
+        else:
+            addend = xin
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        if training and nxt is not None and not nxt.first:      # the next block's bn1: result discarded by the reference, running statistics kept
+            bn1 = nxt.bn1
+            _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend, stat_mode=1, nvalid=n_x,
+                  run_mean=bn1.running_mean, run_var=bn1.running_var, nbt=bn1.num_batches_tracked, **_bn_args(bn1))
+        else:
+            _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend)
+    c_last = pl.cps[-1]
+    out = torch.empty(B, H, W, c_last, device=pl.dev)
+    ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S(), keep=out)
+    return out
+
+
+def _wgrad(pl, inp, dout, cin, cout, shifts, w, bias, co_real, ci_real):
+    arr = (ctypes.c_int32 * 6)(*(list(shifts) + [0] * (6 - len(shifts))))
+    nslab = L.load().scl_rs_wgrad_nslabs(cout)
+    ops._call("scl_rs_wgrad", inp, dout, cin, cout, len(shifts), arr, ctypes.byref(pl.gx), pl.part.data_ptr(), pl.acc.data_ptr(), pl.ticket.data_ptr(),
+              _grad(bias).data_ptr(), _stream(), keep=arr)
+    ops._call("scl_rs_wgrad_reduce", pl.part.data_ptr(), nslab, len(shifts), cin, cout, co_real, ci_real, _grad(w).data_ptr(), _stream())
+
+
+def _backward(pl, d_out, blocks, training, need_dx0):
+    B, H, W = pl.B, pl.H, pl.W
+    S = _stream
+    wv = pl.wv
+    c_last = pl.cps[-1]
+    n_y = float(B * (H + 1) * W)
+    d_out = d_out.contiguous().float()
+    ops._call("scl_rs_copy", d_out.data_ptr(), pl.p(pl.dx[-1], c_last), c_last, c_last, 0, ctypes.byref(pl.gx), S(), keep=d_out)
+    neg = lambda s: [-v for v in s]
+    for i in reversed(range(len(blocks))):
+        blk = blocks[i]
+        ci, co = pl.cps[i], pl.cps[i + 1]
+        ci_real = blk.conv1.weight.shape[1]
+        dcur, dprev = pl.p(pl.dx[i + 1], co), pl.p(pl.dx[i], ci)
+        xin, y1, a, dz = pl.p(pl.x[i], ci), pl.p(pl.y1[i], co), pl.p(pl.a[i], co), pl.p(pl.dz, co)
+        bn2 = blk.bn2
+        # conv2 data gradient x selu'(a) -> dz, its two batch sums -> dgamma / dbeta / the means of the BatchNorm backward
+        _conv(pl, dcur, wv[(i, "c2T")], dz, co, co, neg(pl.s2), pl.gy, stat_mode=2, nvalid=n_y, act_a=a, y1=y1, bnstats=pl.stats[i],
+              dgamma=_grad(bn2.weight), dbeta=_grad(bn2.bias), stats_out=pl.bstats, training=training)
+        ops._call("scl_rs_bn_bwd_apply", dz, y1, pl.stats[i].data_ptr(), pl.bstats.data_ptr(), co, ctypes.byref(pl.gy), S())      # dz is now d(conv1 output)
+        _wgrad(pl, a, dcur, co, co, pl.s2, blk.conv2.weight, blk.conv2.bias, co, co)
+        _wgrad(pl, xin, dz, ci, co, pl.s1, blk.conv1.weight, blk.conv1.bias, co, ci_real)
+        if blk.downsample:
+            _wgrad(pl, xin, dcur, ci, co, pl.sd, blk.conv_downsample.weight, blk.conv_downsample.bias, co, ci_real)
+        if i == 0 and not need_dx0:
+            break
+        if blk.downsample:
+            dtmp = pl.p(pl.dtmp, ci)
+            _conv(pl, dcur, wv[(i, "dsT")], dtmp, co, ci, neg(pl.sd), pl.gx)
+            addend = dtmp
+        else:
+            addend = dcur
+        _conv(pl, dz, wv[(i, "c1T")], dprev, co, ci, neg(pl.s1), pl.gx, addend=addend)
+    if not need_dx0:
+        return None
+    dx0 = torch.empty(B, H, W, 1, device=pl.dev)
+    ops._call("scl_rs_copy", pl.p(pl.dx[0], pl.cps[0]), dx0.data_ptr(), pl.cps[0], 1, 1, ctypes.byref(pl.gx), S(), keep=dx0)
+    return dx0
+
+
+class _ResStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, blocks, training, hold, *params):
+        B, H, W, _ = x0.shape
+        chans = [blocks[0].conv1.weight.shape[1]] + [b.conv1.weight.shape[0] for b in blocks]
+        pl = _acquire(B, H, W, chans, x0.device, hold)
+        out = _forward(pl, x0.contiguous().float(), blocks, training)
+        ctx.pl, ctx.blocks, ctx.training = pl, blocks, training
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pl = ctx.pl
+        try:
+            dx0 = _backward(pl, d_out, ctx.blocks, ctx.training, ctx.needs_input_grad[0])
+        finally:
+            pl.busy = False
+        return (dx0, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)      # parameter gradients were accumulated into p.grad by the kernels
+
+
+def res_stack(x0, blocks):
+    """x0 [B, H, W, 1] -> [B, H, W, C]; `blocks`: the Residual_block modules (parameters, BatchNorm buffers and the training flag)."""
+    blocks = list(blocks)
+    training = bool(blocks[0].training)
+    params = [p for b in blocks for p in b.parameters()]
+    hold = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in params))      # busy until the backward has run
+    return _ResStackFn.apply(x0, blocks, training, hold, *params)
