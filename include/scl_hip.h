@@ -366,12 +366,14 @@ typedef struct SclRsGeom { int32_t B, H, W, r_lo, r_hi, _pad; } SclRsGeom;
  * convolution over a bordered map is ONE flat shift; the data gradient is the same call with negated shifts and transposed weights.
  * wpk: scl_rs_pack_weights image.  (cin, cout, ntaps) in {(16|32,32,6), (32|64,64,6), (16,32,3), (32,64,3), (32,16,3|6), (64,32,3|6)}.
  * stat_mode 1: per-channel sum / sum of squares of the stored values; the last block turns them into BatchNorm statistics
- *   stats_out[4][cout] = mean, rstd, gamma * rstd, beta - mean * gamma * rstd (biased variance, eps) and, when run_mean is given, updates
+ *   stats_out[4][cout] = mean, rstd, gamma * rstd, beta (biased variance, eps) and, when run_mean is given, updates
  *   running_mean / running_var (momentum, unbiased) and num_batches_tracked exactly as nn.BatchNorm2d in training does.
  * stat_mode 2 (BatchNorm + SELU backward, first half): out = mask * conv * selu'(act_a) = dz; sums of dz and dz * xhat with
  *   xhat = (y1 - mean) * rstd from bnstats; the last block adds them to dbeta / dgamma and stores stats_out[2][cout] = their means
  *   (zeros when training == 0) for scl_rs_bn_bwd_apply.
- * acc: 2 * cout zeroed doubles, ticket: one zeroed uint32 (both are left zeroed).  nvalid = number of unmasked positions. */
+ * acc: SCL_RS_NSLOT * 2 * cout zeroed doubles, ticket: one zeroed uint32 (both are left zeroed).  nvalid = number of unmasked positions.
+ * stat_mode 1 exists for the forward shapes (cout >= cin, six taps), stat_mode 2 for cin == cout, six taps. */
+#define SCL_RS_NSLOT 16
 typedef struct SclRsConv {
     const float* in; const float* wpk; const float* bias; const float* addend; float* out;
     const float* act_a; const float* y1; const float* bnstats;
@@ -391,14 +393,14 @@ int scl_rs_conv(const SclRsConv* c, void* stream);
 #define SCL_RS_MAX_PACK_JOBS 32
 typedef struct SclRsPackJob { const float* w; float* out; int32_t Co, Ci, ntaps, CINp, COUTp, transposed; } SclRsPackJob;
 int scl_rs_pack_weights(const SclRsPackJob* jobs, int njobs, void* stream);
-/* part[scl_rs_wgrad_nslabs(cout)][ntaps * cin * cout] f32 partial slabs of dW[t][c][n] = sum_g in[g + shift[t]][c] * dout[g][n]
- * (dout zero off the valid positions); dbias[n] += sum_g dout[g][n] when dbias != NULL (bacc: cout zeroed doubles, ticket as above) */
-int scl_rs_wgrad_nslabs(int cout);
+/* part[scl_rs_wgrad_nslabs(cin, cout)][ntaps * cin * cout] f32 partial slabs of dW[t][c][n] = sum_g in[g + shift[t]][c] * dout[g][n]
+ * (dout zero off the valid positions); dbias[n] += sum_g dout[g][n] when dbias != NULL (bacc: SCL_RS_NSLOT * cout zeroed doubles, ticket as above) */
+int scl_rs_wgrad_nslabs(int cin, int cout);
 int scl_rs_wgrad(const float* in, const float* dout, int cin, int cout, int ntaps, const int* shift, const SclRsGeom* geom, float* part,
                  double* bacc, uint32_t* ticket, float* dbias, void* stream);
 /* dw (torch layout [Co, Ci, ntaps]) += the slabs, summed in index order */
 int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, float* dw, void* stream);
-/* a = mask * selu(y * stats[2] + stats[3]) (BatchNorm + SELU, model/wav2vec2_aasist.py:423-424) */
+/* a = mask * selu((y - stats[0]) * stats[2] + stats[3]) (BatchNorm + SELU, model/wav2vec2_aasist.py:423-424) */
 int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, const SclRsGeom* geom, void* stream);
 /* in place: dz := mask * stats[2] * (dz - bstats[0] - (y - stats[0]) * stats[1] * bstats[1]) — the input gradient of that BatchNorm */
 int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, const SclRsGeom* geom, void* stream);

@@ -168,7 +168,7 @@ class AasistHead(nn.Module):
         x = hipnn.max_pool3(feats.transpose(1, 2)).unsqueeze(-1)
         x = hipnn.batch_norm(x, self.first_bn, hipnn.ACT_SELU)
         blocks = [blk[0] for blk in self.encoder]
-        if FUSED_STACK and resstack.supported(blocks):
+        if FUSED_STACK and resstack.supported(blocks, x.shape[2]):
             x = resstack.res_stack(x, blocks)          # the six Residual_blocks as one autograd node (csrc/resstack.hip)
         else:
             for blk in blocks:

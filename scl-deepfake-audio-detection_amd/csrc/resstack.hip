@@ -27,16 +27,34 @@ namespace {
 
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
-constexpr int RS_MT = 128;      // output positions per tile of the convolution kernel
-constexpr int RS_PC = 64;       // positions per chunk of the weight-gradient kernel
+// output positions per tile of the convolution kernel: 64 input channels keep 96 weight registers per lane, so that form runs ONE block
+// per CU with all 512 registers (256-position tiles, the next tile's 84 registers of input in flight); narrower inputs run two blocks
+// per CU on 128-position tiles
+__host__ __device__ constexpr int rs_mt(int cin) { return cin >= 64 ? 256 : 128; }
+// positions per chunk of the weight-gradient kernel: the 64 -> 64 form (96 accumulator + 50 fragment registers per lane) runs one block
+// per CU on 128-position chunks, the narrower ones two blocks per CU on 64-position chunks
+__host__ __device__ constexpr int rs_pc(int cin, int cout) { return cin * cout >= 4096 ? 128 : 64; }
+__host__ __device__ constexpr int rs_wgrad_blocks(int cin, int cout) { return cin * cout >= 4096 ? 256 : 512; }
+constexpr int RS_MAX_SPAN = 96; // largest halo (W + 3 positions) the register prefetch is sized for: maps up to 93 positions wide
 
-struct RsGeom { int G, Wp, RPU, W, r_lo, r_hi; };
+struct RsGeom { int G, Wp, RPU, W, r_lo, r_hi; unsigned m_wp, m_rpu; };      // m_*: ceil(65536 / x), exact quotients for dividends < 65536 / x
 
 __device__ __forceinline__ bool rs_valid(const RsGeom& q, unsigned g) {
     if (g >= (unsigned)q.G) return false;
     const unsigned row = g / (unsigned)q.Wp;
     const int c = (int)(g - row * (unsigned)q.Wp);
     const int r = (int)(row % (unsigned)q.RPU);
+    return r >= q.r_lo && r <= q.r_hi && c >= 1 && c <= q.W;
+}
+
+// The same test for position g0 + pos of a tile whose first position sits at (row0 % RPU, col0): two 16-bit magic divisions of small
+// numbers instead of two 32-bit integer divisions per position (they were most of the epilogue's instructions).
+__device__ __forceinline__ bool rs_valid_rel(const RsGeom& q, unsigned rr0, unsigned col0, unsigned pos) {
+    const unsigned x = col0 + pos;                        // < Wp + 256
+    const unsigned dq = (x * q.m_wp) >> 16;               // x / Wp
+    const int c = (int)(x - dq * (unsigned)q.Wp);
+    const unsigned y = rr0 + dq;                          // < RPU + 256 / Wp + 1
+    const int r = (int)(y - ((y * q.m_rpu) >> 16) * (unsigned)q.RPU);
     return r >= q.r_lo && r <= q.r_hi && c >= 1 && c <= q.W;
 }
 
@@ -56,34 +74,46 @@ struct RsConvK {
 __device__ __forceinline__ float selu_f(float v) { return v > 0.f ? SELU_SCALE * v : SELU_SCALE * SELU_ALPHA * (__expf(v) - 1.0f); }
 __device__ __forceinline__ float selu_grad_from_y(float y) { return y > 0.f ? SELU_SCALE : y + SELU_SCALE * SELU_ALPHA; }
 
-// Every block adds its n fp64 partials to acc[0..n) with atomics; the LAST block to arrive (ticket) sees the totals, hands them to `fin`
-// thread by thread and leaves accumulators and ticket zeroed for the next launch.  fp64 addition order varies from run to run, i.e. the
-// totals carry an order-dependent error of ~1e-16 relative — invisible after the rounding to fp32 that every consumer applies.
+// Every block adds its n fp64 partials to ONE OF RS_NSLOT accumulator rows (row = block index mod RS_NSLOT: 512 blocks on one row would
+// serialise 512 atomics per address at the L2) with hardware fp64 atomics; the LAST block to arrive (ticket) sums the rows in index
+// order, hands the totals to `fin` and leaves rows and ticket zeroed for the next launch.  fp64 addition order inside a row varies from
+// run to run: an order-dependent error of ~1e-16 relative, invisible after the rounding to fp32 that every consumer applies.
+constexpr int RS_NSLOT = SCL_RS_NSLOT;
 template <class F>
 __device__ __forceinline__ void rs_finish(double* acc, unsigned* ticket, int n, const double* mine, double* lds_tot, F fin) {
     __shared__ int is_last;
     const int tid = threadIdx.x;
-    if (tid < n) atomicAdd(&acc[tid], mine[tid]);
-    __threadfence();
+    // No __threadfence(): at agent scope it writes the XCD's whole L2 back (this kernel has just stored its output map there) — 40 us per
+    // launch with 512 blocks doing it.  The partials travel as RETURNING atomics instead: a thread has its old value back only once the
+    // addition has been performed at the device-coherent level, the barrier collects all of them, then the ticket goes out.
+    if (tid < n) {
+        const double old = __hip_atomic_fetch_add(&acc[(blockIdx.x % RS_NSLOT) * n + tid], mine[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));
+    }
     __syncthreads();
-    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (tid == 0) is_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     if (tid < n) {
-        lds_tot[tid] = __hip_atomic_load(&acc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double t = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < RS_NSLOT; ++sl) {
+            t += __hip_atomic_load(&acc[sl * n + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&acc[sl * n + tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_tot[tid] = t;
     }
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     fin(lds_tot);
 }
 
-template <int CIN, int COUT, int NT>
-__global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
+template <int CIN, int COUT, int NT, int SM>      // SM: statistics mode of the epilogue (0 none, 1 BatchNorm forward, 2 BatchNorm + SELU backward)
+__global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const RsConvK d) {
+    constexpr int RS_MT = rs_mt(CIN);
     constexpr int NCB = COUT / 16;            // 16-channel output blocks: one per wave (64), two waves per block (32), four (16)
-    constexpr int NRG = 4 / NCB;              // wave groups that split the tile's eight 16-position row blocks
-    constexpr int RPW = 8 / NRG;              // row blocks per wave
+    constexpr int NRG = 4 / NCB;              // wave groups that split the tile's 16-position row blocks
+    constexpr int RPW = (RS_MT / 16) / NRG;   // row blocks per wave
     constexpr int RBG = RPW < 4 ? RPW : 4;    // row blocks in flight (independent accumulators: >= 2 covers the 40-cycle MFMA latency)
     constexpr int NGRP = RPW / RBG;
     constexpr int NJJ = CIN / 16;
@@ -105,23 +135,39 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
     const int ch4 = tid % N4;                 // the four output channels this thread owns in every epilogue pass (256 % N4 == 0)
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, mean4 = bias4, rstd4 = bias4;
     if (d.bias) bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * ch4);
-    if (d.stat_mode == 2) {
+    if (SM == 2) {
         mean4 = *reinterpret_cast<const f32x4*>(d.bnstats + 4 * ch4);
         rstd4 = *reinterpret_cast<const f32x4*>(d.bnstats + COUT + 4 * ch4);
     }
     double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int ntiles = (d.q.G + RS_MT - 1) / RS_MT;
-    const int nrows = RS_MT + d.span;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nf4 = (RS_MT + d.span) * C4;      // 16-byte pieces of a tile + halo: one contiguous range of the flat map
+    // The NEXT tile's input travels to registers while this one is multiplied (a load -> ds_write loop inside the tile pays one memory
+    // latency per trip: 13 trips x ~1 us against 12 us of MFMAs); the epilogue's operand reads go out four passes at a time.
+    constexpr int NLD = ((RS_MT + RS_MAX_SPAN) * C4 + 255) / 256;
+    f32x4 pre[NLD];
+    auto issue = [&](int tile) {
+        const float* src = d.in + ((long long)tile * RS_MT + d.smin) * CIN;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int f = tid + 256 * u;
+            if (f < nf4) pre[u] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         const int g0 = tile * RS_MT;
-        {   // input tile + halo: one contiguous range of the flat map
-            const float* src = d.in + ((long long)g0 + d.smin) * CIN;
-            for (int f = tid; f < nrows * C4; f += 256) {
-                const int pos = f / C4, c4 = f - pos * C4;
-                *reinterpret_cast<f32x4*>(lds + pos * PITCH + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
-            }
+        const unsigned row0 = (unsigned)g0 / (unsigned)d.q.Wp, col0 = (unsigned)g0 - row0 * (unsigned)d.q.Wp, rr0 = row0 % (unsigned)d.q.RPU;      // uniform: scalar ALU
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int f = tid + 256 * u;
+            if (f < nf4) { const int pos = f / C4, c4 = f - pos * C4; *reinterpret_cast<f32x4*>(lds + pos * PITCH + 4 * c4) = pre[u]; }
         }
         __syncthreads();
+#ifndef RS_NO_LOAD
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+#endif
         f32x4 acc[NGRP][RBG];
 #pragma unroll
         for (int gp = 0; gp < NGRP; ++gp) {
@@ -139,7 +185,11 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int r = 0; r < RBG; ++r)
+#ifndef RS_NO_MFMA
                             acc[gp][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][jj][j], b4[r][j], acc[gp][r], 0, 0, 0);
+#else
+                            acc[gp][r][j] += w[t][jj][j] * b4[r][j];
+#endif
                 }
             }
         }
@@ -150,38 +200,56 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
             for (int r = 0; r < RBG; ++r)
                 *reinterpret_cast<f32x4*>(lds + (((rg * RPW + gp * RBG + r) * 16) + li) * OPITCH + 16 * cb + 4 * g4) = acc[gp][r];
         __syncthreads();
-#pragma unroll 2
-        for (int f = tid; f < RS_MT * N4; f += 256) {
-            const int pos = f / N4;
-            const unsigned g = (unsigned)(g0 + pos);
-            if (g >= (unsigned)d.q.G) continue;
-            const bool ok = rs_valid(d.q, g);
-            f32x4 v = *reinterpret_cast<const f32x4*>(lds + pos * OPITCH + 4 * ch4);
-            const size_t off = (size_t)g * COUT + 4 * ch4;
-            v += bias4;
-            if (d.addend) v += *reinterpret_cast<const f32x4*>(d.addend + off);
-            if (d.stat_mode == 2) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(d.act_a + off), y = *reinterpret_cast<const f32x4*>(d.y1 + off);
+        constexpr int NPASS = RS_MT * N4 / 256, EB = NPASS < 4 ? NPASS : 4;
+#ifdef RS_NO_EPI
+        if (d.q.G > 0) { if (tid == 0) d.out[(size_t)g0 * COUT] = lds[tid]; __syncthreads(); continue; }
+#endif
+        // statistics of the tile in fp32 (16 or fewer values per thread and channel), carried in fp64 across tiles
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+        for (int p0 = 0; p0 < NPASS; p0 += EB) {
+            f32x4 ad[EB], aa[EB], yy[EB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = ok ? v[e] * selu_grad_from_y(a[e]) : 0.f;
-                    const float xh = (y[e] - mean4[e]) * rstd4[e];
-                    st[e] += (double)v[e];
-                    st[4 + e] += ok ? (double)v[e] * (double)xh : 0.0;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-                if (d.stat_mode == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { st[e] += (double)v[e]; st[4 + e] += (double)v[e] * (double)v[e]; }
+            for (int u = 0; u < EB; ++u) {
+                const int pos = (tid + 256 * (p0 + u)) / N4;
+                const unsigned g = (unsigned)(g0 + pos);
+                const size_t off = (size_t)g * COUT + 4 * ch4;
+                ad[u] = f32x4{0.f, 0.f, 0.f, 0.f}; aa[u] = ad[u]; yy[u] = ad[u];
+                if (g < (unsigned)d.q.G) {
+                    if (d.addend) ad[u] = *reinterpret_cast<const f32x4*>(d.addend + off);
+                    if (SM == 2) { aa[u] = *reinterpret_cast<const f32x4*>(d.act_a + off); yy[u] = *reinterpret_cast<const f32x4*>(d.y1 + off); }
                 }
             }
-            *reinterpret_cast<f32x4*>(d.out + off) = v;
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int pos = (tid + 256 * (p0 + u)) / N4;
+                const unsigned g = (unsigned)(g0 + pos);
+                if (g >= (unsigned)d.q.G) continue;
+                const bool ok = rs_valid_rel(d.q, rr0, col0, (unsigned)pos);
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds + pos * OPITCH + 4 * ch4);
+                v += bias4;
+                v += ad[u];
+                if (SM == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = ok ? v[e] * selu_grad_from_y(aa[u][e]) : 0.f;
+                        t0[e] += v[e];
+                        t1[e] += v[e] * ((yy[u][e] - mean4[e]) * rstd4[e]);      // v is 0 off the valid positions (y1 is finite everywhere)
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                    if (SM == 1) { t0 += v; t1 += v * v; }
+                }
+                *reinterpret_cast<f32x4*>(d.out + (size_t)g * COUT + 4 * ch4) = v;
+            }
+        }
+        if (SM != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { st[e] += (double)t0[e]; st[4 + e] += (double)t1[e]; }
         }
         __syncthreads();      // the staging area becomes the next input tile
     }
-    if (d.stat_mode == 0) return;
+    if (SM == 0) return;
     // block totals: the 256 / N4 threads that share a channel quad, in a fixed order
     double* ld = reinterpret_cast<double*>(lds);
 #pragma unroll
@@ -198,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
     rs_finish(d.acc, d.ticket, 2 * COUT, mine, mine + 2 * COUT, [&](const double* tot) {
         if (tid >= COUT) return;
         const int c = tid;
-        if (d.stat_mode == 1) {
+        if (SM == 1) {
             // BatchNorm forward statistics (nn.BatchNorm2d in training: biased variance to normalise, unbiased into the running buffer)
             const double m = tot[c] / d.nvalid;
             double var = tot[COUT + c] / d.nvalid - m * m;
@@ -207,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
                 const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
                 const float sc = (d.gamma ? d.gamma[c] : 1.f) * rstd;
                 d.stats_out[c] = (float)m; d.stats_out[COUT + c] = rstd;
-                d.stats_out[2 * COUT + c] = sc; d.stats_out[3 * COUT + c] = (d.beta ? d.beta[c] : 0.f) - (float)m * sc;
+                d.stats_out[2 * COUT + c] = sc; d.stats_out[3 * COUT + c] = d.beta ? d.beta[c] : 0.f;
             }
             if (d.run_mean) {
                 const double unb = d.nvalid > 1.0 ? var * d.nvalid / (d.nvalid - 1.0) : var;
@@ -226,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void rs_conv_kernel(const RsConvK d) {
 }
 
 // ---- element-wise passes ---------------------------------------------------------------------------------------------------------------
-// a = selu(y * sc + sh) on the valid positions, 0 on the borders (they are conv2's zero padding)
+// a = selu((y - mean) * sc + beta) on the valid positions, 0 on the borders (they are conv2's zero padding)
 __global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ a, int C, RsGeom q) {
     const int c4n = C >> 2;
     const long long n4 = (long long)q.G * c4n;
@@ -235,10 +303,10 @@ __global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict_
         const int c = (int)(f - (long long)g * c4n) * 4;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (rs_valid(q, g)) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(y + f * 4), sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c),
-                        sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + f * 4), mean = *reinterpret_cast<const f32x4*>(stats + c),
+                        sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c), be = *reinterpret_cast<const f32x4*>(stats + 3 * C + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = selu_f(v[e] * sc[e] + sh[e]);
+            for (int e = 0; e < 4; ++e) o[e] = selu_f((v[e] - mean[e]) * sc[e] + be[e]);
         }
         *reinterpret_cast<f32x4*>(a + f * 4) = o;
     }
@@ -269,7 +337,7 @@ __global__ void rs_bn_eval_stats_kernel(const float* gamma, const float* beta, c
     if (c >= C) return;
     const float rstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
     const float sc = (gamma ? gamma[c] : 1.f) * rstd;
-    stats[c] = rm[c]; stats[C + c] = rstd; stats[2 * C + c] = sc; stats[3 * C + c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+    stats[c] = rm[c]; stats[C + c] = rstd; stats[2 * C + c] = sc; stats[3 * C + c] = beta ? beta[c] : 0.f;
 }
 
 // ---- dense <-> bordered copies ------------------------------------------------------------------------------------------------------------
@@ -334,7 +402,8 @@ struct RsWgradK {
 };
 
 template <int CIN, int COUT, int NT>
-__global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(const RsWgradK d) {
+__global__ __launch_bounds__(256, (CIN * COUT >= 4096 ? 1 : 2)) void rs_wgrad_kernel(const RsWgradK d) {
+    constexpr int RS_PC = rs_pc(CIN, COUT);
     constexpr int NCB = COUT / 16, NPART = 4 / NCB, NCBK = CIN / 16;
     constexpr int PA = CIN == 16 ? 16 : CIN + 16;          // 4 position rows x 16 channels of a 4-byte read hit 64 distinct banks
     constexpr int PD = COUT == 16 ? 16 : COUT + 16;
@@ -352,32 +421,69 @@ __global__ __launch_bounds__(256, 2) void rs_wgrad_kernel(const RsWgradK d) {
         for (int k = 0; k < NCBK; ++k) acc[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     double bs[4] = {0, 0, 0, 0};
     const int nchunks = (d.G + RS_PC - 1) / RS_PC;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int nf4 = nrows * C4;
+    constexpr int NLA = ((RS_PC + RS_MAX_SPAN) * C4 + 255) / 256, NLO = (RS_PC * N4 + 255) / 256;
+    f32x4 pa[NLA], po[NLO];      // the next chunk of both maps, in flight while this one is multiplied
+    auto issue = [&](int chunk) {
         const int p0 = chunk * RS_PC;
-        {
-            const float* src = d.in + ((long long)p0 + d.smin) * CIN;
-            for (int f = tid; f < nrows * C4; f += 256) {
-                const int pos = f / C4, c4 = f - pos * C4;
-                *reinterpret_cast<f32x4*>(la + pos * PA + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
-            }
-            const float* sd = d.dout + (long long)p0 * COUT;
-            for (int f = tid; f < RS_PC * N4; f += 256) {        // f % N4 is the same in every pass (256 % N4 == 0): bs[] stays on one channel quad
+        const float* src = d.in + ((long long)p0 + d.smin) * CIN;
+#pragma unroll
+        for (int u = 0; u < NLA; ++u) {
+            const int f = tid + 256 * u;
+            if (f < nf4) pa[u] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+        }
+        const float* sd = d.dout + (long long)p0 * COUT;
+#pragma unroll
+        for (int u = 0; u < NLO; ++u) {
+            const int f = tid + 256 * u;
+            po[u] = f32x4{0.f, 0.f, 0.f, 0.f};      // past the map: zeros (garbage x 0 could be NaN)
+            if (f < RS_PC * N4 && p0 + f / N4 < d.G) po[u] = *reinterpret_cast<const f32x4*>(sd + (size_t)f * 4);
+        }
+    };
+    int chunk = blockIdx.x;
+    if (chunk < nchunks) issue(chunk);
+    for (; chunk < nchunks; chunk += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < NLA; ++u) {
+            const int f = tid + 256 * u;
+            if (f < nf4) { const int pos = f / C4, c4 = f - pos * C4; *reinterpret_cast<f32x4*>(la + pos * PA + 4 * c4) = pa[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NLO; ++u) {      // f % N4 is the same in every pass (256 % N4 == 0): bs[] stays on one channel quad
+            const int f = tid + 256 * u;
+            if (f < RS_PC * N4) {
                 const int pos = f / N4, c4 = f - pos * N4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (p0 + pos < d.G) v = *reinterpret_cast<const f32x4*>(sd + (size_t)f * 4);      // past the map: zeros (garbage x 0 could be NaN)
-                *reinterpret_cast<f32x4*>(ldo + pos * PD + 4 * c4) = v;
-                bs[0] += v[0]; bs[1] += v[1]; bs[2] += v[2]; bs[3] += v[3];
+                *reinterpret_cast<f32x4*>(ldo + pos * PD + 4 * c4) = po[u];
+                bs[0] += po[u][0]; bs[1] += po[u][1]; bs[2] += po[u][2]; bs[3] += po[u][3];
             }
         }
         __syncthreads();
-        for (int ks = pp; ks < RS_PC / 4; ks += NPART) {
-            const float b = ldo[(4 * ks + g4) * PD + 16 * nb + li];
+        if (chunk + (int)gridDim.x < nchunks) issue(chunk + gridDim.x);
+        // two k-steps in registers: the fragment reads of one step (NT * NCBK + 1 ds_read_b32) travel while the other step's MFMAs issue
+        // (read -> wait -> two MFMAs, as the compiler schedules the plain loop, leaves the matrix pipe idle for an LDS round trip per pair)
+        float a0[NT][NCBK], a1[NT][NCBK], b0, b1;
+        auto frag = [&](int ks, float (&a)[NT][NCBK], float& b) {
+            b = ldo[(4 * ks + g4) * PD + 16 * nb + li];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float* ta = la + (4 * ks + g4 + (d.shift[t] - d.smin)) * PA + li;
 #pragma unroll
-                for (int k = 0; k < NCBK; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[16 * k], b, acc[t][k], 0, 0, 0);
+                for (int k = 0; k < NCBK; ++k) a[t][k] = ta[16 * k];
             }
+        };
+        auto mma = [&](const float (&a)[NT][NCBK], float b) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < NCBK; ++k) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][k], b, acc[t][k], 0, 0, 0);
+        };
+        static_assert((RS_PC / 4) % (2 * NPART) == 0, "an even number of k-steps per wave");
+        frag(pp, a0, b0);
+        for (int ks = pp; ks < RS_PC / 4; ks += 2 * NPART) {
+            frag(ks + NPART, a1, b1);
+            mma(a0, b0);
+            if (ks + 2 * NPART < RS_PC / 4) frag(ks + 2 * NPART, a0, b0);
+            mma(a1, b1);
         }
         __syncthreads();
     }
@@ -435,19 +541,34 @@ __global__ __launch_bounds__(256) void rs_wgrad_reduce_kernel(const float* __res
     }
 }
 
+template <int CIN, int COUT, int NT, int SM>
+int rs_conv_launch_sm(const RsConvK& k, int grid, size_t lds, hipStream_t s) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_conv_kernel<CIN, COUT, NT, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SCL_LAUNCH((rs_conv_kernel<CIN, COUT, NT, SM>), dim3(grid), dim3(256), lds, s, k);
+    return scl_check_launch("rs_conv");
+}
+// which statistics modes an instantiation serves: 1 (BatchNorm forward) the forward shapes, 2 (BatchNorm backward) conv2's data gradient
 template <int CIN, int COUT, int NT>
 int rs_conv_launch_t(const RsConvK& k, int grid, hipStream_t s) {
+    constexpr int RS_MT = rs_mt(CIN);
+    const int ntiles = (k.q.G + RS_MT - 1) / RS_MT;
+    const int cap = CIN >= 64 ? 256 : 512;          // resident blocks: one / two per CU
+    grid = ntiles < cap ? ntiles : cap;
     const size_t lds_in = (size_t)(RS_MT + k.span) * (CIN + 4) * 4, lds_out = (size_t)RS_MT * (COUT + 4) * 4, lds_st = (size_t)(256 * 8 + 4 * COUT) * 8;
     size_t lds = lds_in > lds_out ? lds_in : lds_out;
     if (lds_st > lds) lds = lds_st;
     if (lds > 160 * 1024) { scl_set_error("rs_conv: tile + halo of %zu bytes exceeds the LDS", lds); return SCL_EINVAL; }
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_conv_kernel<CIN, COUT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SCL_LAUNCH((rs_conv_kernel<CIN, COUT, NT>), dim3(grid), dim3(256), lds, s, k);
-    return scl_check_launch("rs_conv");
+    constexpr bool FWD = NT == 6 && COUT >= CIN, C2T = NT == 6 && CIN == COUT;
+    if (k.stat_mode == 0) return rs_conv_launch_sm<CIN, COUT, NT, 0>(k, grid, lds, s);
+    if constexpr (FWD) { if (k.stat_mode == 1) return rs_conv_launch_sm<CIN, COUT, NT, 1>(k, grid, lds, s); }
+    if constexpr (C2T) { if (k.stat_mode == 2) return rs_conv_launch_sm<CIN, COUT, NT, 2>(k, grid, lds, s); }
+    scl_set_error("rs_conv: statistics mode %d is not instantiated for %d -> %d channels, %d taps", k.stat_mode, CIN, COUT, NT);
+    return SCL_EINVAL;
 }
 template <int CIN, int COUT, int NT>
 int rs_wgrad_launch_t(const RsWgradK& k, int grid, hipStream_t s) {
-    constexpr int PA = CIN == 16 ? 16 : CIN + 16, PD = COUT == 16 ? 16 : COUT + 16;
+    constexpr int PA = CIN == 16 ? 16 : CIN + 16, PD = COUT == 16 ? 16 : COUT + 16, RS_PC = rs_pc(CIN, COUT);
+    grid = rs_wgrad_blocks(CIN, COUT);
     size_t lds = ((size_t)(RS_PC + k.span) * PA + (size_t)RS_PC * PD) * 4;
     const size_t lds_st = (size_t)(256 * 4 + 2 * COUT) * 8;
     if (lds_st > lds) lds = lds_st;
@@ -463,6 +584,7 @@ bool rs_fill_geom(const SclRsGeom& g, RsGeom* q) {
     const long long G = (long long)g.B * q->RPU * q->Wp;
     if (G >= (1LL << 31) / 64) { scl_set_error("rs: map too large for 32-bit element offsets"); return false; }
     q->G = (int)G;
+    q->m_wp = (65536u + q->Wp - 1) / q->Wp; q->m_rpu = (65536u + q->RPU - 1) / q->RPU;
     return true;
 }
 bool rs_shifts(const int* shift, int ntaps, int* dst, int* smin, int* span) {
@@ -470,6 +592,7 @@ bool rs_shifts(const int* shift, int ntaps, int* dst, int* smin, int* span) {
     int lo = shift[0], hi = shift[0];
     for (int t = 0; t < 6; ++t) { dst[t] = t < ntaps ? shift[t] : 0; if (t < ntaps) { lo = shift[t] < lo ? shift[t] : lo; hi = shift[t] > hi ? shift[t] : hi; } }
     *smin = lo; *span = hi - lo;
+    if (*span > RS_MAX_SPAN) { scl_set_error("rs: halo of %d positions exceeds %d (map wider than %d)", *span, RS_MAX_SPAN, RS_MAX_SPAN - 3); return false; }
     return true;
 }
 
@@ -503,8 +626,7 @@ extern "C" int scl_rs_conv(const SclRsConv* c, void* stream) {
     k.acc = c->acc; k.ticket = c->ticket; k.gamma = c->gamma; k.beta = c->beta; k.run_mean = c->run_mean; k.run_var = c->run_var;
     k.nbt = (long long*)c->nbt; k.stats_out = c->stats_out; k.dgamma = c->dgamma; k.dbeta = c->dbeta;
     k.stat_mode = c->stat_mode; k.training = c->training; k.eps = c->eps; k.momentum = c->momentum; k.nvalid = c->nvalid;
-    const int ntiles = (k.q.G + RS_MT - 1) / RS_MT;
-    const int grid = ntiles < 512 ? ntiles : 512;
+    int grid = 0;          // chosen per instantiation (tile size, blocks per CU)
     hipStream_t s = (hipStream_t)stream;
     const int key = c->cin * 10000 + c->cout * 10 + c->ntaps;
     switch (key) {
@@ -524,7 +646,7 @@ extern "C" int scl_rs_conv(const SclRsConv* c, void* stream) {
     return SCL_EINVAL;
 }
 
-extern "C" int scl_rs_wgrad_nslabs(int cout) { return 512 * (cout >= 64 ? 1 : (cout == 32 ? 2 : 4)); }
+extern "C" int scl_rs_wgrad_nslabs(int cin, int cout) { return rs_wgrad_blocks(cin, cout) * (cout >= 64 ? 1 : (cout == 32 ? 2 : 4)); }
 
 extern "C" int scl_rs_wgrad(const float* in, const float* dout, int cin, int cout, int ntaps, const int* shift, const SclRsGeom* geom, float* part,
                             double* bacc, unsigned* ticket, float* dbias, void* stream) {
@@ -536,7 +658,7 @@ extern "C" int scl_rs_wgrad(const float* in, const float* dout, int cin, int cou
     if (!rs_shifts(shift, ntaps, k.shift, &k.smin, &k.span)) return SCL_EINVAL;
     k.in = in; k.dout = dout; k.part = part; k.bacc = bacc; k.ticket = ticket; k.dbias = dbias; k.G = q.G;
     hipStream_t s = (hipStream_t)stream;
-    const int grid = 512;      // fixed: the slab count the reduction walks (blocks past the last chunk write zero slabs)
+    int grid = 0;      // fixed per shape: the slab count the reduction walks (blocks past the last chunk write zero slabs)
     const int key = cin * 10000 + cout * 10 + ntaps;
     switch (key) {
         case 160326: return rs_wgrad_launch_t<16, 32, 6>(k, grid, s);

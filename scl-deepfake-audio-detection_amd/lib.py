@@ -168,7 +168,7 @@ def _protos():
         # resstack.hip
         "scl_rs_conv": ([P(SclRsConv), _vp], _i32),
         "scl_rs_pack_weights": ([P(SclRsPackJob), _i32, _vp], _i32),
-        "scl_rs_wgrad_nslabs": ([_i32], _i32),
+        "scl_rs_wgrad_nslabs": ([_i32, _i32], _i32),
         "scl_rs_wgrad": ([_vp, _vp, _i32, _i32, _i32, P(_i32), P(SclRsGeom), _vp, _vp, _vp, _vp, _vp], _i32),
         "scl_rs_wgrad_reduce": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
         "scl_rs_bn_act": ([_vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),

@@ -22,8 +22,13 @@ from . import ops
 _SIZES = {(16, 32), (32, 32), (32, 64), (64, 64)}
 
 
-def supported(blocks):
-    """The instantiated channel steps: 1 (carried as 16) | 32 | 64 -> 32 | 64, kernels (2,3) / (2,3) / (1,3)."""
+MAX_W = 93      # RS_MAX_SPAN of resstack.hip: W + 3 positions of halo
+
+
+def supported(blocks, W=None):
+    """The instantiated channel steps: 1 (carried as 16) | 32 | 64 -> 32 | 64, kernels (2,3) / (2,3) / (1,3); maps up to 93 positions wide."""
+    if W is not None and W > MAX_W:
+        return False
     try:
         for i, blk in enumerate(blocks):
             co, ci, kh, kw = blk.conv1.weight.shape
@@ -66,14 +71,14 @@ class _Plan:
         self.tmp = z(max(cps))
         self.stats = [torch.zeros(4 * c, device=dev) for c in cps[1:]]
         self.bstats = torch.zeros(2 * max(cps), device=dev)
-        self.acc = torch.zeros(2 * max(cps), dtype=torch.float64, device=dev)      # left zeroed by every finishing block
+        self.acc = torch.zeros(16 * 2 * max(cps), dtype=torch.float64, device=dev)      # SCL_RS_NSLOT rows; left zeroed by every finishing block
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dx = [z(c) for c in cps]
         self.dz = z(max(cps))
         self.dtmp = z(max(cps))
         self.wpk = None
         nsl = L.load().scl_rs_wgrad_nslabs
-        self.part = torch.empty(max(nsl(co) * 6 * ci * co for ci, co in zip(cps[:-1], cps[1:])) + max(nsl(c) * 6 * c * c for c in cps[1:]), device=dev)
+        self.part = torch.empty(max(max(nsl(ci, co) * 6 * ci * co for ci, co in zip(cps[:-1], cps[1:])), max(nsl(c, c) * 6 * c * c for c in cps[1:])), device=dev)
         self.gx = L.SclRsGeom(B, H, W, 1, H, 0)        # block inputs / outputs: rows 1..H
         self.gy = L.SclRsGeom(B, H, W, 0, H, 0)        # conv1 outputs (H + 1 rows): rows 0..H
         Wp = self.Wp
@@ -205,7 +210,7 @@ def _forward(pl, x0, blocks, training):
 
 def _wgrad(pl, inp, dout, cin, cout, shifts, w, bias, co_real, ci_real):
     arr = (ctypes.c_int32 * 6)(*(list(shifts) + [0] * (6 - len(shifts))))
-    nslab = L.load().scl_rs_wgrad_nslabs(cout)
+    nslab = L.load().scl_rs_wgrad_nslabs(cin, cout)
     ops._call("scl_rs_wgrad", inp, dout, cin, cout, len(shifts), arr, ctypes.byref(pl.gx), pl.part.data_ptr(), pl.acc.data_ptr(), pl.ticket.data_ptr(),
               _grad(bias).data_ptr(), _stream(), keep=arr)
     ops._call("scl_rs_wgrad_reduce", pl.part.data_ptr(), nslab, len(shifts), cin, cout, co_real, ci_real, _grad(w).data_ptr(), _stream())
