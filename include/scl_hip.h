@@ -360,7 +360,7 @@ int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const f
 /* ------------------------------------------------------------------------------------------ */
 /* A map of the stack: utterance b owns H + 2 rows of W + 2 positions of C channels (f32, channels last); flat position
  * g = (b * (H + 2) + r) * (W + 2) + c.  Rows r_lo..r_hi and columns 1..W hold values, everything else is zero (the convolutions'
- * padding).  Buffers carry >= W + 132 positions of slack on either side of [0, G) (finite values; never part of a valid result). */
+ * padding).  Buffers carry >= W + 260 positions of slack on either side of [0, G) (finite values; never part of a valid result). */
 typedef struct SclRsGeom { int32_t B, H, W, r_lo, r_hi, _pad; } SclRsGeom;
 /* out[g][n] = mask(g) * (bias[n] + addend[g][n] + sum_t sum_c in[g + shift[t]][c] * Wt[t][c][n])   — a (kh, kw) tap of a stride-1
  * convolution over a bordered map is ONE flat shift; the data gradient is the same call with negated shifts and transposed weights.

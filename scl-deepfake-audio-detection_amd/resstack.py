@@ -58,7 +58,7 @@ class _Plan:
         self.key = (B, H, W, tuple(chans))
         self.B, self.H, self.W, self.Wp = B, H, W, W + 2
         self.G = B * (H + 2) * self.Wp
-        self.slack = self.Wp + 2 + 128 + 6          # positions on either side of [0, G): halo of the first / last tile
+        self.slack = self.Wp + 2 + 256 + 6          # positions on either side of [0, G): halo of the first / last (256-position) tile
         self.busy = False
         self.dev = dev
         z = lambda c: torch.zeros((self.G + 2 * self.slack) * c, device=dev)      # zero once: the slack is read, never written
