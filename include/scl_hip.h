@@ -48,6 +48,9 @@ int scl_stream_wait_stream(void* waiter, void* signaler);
 #define SCL_KID_GEMM_F32 2   /* the f32-operand GEMM (scoring path, AASIST / ResNet back-ends) */
 #define SCL_KID_AUG  1   /* the RawBoost chain: scl_fir_multi_f32, scl_clip_stats_f32, scl_isd_scatter_f32, scl_clip_affine_f32 */
 #define SCL_KID_MAX  8
+/* bit 0: the library was built with -DSCL_EXPERIMENTS (the opt-in GEMM experiments: 256x128 / 256x256 ping-pong tiles, two workgroups per
+ * CU, persistent blocks, start stagger).  The shipped library is built without; their flags / environment switches are then ignored. */
+int scl_build_flags(void);
 int scl_prof_enable(int kid, int on);
 /* create n_pairs event pairs ahead of time: the first profiled step would otherwise pay hipEventCreate for every launch inside the
  * timed region (bench.py: 335 launches, ~30 ms) */

@@ -351,6 +351,11 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
 // (A 128x128 / BK = 32 / 5-stage variant that doubles the bytes in flight per CU was measured 4-19 % SLOWER than the kernel
 // above on every encoder shape — the extra barrier per 16 MFMAs costs more than the deeper prefetch returns — and removed.)
 
+// The 256x128 ("big") and 256x256 ping-pong ("p8") kernels and the two-workgroups-per-CU / persistent experiments of gemm_x2.hip /
+// gemm_w8.hip lost every A/B against the default family and are NOT part of the shipped library: they are compiled
+// only with -DSCL_EXPERIMENTS (SCL_BUILD_DEFINES=-DSCL_EXPERIMENTS python scl-deepfake-audio-detection_amd/build.py), for the record and
+// for their bit-identity tests.  Unused instantiations cost the default path 5-15 % through the instruction cache.
+#ifdef SCL_EXPERIMENTS
 // ---- "big" variant: 256x128 tile, 8 waves, 3-stage LDS-DMA ring --------------------------------------
 // The 128x128 kernels above are latency-bound on the K loop (rocprofv3: 48 % of wave cycles in
 // s_waitcnt/barrier, MFMA pipe 22 % busy, ~3300 cycles per 64-deep K step with 64 KiB in flight per CU).
@@ -627,6 +632,8 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_p8_kernel(const GemmK d) {
 #undef P8_ISSUE_A
 #undef P8_ISSUE_B
 
+#endif  // SCL_EXPERIMENTS
+
 __global__ void scl_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
                                         int nslabs, int64_t stride) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -706,6 +713,7 @@ bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long l
 
 // 208 x 128 tiles, two 4-wave workgroups per CU (gemm_x2.hip): the epilogue of one tile runs under the K loop of the other.
 // SCL_GEMM_X2: 0 never, 1 automatic (below), 2 whenever the operands can be addressed.
+#ifdef SCL_EXPERIMENTS
 bool gemm_pick_x2(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, W8Plan* plan) {
     static const int x2_env = [] { const char* e = getenv("SCL_GEMM_X2"); return e ? atoi(e) : 0; }();
     if (d.flags & (SCL_GEMM_NO_X2 | SCL_GEMM_FORCE_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG | SCL_GEMM_NO_DMA)) return false;
@@ -719,6 +727,9 @@ bool gemm_pick_x2(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long l
     return !at && d.N >= 128 && plan->tiles * zdim >= 248;
 }
 
+#else
+bool gemm_pick_x2(const GemmK&, bool, bool, const SclGemmDesc&, long long, W8Plan*) { return false; }
+#endif
 }  // namespace
 
 extern "C" int scl_gemm_uses_wide_tiles(const SclGemmDesc* dp) {
@@ -798,6 +809,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         // 256x128 tiles, one 8-wave block per CU, 3-stage ring: opt-in (SCL_GEMM_FORCE_BIG).  A/B in one process on MI355X: equal
         // to the 128x128 kernel on the conv-stack shapes (+-2 %), 2.5 % slower end to end at batch 64 where it used to be picked
         // for the encoder linears as well; bit-identical results either way.
+#ifdef SCL_EXPERIMENTS
         const long long big_tiles = (long long)((d.M + BIG_BM - 1) / BIG_BM) * ((d.N + BN - 1) / BN) * zdim;
         const bool big = dma && (d.flags & SCL_GEMM_FORCE_BIG) && !(d.flags & SCL_GEMM_NO_BIG) && d.M >= 256 && d.K >= 192 && big_tiles >= 1;
         // 256x256 ping-pong tiles: opt-in (SCL_GEMM_FORCE_P8).  Measured on MI355X (tools/gemm_square.py, tools/gemm_p8_ab.py):
@@ -805,15 +817,25 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         // 400 tiles = 1.56 rounds of 256 CUs and a 16-step K loop leave it behind the 128x128 kernel (fc1 fwd 576 vs 694).
         const long long p8_tiles = (long long)((d.M + P8_BM - 1) / P8_BM) * ((d.N + P8_BN - 1) / P8_BN) * zdim;
         const bool p8 = dma && (d.flags & SCL_GEMM_FORCE_P8) && !(d.flags & SCL_GEMM_NO_P8);
+#else
+        const bool big = false, p8 = false;
+#endif
         // wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the
         // problem fills at least half a round of them and the operands advance linearly along K
         W8Plan plan;
+#ifdef SCL_EXPERIMENTS
         const bool x2 = dma && gemm_pick_x2(k, at, bt, d, zdim, &plan);
+#else
+        const bool x2 = false;
+#endif
         const bool w8 = !x2 && dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
         if (x2) {
+#ifdef SCL_EXPERIMENTS
             scl_gemm_x2_launch(k, at, bt, plan, zdim, s);
+#endif
         } else if (w8) {
             scl_gemm_w8_launch(k, at, bt, plan, zdim, s);
+#ifdef SCL_EXPERIMENTS
         } else if (p8) {
             static bool p8_attr_set = false;
             if (!p8_attr_set) {
@@ -842,6 +864,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
             else if (!at && bt) SCL_LAUNCH((scl_gemm_big_kernel<false, true>), bgrid, bblock, BIG_LDS, s, k);
             else if (at && !bt) SCL_LAUNCH((scl_gemm_big_kernel<true, false>), bgrid, bblock, BIG_LDS, s, k);
             else SCL_LAUNCH((scl_gemm_big_kernel<true, true>), bgrid, bblock, BIG_LDS, s, k);
+#endif
         } else if (dma) {
             if (!at && !bt) SCL_LAUNCH((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);
             else if (!at && bt) SCL_LAUNCH((scl_gemm_dma_kernel<false, true>), grid, block, lds, s, k);
@@ -858,6 +881,13 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
 }
 
 extern "C" long long scl_debug_gemm_persistent_launches(void) { return scl_gemm_w8p_launches(); }
+extern "C" int scl_build_flags(void) {
+#ifdef SCL_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int scl_debug_gemm_stamps(unsigned long long* out, int nblocks) {
     SCL_REQUIRE(out && nblocks > 0 && nblocks <= 4096, "gemm stamps: bad args");

@@ -498,11 +498,13 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
     w8_stamp(d, 0, lane, wave);
+#ifdef SCL_EXPERIMENTS
     // experiment (SCL_W8_STAGGER, units of s_sleep 127 ~ 3.9 us): the first-round blocks of every other XCD start late, so that the
     // epilogues of the two halves of the chip do not hit HBM at the same moment for the rest of the launch
     if ((d.debug >> 8) && (blockIdx.x & 1) && blockIdx.x < 256 && blockIdx.z == 0) {
         for (int i = 0; i < (d.debug >> 8); ++i) __builtin_amdgcn_s_sleep(127);
     }
+#endif
     const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn, d.group_m);
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     }
 }
 
+#ifdef SCL_EXPERIMENTS      // opt-in experiment, not part of the shipped library (see gemm.hip)
 // ---- persistent single-barrier variant ("w8p") -----------------------------------------------------------------------------
 // One block per CU stays resident and walks the tiles v = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: v & 7, the XCD of
 // tile_coords, is the block's own).  Why: with one 160-KiB block per CU nothing overlaps a block's retirement, the dispatch of the
@@ -714,6 +717,8 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8p_kernel(const GemmK d) {
     }
 }
 
+#endif  // SCL_EXPERIMENTS
+
 template <int RB0, int RB1>
 void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, int mode) {
     static bool attr_set = false;
@@ -726,14 +731,17 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<true, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+#ifdef SCL_EXPERIMENTS
         if constexpr (RB0 == 7) {
             (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
             (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<false, true, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
             (void)hipFuncSetAttribute((const void*)scl_gemm_w8p_kernel<true, false, RB0, RB1>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
         }
+#endif
         attr_set = true;
     }
     const dim3 block(512);
+#ifdef SCL_EXPERIMENTS
     if constexpr (RB0 == 7) {      // the persistent loop exists for the 208-row tile only (scl_gemm_w8_launch never asks for it with 256 rows)
         if (mode == 2) {      // grid = resident blocks (never both operands transposed: those launches take the ping-pong loop)
             if (!at && !bt) SCL_LAUNCH((scl_gemm_w8p_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
@@ -742,6 +750,7 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
             return;
         }
     }
+#endif
     if (mode == 1) {
         if (!at && !bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, false, RB0, RB1>), grid, block, W8_LDS, s, k);
         else if (!at && bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, true, RB0, RB1>), grid, block, W8_LDS, s, k);
@@ -820,6 +829,8 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         static const bool epi_generic = [] { const char* e = getenv("SCL_W8_EPI_GENERIC"); return e && atoi(e) != 0; }();
         if (epi_generic) k.debug |= 16;      // A/B: the generic (run-time flag) epilogue loop for every launch
     }
+    dim3 g = grid;
+#ifdef SCL_EXPERIMENTS
     {
         const char* sg = getenv("SCL_W8_STAGGER");
         const int stg = sg ? atoi(sg) : 0;
@@ -836,7 +847,6 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // as a tested, documented experiment; do not switch it on for training.
     const char* pe = getenv("SCL_GEMM_PERSIST");
     const int pv = pe ? atoi(pe) : 0;
-    dim3 g = grid;
     if (mode == 1 && pv > 0 && !(at && bt) && zdim == 1 && k.splitk == 1 && k.K / BK >= 3 && !(k.flags & SCL_GEMM_STAMPS)) {
         const long long ncu = plan.ncu >= 8 ? plan.ncu : 256;
         const long long rounds = (plan.tiles + ncu - 1) / ncu;
@@ -845,6 +855,7 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         // the 208-row variant only — the 256-row one spilled under the persistent loop's register pressure (2 x slower) and is not built
         if (plan.variant == 0 && (pv >= 8 || rounds >= 2) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
     }
+#endif
     if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
     else w8_launch_rb<8, 8>(k, at, bt, g, s, mode);
     return 0;

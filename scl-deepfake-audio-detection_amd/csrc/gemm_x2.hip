@@ -20,6 +20,7 @@
 //     Transposed images: sub-tiles of [32 k][128 columns], the layout and ds_read_b64_tr_b16 reader of gemm_common.h.
 //   * Epilogue: gemm_w8_epi.h (whole lines through a 16 KiB LDS block per wave; 4 x (16 + 4) KiB = the workgroup's 80 KiB).
 //   * Accumulation order per output element is k ascending in steps of 32, as in every other kernel of the family: bit-identical.
+#ifdef SCL_EXPERIMENTS      // not part of the shipped library (slower than the wide tiles on every encoder shape): see gemm.hip
 #include "gemm_common.h"
 #include "gemm_w8_epi.h"
 
@@ -255,3 +256,4 @@ int scl_gemm_x2_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
 }
 
 }  // namespace sclg
+#endif  // SCL_EXPERIMENTS

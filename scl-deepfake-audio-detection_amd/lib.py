@@ -98,6 +98,7 @@ def _protos():
     return {
         "scl_version": ([], _i32),
         "scl_last_error": ([], ctypes.c_char_p),
+        "scl_build_flags": ([], _i32),
         "scl_prof_enable": ([_i32, _i32], _i32),
         "scl_prof_reserve": ([_i32, _i32], _i32),
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),

@@ -64,3 +64,19 @@ def test_product_does_not_import_the_oracle():
                     offenders.append(fn)
     src = open(os.path.join(ROOT, "main.py")).read()
     assert not offenders and not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M)
+
+
+def test_shipped_library_holds_only_default_path_kernels():
+    """The GEMM experiments that lost their A/Bs (two workgroups per CU, persistent blocks, 256x128 ring, 256x256 ping-pong, start stagger)
+    are compiled only with -DSCL_EXPERIMENTS: the shipped library must not carry their code objects (unused instantiations cost the
+    default path through the instruction cache) nor their environment switches."""
+    from scl_amd import lib
+    L = lib.load()
+    assert L.scl_build_flags() == 0, "libscl_hip.so was built with -DSCL_EXPERIMENTS; rebuild without SCL_BUILD_DEFINES"
+    data = open(lib.LIB_PATH, "rb").read()
+    for name in (b"scl_gemm_w8p_kernel", b"scl_gemm_x2_kernel", b"scl_gemm_p8_kernel", b"scl_gemm_big_kernel"):
+        assert data.count(name) == 0, name
+    for env in (b"SCL_GEMM_PERSIST", b"SCL_W8_STAGGER", b"SCL_GEMM_X2"):
+        assert env not in data, env
+    for name in (b"scl_gemm_w8s_kernel", b"scl_gemm_dma_kernel", b"scl_gemm_f32_kernel", b"rs_conv_kernel", b"attn_fwd_kernel"):
+        assert data.count(name) > 0, name

@@ -12,6 +12,15 @@ from scl_amd import ops  # noqa: E402
 from scl_amd.lib import FLAT  # noqa: E402
 
 
+
+def _has_experiments():
+    return bool(ops.L.load().scl_build_flags() & 1)
+
+
+# The opt-in GEMM experiments (256x128 ring, 256x256 ping-pong, two workgroups per CU, persistent blocks) are not part of the shipped
+# library; their bit-identity tests run against a build with SCL_BUILD_DEFINES=-DSCL_EXPERIMENTS (see csrc/gemm.hip).
+needs_experiments = pytest.mark.skipif("not _has_experiments()", reason="library built without -DSCL_EXPERIMENTS")
+
 def _rand(shape, dev, seed, scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
@@ -80,6 +89,7 @@ def test_lds_dma_staging_equals_register_staging(dev, a_t, b_t, M, N, K):
     _close(outs[0], ref, 2e-3, "dma a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@needs_experiments
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(5128, 1280, 264), (6368, 1024, 1024), (2600, 2560, 192)])
 def test_big_tile_ring_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K):
@@ -98,6 +108,7 @@ def test_big_tile_ring_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K):
     _close(outs[0], torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 8e-3, "big a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@needs_experiments
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K,splitk", [(5128, 1288, 264, 1), (6368, 1024, 1024, 1), (520, 776, 4096, 3), (256, 256, 64, 1), (1000, 3072, 512, 1)])
 def test_pingpong_256_tile_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
@@ -303,6 +314,7 @@ def test_wide_tile_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_t, M, 
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K,splitk", [(12736, 1024, 1024, 1), (5128, 1288, 96, 1), (2184, 3072, 1024, 1), (1024, 4096, 12736, 4),
                                           (520, 776, 4128, 3), (200, 256, 32, 1), (1000, 200, 544, 1), (208, 128, 64, 1)])
+@needs_experiments
 def test_two_blocks_per_cu_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K, splitk):
     """gemm_x2.hip (208 x 128 tiles, 4-wave workgroups, two per CU, K step 32, rings of three stages): same K order per output
     element as the 128 x 128 kernels => bit-identical, on ragged M / N edges, K that is a multiple of 32 but not of 64, fewer K steps
@@ -332,6 +344,7 @@ def test_two_blocks_per_cu_kernel_equals_128_tile_kernel(dev, a_t, b_t, M, N, K,
     _close(got, ref if splitk > 1 else torch.relu(ref), 8e-3, "x2 a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@needs_experiments
 def test_two_blocks_per_cu_kernel_epilogues_and_conv_rows(dev):
     """Every fused epilogue of the encoder (bias + GELU + second output; x gelu'(R); f32 residual; dropout) and the utterance-batched
     overlapping rows of a conv layer through gemm_x2.hip against the 128 x 128 kernel, bit for bit."""
@@ -376,6 +389,7 @@ def _persistent_launches():
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False)])
 @pytest.mark.parametrize("M,N,K,blocks", [(12736, 4096, 1024, "1"), (12736, 3072, 1024, "1"), (2184, 3072, 1024, "8"), (5128, 1288, 192, "16"),
                                           (3000, 1000, 320, "8"), (5 * 208 + 8, 2 * 256 + 40, 448, "8"), (6400 * 2, 512, 1536, "24")])
+@needs_experiments
 def test_persistent_wide_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_t, M, N, K, blocks):
     """gemm_w8.hip's persistent blocks (w8p): every resident block walks several tiles, requests the next tile's first K stage two K
     steps before its epilogue and the second one from inside its own epilogue regions.  Same tiles and K order as the one-tile
@@ -403,6 +417,7 @@ def test_persistent_wide_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_
     _close(outs[2], torch.relu(A.float() @ B.float().t()), 8e-3, "w8p a_t=%s b_t=%s" % (a_t, b_t))
 
 
+@needs_experiments
 def test_persistent_wide_kernel_epilogues_column_sums_and_conv_rows(dev, monkeypatch):
     """Every fused epilogue of the encoder through the persistent blocks (two 16-row blocks per pass, R staged in the free B image)
     against the 128 x 128 kernel, bit for bit; the per-tile column sums must equal the one-tile kernel's partial rows bit for bit
