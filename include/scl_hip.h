@@ -295,6 +295,10 @@ int scl_posconv_weight_bwd(const float* dwf, const float* v, const float* g, con
 /* y = x * keep-mask(seed, i) / (1 - p), to f32 and / or bf16 (in place allowed): fairseq TransformerEncoder.extract_features'
  * F.dropout(x, p = cfg.dropout) after the positional-conv residual add, its backward, and the backward of dropout_input */
 int scl_dropout_f32(const float* x, float* y_f32, void* y_bf16, int64_t n, uint32_t seed, float p, void* stream);
+/* y[r][j] = x[r][j] * keep-mask(seed, r * T + j) / (1 - p) for j < T, 0 for T <= j < ld; x, y: [R, ld] bf16 (is_f32 == 0) or f32, in place
+ * allowed.  Attention dropout of fairseq MultiheadAttention (reached from model/xlsr.py:41) on the un-fused path: same mask index as
+ * scl_attn_fwd / scl_attn_bwd (row r = (b, h, q)). */
+int scl_dropout_rows(const void* x, void* y, int64_t R, int T, int ld, int is_f32, uint32_t seed, float p, void* stream);
 int scl_meanpool_fwd(const void* h, float* emb, int B, int T, int C, void* stream);
 int scl_meanpool_bwd(const float* demb, const void* pre, void* dpre, int B, int T, int C, int ract, float drop_p,
                      uint32_t seed, void* stream);

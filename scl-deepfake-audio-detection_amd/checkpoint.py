@@ -83,7 +83,7 @@ def read_fairseq_checkpoint(path):
     return tensors, probs
 
 
-def load_pretrained_into(model, path, strict_dropout=True):
+def load_pretrained_into(model, path):
     """Copy the checkpoint's encoder tensors into `model` (names prefixed with ssl_model.model.), set the encoder's element-dropout
     probabilities from its cfg and return all of them (LayerDrop included; the caller applies that one)."""
     tensors, probs = read_fairseq_checkpoint(path)

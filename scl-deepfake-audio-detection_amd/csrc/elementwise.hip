@@ -444,6 +444,28 @@ extern "C" int scl_dropout_f32(const float* x, float* y_f32, void* y_bf16, int64
     hipLaunchKernelGGL(dropout_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y_f32, (bf16_t*)y_bf16, n, seed, p);
     return scl_check_launch("scl_dropout_f32");
 }
+// attention dropout on the UN-fused attention path (T > 224 or head dim != 64): the keep-mask of probability row r = (b, h, q), key j is
+// hash(seed, r * T + j) — the index the fused kernels of attention.hip use — so both paths drop the same elements for one seed.
+template <typename TX>
+__global__ void dropout_rows_kernel(const TX* __restrict__ x, TX* __restrict__ y, int64_t R, int T, int ld, uint32_t seed, float p) {
+    const int64_t n = R * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int j = (int)(i - r * ld);
+        float v = 0.f;
+        if (j < T) {
+            if constexpr (sizeof(TX) == 2) v = bf2f(x[i]); else v = x[i];
+            v *= dropout_scale(seed, (uint64_t)(r * T + j), p);
+        }
+        if constexpr (sizeof(TX) == 2) y[i] = f2bf(v); else y[i] = v;
+    }
+}
+extern "C" int scl_dropout_rows(const void* x, void* y, int64_t R, int T, int ld, int is_f32, uint32_t seed, float p, void* stream) {
+    SCL_REQUIRE(x && y && R > 0 && T > 0 && ld >= T && p >= 0.f && p < 1.f, "dropout_rows: bad args");
+    if (is_f32) hipLaunchKernelGGL(dropout_rows_kernel<float>, dim3(grid_for(R * ld)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, R, T, ld, seed, p);
+    else hipLaunchKernelGGL(dropout_rows_kernel<bf16_t>, dim3(grid_for(R * ld)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, R, T, ld, seed, p);
+    return scl_check_launch("scl_dropout_rows");
+}
 extern "C" int scl_add_f32(const float* a, const float* b, float* out, void* out_bf16, int64_t n, void* stream) {
     SCL_REQUIRE(a && (out || out_bf16) && n > 0, "add_f32: bad args");
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16_t*)out_bf16, n);

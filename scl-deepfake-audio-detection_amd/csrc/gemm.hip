@@ -791,6 +791,8 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     const bool strides4 = !(d.ldc & 3) && !(d.c_bs1 & 3) && !(d.c_bs2 & 3) && !(d.c_rbstride & 3) && !(d.c_split_stride & 3) && !(d.bias_bs2 & 3);
     k.vec_ok = strides4 && al(d.C, (d.flags & SCL_GEMM_C_F32) ? 16 : 8) && al(d.C2, (d.flags & SCL_GEMM_C2_F32) ? 16 : 8) &&
                al(d.R, (d.flags & SCL_GEMM_R_F32) ? 16 : 8) && al(d.bias, 16);
+    // the wide epilogue writes its column-sum partial rows from the 8-column vector path only: without it the rows would stay unwritten
+    SCL_REQUIRE(!d.colsum_part || k.vec_ok, "gemm: colsum_part needs 16-byte aligned C / C2 / R / bias and strides that are multiples of 4");
     dim3 grid(tiles, 1, (unsigned)zdim), block(256);
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;

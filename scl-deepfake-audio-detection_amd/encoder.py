@@ -398,8 +398,6 @@ class Encoder:
                      act=ACT_GELU, c2=d["pc_pre"], R=d["x0"], rmode=1)
         if p_res > 0:      # F.dropout(x + pos_conv(x), p = cfg.dropout): after the residual add, so not a GEMM epilogue
             self._slot(slots, ops.dropout(d["xin"][0], d["xin"][0], None, M * E, sseed(-1, self.SITE_ENC), p_res), ops.DROPOUT_SEED, -1, self.SITE_ENC)
-        if p_attn > 0 and not d["fused_attn"]:
-            raise NotImplementedError("attention_dropout needs the fused attention kernels (head dim 64, T <= 224)")
         # -- transformer layers
         skipped = []
         for n in range(cfg.layers):
@@ -422,7 +420,11 @@ class Encoder:
                 ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), d["S"], T, T, D,
                          nb1=B, nb2=H, alpha=D ** -0.5, ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
                 ops.softmax_fwd(d["S"], d["P"][n], B * H * T, T, Tp, Tp)
-                ops.gemm(Op(d["P"][n], Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
+                Pv = d["P"][n]
+                if p_attn > 0:      # attention dropout: the dropped copy feeds P V (the backward rebuilds it from P and the seed)
+                    Pv = d["dS"]
+                    self._slot(slots, ops.dropout_rows(d["P"][n], Pv, B * H * T, T, Tp, sseed(n, self.SITE_ATTN), p_attn), ops.DROPOUT_ROWS_SEED, n, self.SITE_ATTN)
+                ops.gemm(Op(Pv, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E),
                          d["ctx"][n], T, D, T, b_t=True, nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
             dsc = ops.gemm(Op(d["ctx"][n], E), self.W(pn + "self_attn.out_proj.weight", E), d["x1"][n], M, E, E,
                            bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1, drop_p=p_res, drop_seed=sseed(n, self.SITE_1))    # dropout1
@@ -611,12 +613,18 @@ class Encoder:
             else:
                 Pn = d["P"][n]
                 bq = dict(nb1=B, nb2=H)
-                # dV[j] = sum_i P[i][j] dctx[i]
-                ops.gemm(Op(Pn, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(d["d_ctx"], E, bs1=T * E, bs2=D), dqkv, T, D, T, a_t=True, b_t=True,
+                Pv = Pn
+                if p_attn > 0:      # the dropped probabilities, rebuilt from P with the forward's seed
+                    Pv = d["dS"]
+                    self._slot(slots, ops.dropout_rows(Pn, Pv, B * H * T, T, Tp, sseed(n, self.SITE_ATTN), p_attn), ops.DROPOUT_ROWS_SEED, n, self.SITE_ATTN)
+                # dV[j] = sum_i (P o mask)[i][j] dctx[i]
+                ops.gemm(Op(Pv, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(d["d_ctx"], E, bs1=T * E, bs2=D), dqkv, T, D, T, a_t=True, b_t=True,
                          ldc=3 * E, c_bs1=T * 3 * E, c_bs2=D, c_offset=2 * E, **bq)
-                # dP = dctx V^T
+                # dP = (dctx V^T) o mask
                 ops.gemm(Op(d["d_ctx"], E, bs1=T * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["S"], T, T, D,
                          ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp, **bq)
+                if p_attn > 0:
+                    self._slot(slots, ops.dropout_rows(d["S"], d["S"], B * H * T, T, Tp, sseed(n, self.SITE_ATTN), p_attn), ops.DROPOUT_ROWS_SEED, n, self.SITE_ATTN)
                 ops.softmax_bwd(Pn, d["S"], d["dS"], B * H * T, T, Tp, Tp)
                 sc = D ** -0.5
                 dS = Op(d["dS"], Tp, bs1=H * T * Tp, bs2=T * Tp)

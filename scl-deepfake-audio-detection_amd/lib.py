@@ -166,6 +166,7 @@ def _protos():
         "scl_gat_score_nblocks": ([_i32], _i32),
         "scl_gat_score_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_gat_score_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_dropout_rows": ([_vp, _vp, _i64, _i32, _i32, _i32, _u32, _f32, _vp], _i32),
         # resstack.hip
         "scl_rs_conv": ([P(SclRsConv), _vp], _i32),
         "scl_rs_pack_weights": ([P(SclRsPackJob), _i32, _vp], _i32),

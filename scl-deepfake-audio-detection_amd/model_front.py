@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .encoder import Encoder, W2VConfig, param_specs
-from .model_linear import SCORE_FP32, init_parameters_, loss_custom, maybe_load_pretrained
+from .model_linear import SCORE_FP32, dropout_stream_seed, init_parameters_, loss_custom, maybe_load_pretrained
 from .ops import Op
 from .params import FlatParams, register_by_name
 
@@ -112,6 +112,7 @@ class FrontHeadModel(nn.Module):
         self._states = {}
         self.out_dim = self.cfg.embed
         self.grad_sync = None
+        self._drop_step = dropout_stream_seed(seed, rank)      # encoder element-dropout masks differ per --seed and per data-parallel rank
         # Optional (SCL_HEAD_GRAPH=1): replay the back-end's training forward / backward as two captured hipGraphs per feature
         # shape.  Both HIP back-ends capture and replay correctly (tests/test_aasist_gpu.py), but the step is kernel-bound: AASIST
         # 45.9 -> 45.5 ms/step at batch 32, ResNet +-0.  Off by default.
@@ -172,7 +173,7 @@ class FrontHeadModel(nn.Module):
         use_plan = self.cfg.encoder_layerdrop == 0 or not ssl_train
         pk = ("fwd", ssl_train)
         plan = st["plans"].get(pk) if use_plan else None
-        self._drop_step = (getattr(self, "_drop_step", 0x5EED + 7919 * int(getattr(self, "rank", 0))) * 1664525 + 1013904223) & 0x7FFFFFFF
+        self._drop_step = (self._drop_step * 1664525 + 1013904223) & 0x7FFFFFFF
         if plan is not None:
             ectx = plan["saved"]["ectx"]
             self.ssl.apply_seeds(ectx["drop_slots"], self._drop_step)      # the encoder's element-dropout sites (none at p = 0)

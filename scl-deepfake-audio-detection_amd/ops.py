@@ -420,6 +420,14 @@ def dropout(x, y_f32, y_bf16, n, seed, p):
     return _call("scl_dropout_f32", _p(x), _p(y_f32), _p(y_bf16), n, int(seed), float(p), _stream())
 
 
+DROPOUT_ROWS_SEED = 6
+
+
+def dropout_rows(x, y, R, T, ld, seed, p):
+    """Attention dropout on the un-fused path: y[r][j] = x[r][j] * keep-mask(seed, r * T + j) / (1 - p), zero padding columns (bf16 or f32)."""
+    return _call("scl_dropout_rows", _p(x), _p(y), R, T, ld, 1 if x.dtype == torch.float32 else 0, int(seed), float(p), _stream())
+
+
 def conv0_fwd(x, w, b, gamma, beta, z, B, Lx, C, k, stride, eps=1e-5, stats=None):
     _call("scl_conv0_fwd", _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(z), _p(stats), B, Lx, C, k, stride, eps, _stream())
 

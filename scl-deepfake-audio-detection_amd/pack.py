@@ -52,6 +52,9 @@ def _read_wav(path):
     return x, sr
 
 
+_FLAC_MAX_SAMPLES = 1 << 26      # 70 minutes at 16 kHz: the bound for streams whose STREAMINFO carries no length
+
+
 def _read_flac(path):
     """FLAC through the library's own decoder (csrc/flac.hip: frame CRCs and the STREAMINFO MD5 are verified); channels are averaged
     as librosa.load(mono=True) does."""
@@ -70,8 +73,10 @@ def _read_flac(path):
     while True:
         out = np.empty((cap, ch.value), dtype=np.int32)
         rc = lib.scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got), 1)
-        if rc != 0 and total.value <= 0 and cap < (1 << 31) and b"output too small" in (lib.scl_last_error() or b""):
-            cap *= 8
+        if rc != 0 and total.value <= 0 and b"output too small" in (lib.scl_last_error() or b""):
+            if cap >= _FLAC_MAX_SAMPLES:      # a stream without a declared length that is still growing: refuse instead of exhausting the worker's memory
+                raise ValueError("%s: FLAC stream without a STREAMINFO length exceeds %d samples per channel" % (path, _FLAC_MAX_SAMPLES))
+            cap = min(cap * 8, _FLAC_MAX_SAMPLES)
             continue
         L.check(rc, "scl_flac_decode_i32(%s)" % path)
         break

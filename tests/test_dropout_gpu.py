@@ -82,12 +82,14 @@ def enc_masks_for(step_seed, cfg, B, T, probs):
     return masks
 
 
-@pytest.mark.parametrize("probs", [(0.1, 0.1, 0.1, 0.1), (0.2, 0.0, 0.0, 0.0), (0.0, 0.15, 0.05, 0.0)])
-def test_encoder_dropout_matches_the_oracle_given_the_same_masks(dev, probs):
+@pytest.mark.parametrize("probs,heads", [((0.1, 0.1, 0.1, 0.1), 2), ((0.2, 0.0, 0.0, 0.0), 2), ((0.0, 0.15, 0.05, 0.0), 2),
+                                         ((0.0, 0.15, 0.05, 0.0), 4), ((0.1, 0.1, 0.1, 0.1), 4)])
+def test_encoder_dropout_matches_the_oracle_given_the_same_masks(dev, probs, heads):
     """(dropout, attention_dropout, activation_dropout, dropout_input) on a 2-layer encoder with 64-wide heads (the fused attention
-    kernels), head dropout on as well (train mode, p = 0.5): three steps, the last two replayed from launch plans; after each the
+    kernels) or 32-wide heads (the un-fused path: materialised probabilities, scl_dropout_rows with the fused kernels' mask index),
+    head dropout on as well (train mode, p = 0.5): three steps, the last two replayed from launch plans; after each the
     step's masks are rebuilt on the host and the oracle's autograd through them must agree at the bf16 bar."""
-    kw = dict(conv_dim=32, embed=128, layers=2, heads=2, ffn=256, pos_k=16, pos_groups=4, final_dim=16, latent_vars=8, latent_groups=2)
+    kw = dict(conv_dim=32, embed=128, layers=2, heads=heads, ffn=256, pos_k=16, pos_groups=4, final_dim=16, latent_vars=8, latent_groups=2)
     ocfg = W.W2VConfig(**kw)
     cfg = W2VConfig(dropout=probs[0], attention_dropout=probs[1], activation_dropout=probs[2], dropout_input=probs[3], **kw)
     ssl, head = W.init_state(ocfg, seed=41), OH.init_head(ocfg.embed, seed=42)
