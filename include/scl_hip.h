@@ -419,6 +419,91 @@ int scl_rs_bn_eval_stats(const float* gamma, const float* beta, const float* run
 int scl_rs_copy(const float* src, float* dst, int Cs, int Cd, int to_dense, const SclRsGeom* geom, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* AASIST graph module: GraphAttentionLayer / HtrgGraphAttentionLayer / GraphPool / read-out    */
+/* (model/wav2vec2_aasist.py:62-155, 158-332, 336-374, 545-604), one workgroup per utterance     */
+/* ------------------------------------------------------------------------------------------ */
+/* All tensors f32 (indices int32), [B][...] contiguous per utterance.  Parameter gradients: every workgroup writes its contribution
+ * into row b of a slab [B][slab_bs] at the o_* offsets; scl_graph_reduce sums the rows in index order into the gradients.
+ * BatchNorm1d over (utterances x nodes): acc = SCL_RS_NSLOT * 2 * C zeroed doubles + a zeroed uint32 ticket (left zeroed). */
+typedef struct SclGraphBn {
+    double* acc; uint32_t* ticket;
+    const float* gamma; const float* beta; float* run_mean; float* run_var; int64_t* nbt;
+    float* stats;          /* [4][C] mean, rstd, gamma * rstd, beta (written in training, given in eval) */
+    float* bstats;         /* [2][C] backward: means of dz and dz x xhat (zeros in eval) */
+    float* dgamma; float* dbeta;      /* += */
+    double nvalid; float eps, momentum; int32_t training, _pad;
+} SclGraphBn;
+/* One attention layer after its pairwise scores (scl_gat_score_fwd wrote S): A = softmax_j(S / temp) (stored over S), g = A xd,
+ * y = g Wa^T + ba + xd Wb^T + bb, BatchNorm statistics of y; heterogeneous layers (has_master) also update the master node:
+ * am = softmax_n((tanh((xd * m) WM^T + bM) aM) / temp), gm = am^T xd, mout = gm WaM^T + baM + m WbM^T + bbM.
+ * Backward (dz = d selu-output * selu' given, bn.bstats finished): dy, the parameter-gradient slab entries, dS (for scl_gat_score_bwd),
+ * dxd (without the score path's part), d_min; d_mout / d_mout2 are the two gradients arriving at mout (either may be NULL). */
+typedef struct SclGraphLayer {
+    const float* xd; float* S; float* g; float* y;
+    const float *Wa, *ba, *Wb, *bb;
+    const float* min; int64_t min_bs;
+    const float *WM, *bM, *aM, *WaM, *baM, *WbM, *bbM;
+    float *am, *gm, *tM, *mout;
+    SclGraphBn bn;
+    int32_t N, D, Do, has_master; float inv_temp; int32_t _pad;
+    const float* dz; const float* d_mout; const float* d_mout2; float* dS; float* dxd; float* d_min;
+    float* slab; int64_t slab_bs;
+    int32_t o_Wa, o_ba, o_Wb, o_bb, o_WM, o_bM, o_aM, o_WaM, o_baM, o_WbM, o_bbM, _pad2;
+} SclGraphLayer;
+/* launches 1 or 2 layers (grid.y) of equal batch */
+int scl_graph_post_fwd(const SclGraphLayer* layers, int nlayers, int B, void* stream);
+int scl_graph_post_bwd(const SclGraphLayer* layers, int nlayers, int B, void* stream);
+/* What sits between two attention layers, per unit of nodes: h = selu(bn(y rows)) of the layer below, GraphPool (score = sigmoid(proj(drop h)),
+ * top-K by descending score, rows gated by their score), proj_type, then the input dropout of the next layer over the concatenated units. */
+typedef struct SclGraphPoolUnit {
+    const float* ysrc; int32_t src_n, row0, n_in, K;
+    const float* stats;
+    const float* pw; const float* pb; uint32_t pool_seed; float pool_p;
+    float* h; float* sc; int32_t* idx; float* pooled;
+    const float* Wt; const float* bt;
+    int32_t row_out, _pad;
+    const float* d_res; float* dz;
+    int32_t o_pw, o_pb, o_Wt, o_bt;
+    SclGraphBn bn;
+} SclGraphPoolUnit;
+typedef struct SclGraphPre {
+    SclGraphPoolUnit u[2];
+    float* xd; const float* dxd_a; const float* dxd_b;
+    uint32_t in_seed; float in_p;
+    int32_t Dp, N, store_common, same_bn;
+    float* slab; int64_t slab_bs;
+} SclGraphPre;
+/* two instances per launch; shared_pool != 0: both read the same pooled nodes (HtrgGAT_layer_ST11 / ST21 share pool_S / pool_T), the
+ * backward then sums their pooled-node gradients inside one workgroup */
+int scl_graph_pre_fwd(const SclGraphPre* inst, int shared_pool, int B, void* stream);
+int scl_graph_pre_bwd(const SclGraphPre* inst, int shared_pool, int B, void* stream);
+/* y = x * keep-mask(seed, element) / (1 - p) for the two first layers; backward de = (da + db) * mask */
+int scl_graph_drop(const float* x0, float* y0, int64_t n0, uint32_t seed0, const float* x1, float* y1, int64_t n1, uint32_t seed1, float p, void* stream);
+int scl_graph_drop_bwd(const float* da0, const float* db0, float* de0, int64_t n0, uint32_t seed0, const float* da1, const float* db1, float* de1,
+                       int64_t n1, uint32_t seed1, float p, void* stream);
+/* read-out of the two branches: aug = selu(bn(y2)); T = Tp + aug[:KT], S = Sp + aug[KT:], m = m1 + m2; drop_way; branch max;
+ * hidden = dropout([max|T|, mean T, max|S|, mean S, m]); logits = hidden Wout^T + bout   (model/wav2vec2_aasist.py:572-604) */
+typedef struct SclGraphFinalBranch {
+    const float* y2; const float* stats2; const float* Tp; const float* Sp; const float* m1; const float* m2;
+    uint32_t way_seed[3]; int32_t _pad;
+    float* dz2; float* dTp; float* dSp; float* dm1; float* dm2;
+    SclGraphBn bn;
+} SclGraphFinalBranch;
+typedef struct SclGraphFinal {
+    SclGraphFinalBranch br[2];
+    const float* Wout; const float* bout; float* logits; float* hidden;
+    const float* d_logits; const float* d_hidden;
+    float* slab; int64_t slab_bs; int32_t o_Wout, o_bout;
+    int32_t KT, KS, D, NC; float way_p, drop_p; uint32_t drop_seed; int32_t _pad;
+} SclGraphFinal;
+int scl_graph_final_fwd(const SclGraphFinal* f, int B, void* stream);
+int scl_graph_final_bwd(const SclGraphFinal* f, int B, void* stream);
+/* dst[i] += sum_{k < nparts} src[k * stride + i], k ascending; up to SCL_GRAPH_MAX_REDUCE_JOBS jobs per launch */
+#define SCL_GRAPH_MAX_REDUCE_JOBS 96
+typedef struct SclGraphReduceJob { const float* src; float* dst; int64_t stride; int32_t n, nparts; } SclGraphReduceJob;
+int scl_graph_reduce(const SclGraphReduceJob* jobs, int njobs, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
 /* ------------------------------------------------------------------------------------------ */
 /* Buffers: ws = scl_supcon_nchunks(K) * bz * bz floats; G = 2 * bz * bz floats — [0, bz*bz) receives dL/dS from the forward and is

@@ -18,11 +18,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import hipnn, resstack
+from . import graph, hipnn, resstack
 from .gat import gat_score
 from .resnet_head import ConvWeight
 
 FUSED_STACK = os.environ.get("SCL_AASIST_FUSED", "1") == "1"      # 0: one autograd Function per layer (the round-2 composition)
+FUSED_GRAPH = os.environ.get("SCL_AASIST_FUSED_GRAPH", os.environ.get("SCL_AASIST_FUSED", "1")) == "1"
 
 UPSTREAM_AASIST = {"filts": [128, [1, 32], [32, 32], [32, 64], [64, 64]], "gat_dims": [64, 32],
                    "pool_ratios": [0.5, 0.5, 0.5, 0.5], "temperatures": [2.0, 2.0, 100.0, 100.0], "nclasses": 2}
@@ -180,6 +181,13 @@ class AasistHead(nn.Module):
         w = hipnn.linear(w, a3.weight.view(a3.weight.shape[0], -1), a3.bias)      # one score map for both poolings
         e_S = (x * F.softmax(w, dim=2)).sum(2) + self.pos_S                        # spectral nodes  [B, 42, 64]
         e_T = (x * F.softmax(w, dim=1)).sum(1)                                     # temporal nodes  [B, T/3, 64]
+        if FUSED_GRAPH and graph.supported(self, e_S.shape[1], e_T.shape[1]):
+            return graph.graph_module(e_S, e_T, self)          # the whole graph module as one autograd node (csrc/graph.hip)
+        return AasistHead.graph_unfused(self, e_S, e_T)
+
+    def graph_unfused(self, e_S, e_T):
+        """The graph module as a composition of per-operation autograd Functions (round 2): the fall-back for graph sizes the fused
+        kernels do not take, and the arm tests/test_graph_gpu.py compares them with."""
         out_S = self.pool_S(self.GAT_layer_S(e_S))
         out_T = self.pool_T(self.GAT_layer_T(e_T))
         # two heterogeneous branches

@@ -21,12 +21,10 @@
 //                                   by rs_wgrad_reduce_kernel straight into the torch-layout gradient; bias gradient alongside.
 //   rs_bn_act / rs_bn_bwd_apply     the two element-wise passes BatchNorm's batch statistics force between the convolutions.
 //   rs_scatter_c1 / rs_gather_c1 / rs_unpad / rs_pad    dense <-> bordered copies at the two ends of the stack.
-#include "common.h"
+#include "rs_finish.h"
 
 namespace {
 
-constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
-constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 // output positions per tile of the convolution kernel: 64 input channels keep 96 weight registers per lane, so that form runs ONE block
 // per CU with all 512 registers (256-position tiles, the next tile's 84 registers of input in flight); narrower inputs run two blocks
 // per CU on 128-position tiles
@@ -70,43 +68,6 @@ struct RsConvK {
     float eps, momentum;
     double nvalid;
 };
-
-__device__ __forceinline__ float selu_f(float v) { return v > 0.f ? SELU_SCALE * v : SELU_SCALE * SELU_ALPHA * (__expf(v) - 1.0f); }
-__device__ __forceinline__ float selu_grad_from_y(float y) { return y > 0.f ? SELU_SCALE : y + SELU_SCALE * SELU_ALPHA; }
-
-// Every block adds its n fp64 partials to ONE OF RS_NSLOT accumulator rows (row = block index mod RS_NSLOT: 512 blocks on one row would
-// serialise 512 atomics per address at the L2) with hardware fp64 atomics; the LAST block to arrive (ticket) sums the rows in index
-// order, hands the totals to `fin` and leaves rows and ticket zeroed for the next launch.  fp64 addition order inside a row varies from
-// run to run: an order-dependent error of ~1e-16 relative, invisible after the rounding to fp32 that every consumer applies.
-constexpr int RS_NSLOT = SCL_RS_NSLOT;
-template <class F>
-__device__ __forceinline__ void rs_finish(double* acc, unsigned* ticket, int n, const double* mine, double* lds_tot, F fin) {
-    __shared__ int is_last;
-    const int tid = threadIdx.x;
-    // No __threadfence(): at agent scope it writes the XCD's whole L2 back (this kernel has just stored its output map there) — 40 us per
-    // launch with 512 blocks doing it.  The partials travel as RETURNING atomics instead: a thread has its old value back only once the
-    // addition has been performed at the device-coherent level, the barrier collects all of them, then the ticket goes out.
-    if (tid < n) {
-        const double old = __hip_atomic_fetch_add(&acc[(blockIdx.x % RS_NSLOT) * n + tid], mine[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(old));
-    }
-    __syncthreads();
-    if (tid == 0) is_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!is_last) return;
-    if (tid < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < RS_NSLOT; ++sl) {
-            t += __hip_atomic_load(&acc[sl * n + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&acc[sl * n + tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lds_tot[tid] = t;
-    }
-    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    fin(lds_tot);
-}
 
 template <int CIN, int COUT, int NT, int SM>      // SM: statistics mode of the epilogue (0 none, 1 BatchNorm forward, 2 BatchNorm + SELU backward)
 __global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const RsConvK d) {

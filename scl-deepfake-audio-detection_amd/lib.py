@@ -177,6 +177,16 @@ def _protos():
         "scl_rs_bn_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),
         "scl_rs_bn_eval_stats": ([_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp], _i32),
         "scl_rs_copy": ([_vp, _vp, _i32, _i32, _i32, P(SclRsGeom), _vp], _i32),
+        # graph.hip
+        "scl_graph_post_fwd": ([_vp, _i32, _i32, _vp], _i32),
+        "scl_graph_post_bwd": ([_vp, _i32, _i32, _vp], _i32),
+        "scl_graph_pre_fwd": ([_vp, _i32, _i32, _vp], _i32),
+        "scl_graph_pre_bwd": ([_vp, _i32, _i32, _vp], _i32),
+        "scl_graph_drop": ([_vp, _vp, _i64, _u32, _vp, _vp, _i64, _u32, _f32, _vp], _i32),
+        "scl_graph_drop_bwd": ([_vp, _vp, _vp, _i64, _u32, _vp, _vp, _vp, _i64, _u32, _f32, _vp], _i32),
+        "scl_graph_final_fwd": ([_vp, _i32, _vp], _i32),
+        "scl_graph_final_bwd": ([_vp, _i32, _vp], _i32),
+        "scl_graph_reduce": ([_vp, _i32, _vp], _i32),
         # loss.hip
         "scl_supcon_nchunks": ([_i64], _i32),
         "scl_supcon_fwd": ([_vp, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
@@ -232,3 +242,47 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().scl_last_error()
         raise SclError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+# ---- csrc/graph.hip --------------------------------------------------------------------------------------------------------------------
+_P = ctypes.c_void_p
+
+
+class SclGraphBn(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("acc", "ticket", "gamma", "beta", "run_mean", "run_var", "nbt", "stats", "bstats", "dgamma", "dbeta")] + \
+               [("nvalid", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("training", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+class SclGraphLayer(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("xd", "S", "g", "y", "Wa", "ba", "Wb", "bb", "min")] + [("min_bs", ctypes.c_int64)] + \
+               [(n, _P) for n in ("WM", "bM", "aM", "WaM", "baM", "WbM", "bbM", "am", "gm", "tM", "mout")] + [("bn", SclGraphBn)] + \
+               [("N", ctypes.c_int32), ("D", ctypes.c_int32), ("Do", ctypes.c_int32), ("has_master", ctypes.c_int32), ("inv_temp", ctypes.c_float), ("_pad", ctypes.c_int32)] + \
+               [(n, _P) for n in ("dz", "d_mout", "d_mout2", "dS", "dxd", "d_min", "slab")] + [("slab_bs", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("o_Wa", "o_ba", "o_Wb", "o_bb", "o_WM", "o_bM", "o_aM", "o_WaM", "o_baM", "o_WbM", "o_bbM", "_pad2")]
+
+
+class SclGraphPoolUnit(ctypes.Structure):
+    _fields_ = [("ysrc", _P), ("src_n", ctypes.c_int32), ("row0", ctypes.c_int32), ("n_in", ctypes.c_int32), ("K", ctypes.c_int32), ("stats", _P),
+                ("pw", _P), ("pb", _P), ("pool_seed", ctypes.c_uint32), ("pool_p", ctypes.c_float), ("h", _P), ("sc", _P), ("idx", _P), ("pooled", _P),
+                ("Wt", _P), ("bt", _P), ("row_out", ctypes.c_int32), ("_pad", ctypes.c_int32), ("d_res", _P), ("dz", _P),
+                ("o_pw", ctypes.c_int32), ("o_pb", ctypes.c_int32), ("o_Wt", ctypes.c_int32), ("o_bt", ctypes.c_int32), ("bn", SclGraphBn)]
+
+
+class SclGraphPre(ctypes.Structure):
+    _fields_ = [("u", SclGraphPoolUnit * 2), ("xd", _P), ("dxd_a", _P), ("dxd_b", _P), ("in_seed", ctypes.c_uint32), ("in_p", ctypes.c_float),
+                ("Dp", ctypes.c_int32), ("N", ctypes.c_int32), ("store_common", ctypes.c_int32), ("same_bn", ctypes.c_int32), ("slab", _P), ("slab_bs", ctypes.c_int64)]
+
+
+class SclGraphFinalBranch(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("y2", "stats2", "Tp", "Sp", "m1", "m2")] + [("way_seed", ctypes.c_uint32 * 3), ("_pad", ctypes.c_int32)] + \
+               [(n, _P) for n in ("dz2", "dTp", "dSp", "dm1", "dm2")] + [("bn", SclGraphBn)]
+
+
+class SclGraphFinal(ctypes.Structure):
+    _fields_ = [("br", SclGraphFinalBranch * 2)] + [(n, _P) for n in ("Wout", "bout", "logits", "hidden", "d_logits", "d_hidden", "slab")] + \
+               [("slab_bs", ctypes.c_int64), ("o_Wout", ctypes.c_int32), ("o_bout", ctypes.c_int32), ("KT", ctypes.c_int32), ("KS", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("NC", ctypes.c_int32), ("way_p", ctypes.c_float), ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("_pad", ctypes.c_int32)]
+
+
+class SclGraphReduceJob(ctypes.Structure):
+    _fields_ = [("src", _P), ("dst", _P), ("stride", ctypes.c_int64), ("n", ctypes.c_int32), ("nparts", ctypes.c_int32)]
