@@ -729,19 +729,35 @@ __global__ __launch_bounds__(GT) void graph_final_bwd_kernel(const FinalArgs a) 
     }
 }
 
-// ---- parameter gradients: dst[i] += sum over parts of src[part * stride + i], parts in index order ---------------------------------------
-struct ReduceJobs { SclGraphReduceJob j[SCL_GRAPH_MAX_REDUCE_JOBS]; };
+// ---- parameter gradients: dst[i] += sum over parts of src[part * stride + i], parts in a fixed order ---------------------------------------
+// A block owns 32 consecutive elements of one job and splits the parts eight ways (the pairwise-score partials of a 66-node layer are
+// 1152 parts x 4352 columns: one thread walking them alone took a millisecond); the eight partial sums are combined in lane order.
+struct ReduceJobs { SclGraphReduceJob j[SCL_GRAPH_MAX_REDUCE_JOBS]; int chunk0[SCL_GRAPH_MAX_REDUCE_JOBS + 1]; int njobs; };
 __global__ __launch_bounds__(GT) void graph_reduce_kernel(const ReduceJobs jobs) {
-    const SclGraphReduceJob& q = jobs.j[blockIdx.x];
-    for (int i = threadIdx.x; i < q.n; i += GT) {
+    __shared__ float red[8][32];
+    int ji = 0;
+    while (ji + 1 < jobs.njobs && (int)blockIdx.x >= jobs.chunk0[ji + 1]) ++ji;
+    const SclGraphReduceJob& q = jobs.j[ji];
+    const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int i = ((int)blockIdx.x - jobs.chunk0[ji]) * 32 + el;
+    float s = 0.f;
+    if (i < q.n) {
         const float* p = q.src + i;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 3 < q.nparts; k += 4) {
-            s0 += p[(size_t)k * q.stride]; s1 += p[(size_t)(k + 1) * q.stride]; s2 += p[(size_t)(k + 2) * q.stride]; s3 += p[(size_t)(k + 3) * q.stride];
+        int k = pl;
+        for (; k + 24 < q.nparts; k += 32) {
+            s0 += p[(size_t)k * q.stride]; s1 += p[(size_t)(k + 8) * q.stride]; s2 += p[(size_t)(k + 16) * q.stride]; s3 += p[(size_t)(k + 24) * q.stride];
         }
-        for (; k < q.nparts; ++k) s0 += p[(size_t)k * q.stride];
-        q.dst[i] += (s0 + s1) + (s2 + s3);
+        for (; k < q.nparts; k += 8) s0 += p[(size_t)k * q.stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && i < q.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][el];
+        q.dst[i] += t;
     }
 }
 
@@ -832,7 +848,12 @@ extern "C" int scl_graph_final_bwd(const SclGraphFinal* f, int B, void* stream) 
 extern "C" int scl_graph_reduce(const SclGraphReduceJob* jobs, int njobs, void* stream) {
     SCL_REQUIRE(jobs && njobs > 0 && njobs <= SCL_GRAPH_MAX_REDUCE_JOBS, "graph_reduce: 1..%d jobs", SCL_GRAPH_MAX_REDUCE_JOBS);
     ReduceJobs rj;
-    for (int i = 0; i < njobs; ++i) { SCL_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].n > 0 && jobs[i].nparts > 0, "graph_reduce: bad job %d", i); rj.j[i] = jobs[i]; }
-    hipLaunchKernelGGL(graph_reduce_kernel, dim3(njobs), dim3(GT), 0, (hipStream_t)stream, rj);
+    int chunks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        SCL_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].n > 0 && jobs[i].nparts > 0, "graph_reduce: bad job %d", i);
+        rj.j[i] = jobs[i]; rj.chunk0[i] = chunks; chunks += (jobs[i].n + 31) / 32;
+    }
+    rj.chunk0[njobs] = chunks; rj.njobs = njobs;
+    hipLaunchKernelGGL(graph_reduce_kernel, dim3(chunks), dim3(GT), 0, (hipStream_t)stream, rj);
     return scl_check_launch("graph_reduce");
 }

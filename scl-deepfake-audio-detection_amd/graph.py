@@ -81,7 +81,7 @@ class _Plan:
         self.fin = [dict(dTp=f(B, self.kT2, g1), dSp=f(B, self.kS2, g1), dm1=f(B, g1), dm2=f(B, g1)) for _ in range(2)]
         self.de = (f(B, nS, 64), f(B, nT, 64))
         self.slab = None
-        self.seeds = {}
+        self.sig, self.fwd_calls, self.bwd_calls = None, None, None
 
 
 _PLANS = []
@@ -174,6 +174,7 @@ def _a3(lay, mod):
     with torch.no_grad():
         for i, w in enumerate(ws):
             a[i].copy_(w.detach().view(-1))
+    lay["a3_src"] = ws                    # stand-alone parameter tensors: the copy is refreshed before every replay
     return a
 
 
@@ -287,20 +288,71 @@ def _post(st, names, B, fwd):
     ops._call("scl_graph_post_fwd" if fwd else "scl_graph_post_bwd", arr, 2, B, _S(), keep=arr)
 
 
+_SEED_NAMES = ["in_S", "in_T", "in_11", "in_21", "in_12", "in_22", "pool_T", "pool_S", "pool_T1", "pool_S1", "pool_T2", "pool_S2", "drop"] + \
+              ["way_%s%d" % (s, i) for s in "TSM" for i in (0, 1)]
+
+
+def _signature(head, training):
+    """What the recorded launch sequence of a plan depends on besides the plan's own buffers: parameter and gradient storage."""
+    w, bnw = head.out_layer.weight, head.GAT_layer_S.bn.weight
+    return (torch.cuda.current_stream().cuda_stream, id(head), training, w.data_ptr(), _grad(w).data_ptr(), bnw.data_ptr(), _grad(bnw).data_ptr(), head.pool_hT2.proj.weight.data_ptr(),
+            _grad(head.master1).data_ptr(), float(head.drop.p), float(head.drop_way.p), float(head.GAT_layer_S.input_drop.p))
+
+
+def _set_seeds(pl, seeds):
+    """Per-call values inside the persistent argument blocks of a recorded program."""
+    st = pl.st
+    for tag, names in (("1", ("11", "21")), ("2", ("12", "22"))):
+        arr = st["pre"][tag]
+        for i, nm in enumerate(names):
+            arr[i].in_seed = seeds["in_" + nm]
+            if tag == "1":
+                arr[i].u[0].pool_seed, arr[i].u[1].pool_seed = seeds["pool_T"], seeds["pool_S"]
+            else:
+                arr[i].u[0].pool_seed, arr[i].u[1].pool_seed = seeds["pool_T%d" % (i + 1)], seeds["pool_S%d" % (i + 1)]
+    fin = st["fin"]
+    for i in range(2):
+        for k, site in enumerate("TSM"):
+            fin.br[i].way_seed[k] = seeds["way_%s%d" % (site, i)]
+    fin.drop_seed = seeds["drop"]
+
+
 def _forward(pl, head, e_S, e_T, training):
+    """First call of a (plan, parameter storage, mode): run the launch sequence while ops records it; later calls patch the per-call
+    values (seeds, input / output pointers) and replay the recorded C calls — the host stays ahead of the ~45 small kernels."""
     B = e_S.shape[0]
-    names = ["in_S", "in_T", "in_11", "in_21", "in_12", "in_22", "pool_T", "pool_S", "pool_T1", "pool_S1", "pool_T2", "pool_S2", "drop"] + \
-            ["way_%s%d" % (s, i) for s in "TSM" for i in (0, 1)]
-    seeds = {n: (_next_seed() if training else 0) for n in names}
+    seeds = {n: (_next_seed() if training else 0) for n in _SEED_NAMES}
+    pl.seeds_used = seeds
+    sig = _signature(head, training)
+    fin_out = (torch.empty(B, head.out_layer.weight.shape[0], device=pl.dev), torch.empty(B, 5 * pl.g1, device=pl.dev))
+    if getattr(pl, "sig", None) == sig and pl.fwd_calls is not None:
+        _set_seeds(pl, seeds)
+        for lay in pl.layers.values():
+            if lay.get("a3_src") is not None:
+                with torch.no_grad():
+                    for i, w in enumerate(lay["a3_src"]):
+                        lay["a3"][i].copy_(w.detach().view(-1))
+        fin = pl.st["fin"]
+        fin.logits, fin.hidden = fin_out[0].data_ptr(), fin_out[1].data_ptr()
+        a = pl.drop_entry[1]
+        a[0], a[3], a[4], a[7] = e_S.data_ptr(), seeds["in_S"], e_T.data_ptr(), seeds["in_T"]
+        pl.live = (e_S, e_T, fin_out)
+        ops.replay(pl.fwd_calls)
+        return fin_out
     st = _structs(pl, head, B, training, seeds)
-    pl.st, pl.seeds_used = st, seeds
+    pl.st, pl.sig, pl.fwd_calls, pl.bwd_calls = st, sig, None, None
+    for lay in pl.layers.values():
+        lay["a3_src"] = None
     mods = st["mods"]
+    record = ops._rec() is None
+    if record:
+        ops.start_recording()
     if not training:
         _eval_stats(pl, mods)
     lS, lT = pl.layers["S"], pl.layers["T"]
     p_in = float(mods["S"].input_drop.p) if training else 0.0
-    ops._call("scl_graph_drop", e_S.data_ptr(), lS["xd"].data_ptr(), e_S.numel(), seeds["in_S"], e_T.data_ptr(), lT["xd"].data_ptr(), e_T.numel(), seeds["in_T"],
-              p_in, _S(), keep=(e_S, e_T))
+    pl.drop_entry = ops._call("scl_graph_drop", e_S.data_ptr(), lS["xd"].data_ptr(), e_S.numel(), seeds["in_S"], e_T.data_ptr(), lT["xd"].data_ptr(), e_T.numel(),
+                              seeds["in_T"], p_in, _S())
     pl.p_in0 = p_in
     _score_fwd(pl, "S", mods["S"], B)
     _score_fwd(pl, "T", mods["T"], B)
@@ -314,11 +366,12 @@ def _forward(pl, head, e_S, e_T, training):
     _score_fwd(pl, "22", mods["22"], B)
     _post(st, ("12", "22"), B, True)
     fin = st["fin"]
-    logits = torch.empty(B, fin.NC, device=pl.dev)
-    hidden = torch.empty(B, 5 * pl.g1, device=pl.dev)
-    fin.logits, fin.hidden = logits.data_ptr(), hidden.data_ptr()
-    ops._call("scl_graph_final_fwd", ctypes.byref(fin), B, _S(), keep=(fin, logits, hidden))
-    return logits, hidden
+    fin.logits, fin.hidden = fin_out[0].data_ptr(), fin_out[1].data_ptr()
+    ops._call("scl_graph_final_fwd", ctypes.byref(fin), B, _S(), keep=fin)
+    pl.live = (e_S, e_T, fin_out)
+    if record:
+        pl.fwd_calls = ops.stop_recording()
+    return fin_out
 
 
 def _reduce(pl, head, B):
@@ -354,7 +407,18 @@ def _backward(pl, head, d_logits, d_hidden, training):
     dl = None if d_logits is None else d_logits.contiguous().float()
     dh = None if d_hidden is None else d_hidden.contiguous().float()
     fin.d_logits, fin.d_hidden = _ptr(dl), _ptr(dh)
-    ops._call("scl_graph_final_bwd", ctypes.byref(fin), B, _S(), keep=(fin, dl, dh))
+    deS, deT = torch.empty_like(pl.de[0]), torch.empty_like(pl.de[1])
+    sd = pl.seeds_used
+    if pl.bwd_calls is not None and pl.sig == _signature(head, training):
+        a = pl.dropb_entry[1]
+        a[2], a[4], a[7], a[9] = deS.data_ptr(), sd["in_S"], deT.data_ptr(), sd["in_T"]
+        pl.live_b = (dl, dh, deS, deT)
+        ops.replay(pl.bwd_calls)
+        return deS, deT
+    record = ops._rec() is None and pl.fwd_calls is not None
+    if record:
+        ops.start_recording()
+    ops._call("scl_graph_final_bwd", ctypes.byref(fin), B, _S(), keep=fin)
     _post(st, ("12", "22"), B, False)
     _score_bwd(pl, "12", mods["12"], B)
     _score_bwd(pl, "22", mods["22"], B)
@@ -367,11 +431,12 @@ def _backward(pl, head, d_logits, d_hidden, training):
     _score_bwd(pl, "S", mods["S"], B)
     _score_bwd(pl, "T", mods["T"], B)
     lS, lT = pl.layers["S"], pl.layers["T"]
-    deS, deT = torch.empty_like(pl.de[0]), torch.empty_like(pl.de[1])
-    sd = pl.seeds_used
-    ops._call("scl_graph_drop_bwd", lS["dxd_a"].data_ptr(), lS["dxd_b"].data_ptr(), deS.data_ptr(), deS.numel(), sd["in_S"],
-              lT["dxd_a"].data_ptr(), lT["dxd_b"].data_ptr(), deT.data_ptr(), deT.numel(), sd["in_T"], pl.p_in0, _S(), keep=(deS, deT))
+    pl.dropb_entry = ops._call("scl_graph_drop_bwd", lS["dxd_a"].data_ptr(), lS["dxd_b"].data_ptr(), deS.data_ptr(), deS.numel(), sd["in_S"],
+                               lT["dxd_a"].data_ptr(), lT["dxd_b"].data_ptr(), deT.data_ptr(), deT.numel(), sd["in_T"], pl.p_in0, _S())
     _reduce(pl, head, B)
+    pl.live_b = (dl, dh, deS, deT)
+    if record:
+        pl.bwd_calls = ops.stop_recording()
     return deS, deT
 
 

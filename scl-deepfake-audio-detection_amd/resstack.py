@@ -77,6 +77,7 @@ class _Plan:
         self.dz = z(max(cps))
         self.dtmp = z(max(cps))
         self.wpk = None
+        self.sig, self.fwd_calls, self.bwd_calls, self.bwd_need = None, None, None, None
         nsl = L.load().scl_rs_wgrad_nslabs
         self.part = torch.empty(max(max(nsl(ci, co) * 6 * ci * co for ci, co in zip(cps[:-1], cps[1:])), max(nsl(c, c) * 6 * c * c for c in cps[1:])), device=dev)
         self.gx = L.SclRsGeom(B, H, W, 1, H, 0)        # block inputs / outputs: rows 1..H
@@ -170,12 +171,33 @@ def _bn_args(bn):
     return dict(eps=float(bn.eps), momentum=0.1 if bn.momentum is None else float(bn.momentum))
 
 
+def _signature(blocks, training):
+    """What a plan's recorded launch sequence depends on besides its own buffers: parameter / gradient / buffer storage and the mode."""
+    w0, wl = blocks[0].conv1.weight, blocks[-1].conv2.weight
+    return (torch.cuda.current_stream().cuda_stream, id(blocks[0]), len(blocks), training, w0.data_ptr(), wl.data_ptr(), _grad(w0).data_ptr(), _grad(wl).data_ptr(),
+            _grad(blocks[-1].bn2.bias).data_ptr(), blocks[-1].bn2.running_mean.data_ptr())
+
+
 def _forward(pl, x0, blocks, training):
+    """The first call of a (plan, parameter storage, mode) runs the launch sequence while ops records it; later calls patch the input /
+    output pointers and replay the recorded C calls."""
     B, H, W = pl.B, pl.H, pl.W
     S = _stream
+    c_last = pl.cps[-1]
+    out = torch.empty(B, H, W, c_last, device=pl.dev)
+    sig = _signature(blocks, training)
+    if pl.sig == sig and pl.fwd_calls is not None:
+        pl.in_entry[1][0], pl.out_entry[1][1] = x0.data_ptr(), out.data_ptr()
+        pl.live = (x0, out)
+        ops.replay(pl.fwd_calls)
+        return out
+    pl.sig, pl.fwd_calls, pl.bwd_calls = sig, None, None
+    record = ops._rec() is None
+    if record:
+        ops.start_recording()
     wv = _pack_all(pl, blocks)
     pl.wv = wv
-    ops._call("scl_rs_copy", x0.data_ptr(), pl.p(pl.x[0], pl.cps[0]), x0.shape[-1], pl.cps[0], 0, ctypes.byref(pl.gx), S(), keep=x0)
+    pl.in_entry = ops._call("scl_rs_copy", x0.data_ptr(), pl.p(pl.x[0], pl.cps[0]), x0.shape[-1], pl.cps[0], 0, ctypes.byref(pl.gx), S())
     n_y, n_x = float(B * (H + 1) * W), float(B * H * W)
     for i, blk in enumerate(blocks):
         ci, co = pl.cps[i], pl.cps[i + 1]
@@ -202,9 +224,10 @@ def _forward(pl, x0, blocks, training):
                   run_mean=bn1.running_mean, run_var=bn1.running_var, nbt=bn1.num_batches_tracked, **_bn_args(bn1))
         else:
             _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend)
-    c_last = pl.cps[-1]
-    out = torch.empty(B, H, W, c_last, device=pl.dev)
-    ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S(), keep=out)
+    pl.out_entry = ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S())
+    pl.live = (x0, out)
+    if record:
+        pl.fwd_calls = ops.stop_recording()
     return out
 
 
@@ -223,7 +246,18 @@ def _backward(pl, d_out, blocks, training, need_dx0):
     c_last = pl.cps[-1]
     n_y = float(B * (H + 1) * W)
     d_out = d_out.contiguous().float()
-    ops._call("scl_rs_copy", d_out.data_ptr(), pl.p(pl.dx[-1], c_last), c_last, c_last, 0, ctypes.byref(pl.gx), S(), keep=d_out)
+    dx0 = torch.empty(B, H, W, 1, device=pl.dev) if need_dx0 else None
+    if pl.bwd_calls is not None and pl.bwd_need == need_dx0 and pl.sig == _signature(blocks, training):
+        pl.din_entry[1][0] = d_out.data_ptr()
+        if need_dx0:
+            pl.dout_entry[1][1] = dx0.data_ptr()
+        pl.live_b = (d_out, dx0)
+        ops.replay(pl.bwd_calls)
+        return dx0
+    record = ops._rec() is None and pl.fwd_calls is not None
+    if record:
+        ops.start_recording()
+    pl.din_entry = ops._call("scl_rs_copy", d_out.data_ptr(), pl.p(pl.dx[-1], c_last), c_last, c_last, 0, ctypes.byref(pl.gx), S())
     neg = lambda s: [-v for v in s]
     for i in reversed(range(len(blocks))):
         blk = blocks[i]
@@ -249,10 +283,11 @@ def _backward(pl, d_out, blocks, training, need_dx0):
         else:
             addend = dcur
         _conv(pl, dz, wv[(i, "c1T")], dprev, co, ci, neg(pl.s1), pl.gx, addend=addend)
-    if not need_dx0:
-        return None
-    dx0 = torch.empty(B, H, W, 1, device=pl.dev)
-    ops._call("scl_rs_copy", pl.p(pl.dx[0], pl.cps[0]), dx0.data_ptr(), pl.cps[0], 1, 1, ctypes.byref(pl.gx), S(), keep=dx0)
+    if need_dx0:
+        pl.dout_entry = ops._call("scl_rs_copy", pl.p(pl.dx[0], pl.cps[0]), dx0.data_ptr(), pl.cps[0], 1, 1, ctypes.byref(pl.gx), S())
+    pl.live_b, pl.bwd_need = (d_out, dx0), need_dx0
+    if record:
+        pl.bwd_calls = ops.stop_recording()
     return dx0
 
 
