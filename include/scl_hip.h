@@ -371,7 +371,7 @@ int scl_gat_score_bwd(const float* x, const float* W, const float* bias, const f
 typedef struct SclRsGeom { int32_t B, H, W, r_lo, r_hi, _pad; } SclRsGeom;
 /* out[g][n] = mask(g) * (bias[n] + addend[g][n] + sum_t sum_c in[g + shift[t]][c] * Wt[t][c][n])   — a (kh, kw) tap of a stride-1
  * convolution over a bordered map is ONE flat shift; the data gradient is the same call with negated shifts and transposed weights.
- * wpk: scl_rs_pack_weights image.  (cin, cout, ntaps) in {(16|32,32,6), (32|64,64,6), (16,32,3), (32,64,3), (32,16,3|6), (64,32,3|6)}.
+ * wpk: scl_rs_pack_weights image.  (cin, cout, ntaps) in {(16|32,32,6), (32|64,64,6), (16,32,3), (32,64,3), (32,16,3|6), (64,32,3|6), (64,64,1)}.
  * stat_mode 1: per-channel sum / sum of squares of the stored values; the last block turns them into BatchNorm statistics
  *   stats_out[4][cout] = mean, rstd, gamma * rstd, beta (biased variance, eps) and, when run_mean is given, updates
  *   running_mean / running_var (momentum, unbiased) and num_batches_tracked exactly as nn.BatchNorm2d in training does.
@@ -379,7 +379,8 @@ typedef struct SclRsGeom { int32_t B, H, W, r_lo, r_hi, _pad; } SclRsGeom;
  *   xhat = (y1 - mean) * rstd from bnstats; the last block adds them to dbeta / dgamma and stores stats_out[2][cout] = their means
  *   (zeros when training == 0) for scl_rs_bn_bwd_apply.
  * acc: SCL_RS_NSLOT * 2 * cout zeroed doubles, ticket: one zeroed uint32 (both are left zeroed).  nvalid = number of unmasked positions.
- * stat_mode 1 exists for the forward shapes (cout >= cin, six taps), stat_mode 2 for cin == cout, six taps. */
+ * stat_mode 1 exists for the forward shapes (cout >= cin, six taps) and the 1-tap 64 -> 64 form, stat_mode 2 for cin == cout with six taps or one
+ * (act_a == NULL: the sums of the plain convolution result — the gradient arriving at a BatchNorm output). */
 #define SCL_RS_NSLOT 16
 typedef struct SclRsConv {
     const float* in; const float* wpk; const float* bias; const float* addend; float* out;
@@ -390,7 +391,7 @@ typedef struct SclRsConv {
     double nvalid;
     SclRsGeom geom;
     int32_t shift[6];
-    int32_t cin, cout, ntaps, stat_mode, training, _pad;
+    int32_t cin, cout, ntaps, stat_mode, training, epi_act;      /* epi_act: store (and take the statistics of) selu(conv + bias + addend) */
     float eps, momentum;
 } SclRsConv;
 int scl_rs_conv(const SclRsConv* c, void* stream);
@@ -398,7 +399,7 @@ int scl_rs_conv(const SclRsConv* c, void* stream);
  * CINp / COUTp: the kernel's channel counts (multiples of 16, zero-filled); transposed != 0: the data-gradient image (the convolution's
  * Co becomes the contraction).  One launch packs up to SCL_RS_MAX_PACK_JOBS images. */
 #define SCL_RS_MAX_PACK_JOBS 32
-typedef struct SclRsPackJob { const float* w; float* out; int32_t Co, Ci, ntaps, CINp, COUTp, transposed; } SclRsPackJob;
+typedef struct SclRsPackJob { const float* w; float* out; int32_t Co, Ci, ntaps, CINp, COUTp, transposed, ld, _pad; } SclRsPackJob;      /* ld: row pitch (0: Ci) */
 int scl_rs_pack_weights(const SclRsPackJob* jobs, int njobs, void* stream);
 /* part[scl_rs_wgrad_nslabs(cin, cout)][ntaps * cin * cout] f32 partial slabs of dW[t][c][n] = sum_g in[g + shift[t]][c] * dout[g][n]
  * (dout zero off the valid positions); dbias[n] += sum_g dout[g][n] when dbias != NULL (bacc: SCL_RS_NSLOT * cout zeroed doubles, ticket as above) */
@@ -406,11 +407,16 @@ int scl_rs_wgrad_nslabs(int cin, int cout);
 int scl_rs_wgrad(const float* in, const float* dout, int cin, int cout, int ntaps, const int* shift, const SclRsGeom* geom, float* part,
                  double* bacc, uint32_t* ticket, float* dbias, void* stream);
 /* dw (torch layout [Co, Ci, ntaps]) += the slabs, summed in index order */
-int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, float* dw, void* stream);
+int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, int ld, float* dw, void* stream);      /* ld: row pitch of dw (0: Ci) */
 /* a = mask * selu((y - stats[0]) * stats[2] + stats[3]) (BatchNorm + SELU, model/wav2vec2_aasist.py:423-424) */
-int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, const SclRsGeom* geom, void* stream);
+int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, int act, const SclRsGeom* geom, void* stream);      /* act 0: the affine map alone */
 /* in place: dz := mask * stats[2] * (dz - bstats[0] - (y - stats[0]) * stats[1] * bstats[1]) — the input gradient of that BatchNorm */
-int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, const SclRsGeom* geom, void* stream);
+int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, int selu_in, const SclRsGeom* geom, void* stream);      /* selu_in: y is a SELU output, chain selu'(y) */
+/* attention pooling of the AASIST encoder output (model/wav2vec2_aasist.py:527-541) over bordered maps x, l [G, C]:
+ * eS[b][h][c] = sum_w x softmax_w(l) + pos[h][c] (pos may be NULL), eT[b][w][c] = sum_h x softmax_h(l); backward writes the interiors of
+ * dx, dl (their borders must already be zero) */
+int scl_rs_attn_pool_fwd(const float* x, const float* l, const float* pos, float* eS, float* eT, int C, const SclRsGeom* geom, void* stream);
+int scl_rs_attn_pool_bwd(const float* x, const float* l, const float* deS, const float* deT, float* dx, float* dl, int C, const SclRsGeom* geom, void* stream);
 /* eval mode: stats[4][C] from the running statistics */
 int scl_rs_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
                          float* stats, void* stream);

@@ -169,18 +169,23 @@ class AasistHead(nn.Module):
         x = hipnn.max_pool3(feats.transpose(1, 2)).unsqueeze(-1)
         x = hipnn.batch_norm(x, self.first_bn, hipnn.ACT_SELU)
         blocks = [blk[0] for blk in self.encoder]
-        if FUSED_STACK and resstack.supported(blocks, x.shape[2]):
-            x = resstack.res_stack(x, blocks)          # the six Residual_blocks as one autograd node (csrc/resstack.hip)
+        fused_stack = FUSED_STACK and resstack.supported(blocks, x.shape[2])
+        if fused_stack and resstack.attn_supported(self.first_bn1, self.attention, self.pos_S, blocks[-1].conv2.weight.shape[0]) and x.shape[1] == self.pos_S.shape[1]:
+            # the six Residual_blocks, first_bn1 + SELU, the attention block and both attention poolings as one autograd node (csrc/resstack.hip)
+            e_S, e_T = resstack.res_stack_pool(x, blocks, self.first_bn1, self.attention, self.pos_S)
         else:
-            for blk in blocks:
-                x = blk.run(x)
-        x = hipnn.batch_norm(x, self.first_bn1, hipnn.ACT_SELU)                    # [B, 42, T/3, 64]
-        a0, a2, a3 = self.attention[0], self.attention[2], self.attention[3]
-        w = hipnn.linear(x, a0.weight.view(a0.weight.shape[0], -1), a0.bias)
-        w = hipnn.batch_norm(F.selu(w), a2, hipnn.ACT_NONE)
-        w = hipnn.linear(w, a3.weight.view(a3.weight.shape[0], -1), a3.bias)      # one score map for both poolings
-        e_S = (x * F.softmax(w, dim=2)).sum(2) + self.pos_S                        # spectral nodes  [B, 42, 64]
-        e_T = (x * F.softmax(w, dim=1)).sum(1)                                     # temporal nodes  [B, T/3, 64]
+            if fused_stack:
+                x = resstack.res_stack(x, blocks)          # the six Residual_blocks as one autograd node
+            else:
+                for blk in blocks:
+                    x = blk.run(x)
+            x = hipnn.batch_norm(x, self.first_bn1, hipnn.ACT_SELU)                    # [B, 42, T/3, 64]
+            a0, a2, a3 = self.attention[0], self.attention[2], self.attention[3]
+            w = hipnn.linear(x, a0.weight.view(a0.weight.shape[0], -1), a0.bias)
+            w = hipnn.batch_norm(F.selu(w), a2, hipnn.ACT_NONE)
+            w = hipnn.linear(w, a3.weight.view(a3.weight.shape[0], -1), a3.bias)      # one score map for both poolings
+            e_S = (x * F.softmax(w, dim=2)).sum(2) + self.pos_S                        # spectral nodes  [B, 42, 64]
+            e_T = (x * F.softmax(w, dim=1)).sum(1)                                     # temporal nodes  [B, T/3, 64]
         if FUSED_GRAPH and graph.supported(self, e_S.shape[1], e_T.shape[1]):
             return graph.graph_module(e_S, e_T, self)          # the whole graph module as one autograd node (csrc/graph.hip)
         return AasistHead.graph_unfused(self, e_S, e_T)

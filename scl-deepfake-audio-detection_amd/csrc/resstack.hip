@@ -65,6 +65,8 @@ struct RsConvK {
     RsGeom q;
     int shift[6];
     int smin, span, stat_mode, training;
+    int epi_act;        // 1: the stored value (and its statistics) is selu(conv + bias + addend)   — the attention block's conv -> SELU -> BatchNorm
+    int act_a_none;     // statistics mode 2 without the activation factor: out = conv (the gradient of a BatchNorm OUTPUT), xhat from y1
     float eps, momentum;
     double nvalid;
 };
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const
                 ad[u] = f32x4{0.f, 0.f, 0.f, 0.f}; aa[u] = ad[u]; yy[u] = ad[u];
                 if (g < (unsigned)d.q.G) {
                     if (d.addend) ad[u] = *reinterpret_cast<const f32x4*>(d.addend + off);
-                    if (SM == 2) { aa[u] = *reinterpret_cast<const f32x4*>(d.act_a + off); yy[u] = *reinterpret_cast<const f32x4*>(d.y1 + off); }
+                    if (SM == 2) { if (!d.act_a_none) aa[u] = *reinterpret_cast<const f32x4*>(d.act_a + off); yy[u] = *reinterpret_cast<const f32x4*>(d.y1 + off); }
                 }
             }
 #pragma unroll
@@ -192,13 +194,13 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const
                 if (SM == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = ok ? v[e] * selu_grad_from_y(aa[u][e]) : 0.f;
+                        v[e] = ok ? (d.act_a_none ? v[e] : v[e] * selu_grad_from_y(aa[u][e])) : 0.f;
                         t0[e] += v[e];
                         t1[e] += v[e] * ((yy[u][e] - mean4[e]) * rstd4[e]);      // v is 0 off the valid positions (y1 is finite everywhere)
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? (d.epi_act ? selu_f(v[e]) : v[e]) : 0.f;
                     if (SM == 1) { t0 += v; t1 += v * v; }
                 }
                 *reinterpret_cast<f32x4*>(d.out + (size_t)g * COUT + 4 * ch4) = v;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const
 
 // ---- element-wise passes ---------------------------------------------------------------------------------------------------------------
 // a = selu((y - mean) * sc + beta) on the valid positions, 0 on the borders (they are conv2's zero padding)
-__global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ a, int C, RsGeom q) {
+__global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ a, int C, int act, RsGeom q) {
     const int c4n = C >> 2;
     const long long n4 = (long long)q.G * c4n;
     for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < n4; f += (long long)gridDim.x * 256) {
@@ -267,14 +269,14 @@ __global__ __launch_bounds__(256) void rs_bn_act_kernel(const float* __restrict_
             const f32x4 v = *reinterpret_cast<const f32x4*>(y + f * 4), mean = *reinterpret_cast<const f32x4*>(stats + c),
                         sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c), be = *reinterpret_cast<const f32x4*>(stats + 3 * C + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = selu_f((v[e] - mean[e]) * sc[e] + be[e]);
+            for (int e = 0; e < 4; ++e) { const float z = (v[e] - mean[e]) * sc[e] + be[e]; o[e] = act ? selu_f(z) : z; }
         }
         *reinterpret_cast<f32x4*>(a + f * 4) = o;
     }
 }
 // dy = sc * (dz - m1 - xhat * m2) on the valid positions (m1 = m2 = 0 in eval mode), 0 elsewhere; in place on dz
 __global__ __launch_bounds__(256) void rs_bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ stats,
-                                                             const float* __restrict__ bstats, int C, RsGeom q) {
+                                                             const float* __restrict__ bstats, int C, int selu_in, RsGeom q) {
     const int c4n = C >> 2;
     const long long n4 = (long long)q.G * c4n;
     for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < n4; f += (long long)gridDim.x * 256) {
@@ -287,7 +289,10 @@ __global__ __launch_bounds__(256) void rs_bn_bwd_apply_kernel(float* __restrict_
                         sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c);
             const f32x4 m1 = *reinterpret_cast<const f32x4*>(bstats + c), m2 = *reinterpret_cast<const f32x4*>(bstats + C + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = sc[e] * (v[e] - m1[e] - (yy[e] - mean[e]) * rstd[e] * m2[e]);
+            for (int e = 0; e < 4; ++e) {      // selu_in: y is itself a SELU output (conv -> SELU -> BatchNorm): chain its derivative
+                o[e] = sc[e] * (v[e] - m1[e] - (yy[e] - mean[e]) * rstd[e] * m2[e]);
+                if (selu_in) o[e] *= selu_grad_from_y(yy[e]);
+            }
         }
         *reinterpret_cast<f32x4*>(dz + f * 4) = o;
     }
@@ -348,8 +353,9 @@ __global__ __launch_bounds__(256) void rs_pack_kernel(const RsPackJobs jobs) {
         const int t = rest % q.ntaps; const int cb = rest / q.ntaps;
         const int c = 16 * jj + 4 * (lane >> 4) + j, n = 16 * cb + (lane & 15);
         float v = 0.f;
-        if (!q.transposed) { if (n < q.Co && c < q.Ci) v = q.w[((size_t)n * q.Ci + c) * q.ntaps + t]; }
-        else { if (c < q.Co && n < q.Ci) v = q.w[((size_t)c * q.Ci + n) * q.ntaps + t]; }
+        const int ld = q.ld > 0 ? q.ld : q.Ci;      // row pitch of the torch tensor (a column block of a wider filter: Ci < ld)
+        if (!q.transposed) { if (n < q.Co && c < q.Ci) v = q.w[((size_t)n * ld + c) * q.ntaps + t]; }
+        else { if (c < q.Co && n < q.Ci) v = q.w[((size_t)c * ld + n) * q.ntaps + t]; }
         q.out[e] = v;
     }
 }
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(256, (CIN * COUT >= 4096 ? 1 : 2)) void rs_wgrad_ke
 }
 
 // dW[n][c][t] (torch layout [Co, Ci, NT]) += sum over slabs of part[slab][t][c][n], slabs in index order.  64 elements x 4 slab lanes per block.
-__global__ __launch_bounds__(256) void rs_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int NT, int CINp, int COUTp, int Co, int Ci, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void rs_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int NT, int CINp, int COUTp, int Co, int Ci, int ld, float* __restrict__ dw) {
     __shared__ float red[4][64];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -498,7 +504,101 @@ __global__ __launch_bounds__(256) void rs_wgrad_reduce_kernel(const float* __res
     if (sl == 0 && e < n_el) {
         const float tot = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
         const int n = e % COUTp, c = (e / COUTp) % CINp, t = e / (COUTp * CINp);
-        if (n < Co && c < Ci) dw[((size_t)n * Ci + c) * NT + t] += tot;
+        if (n < Co && c < Ci) dw[((size_t)n * ld + c) * NT + t] += tot;
+    }
+}
+
+// ---- attention pooling over the [H, W] map (model/wav2vec2_aasist.py:527-541): e_S[h][c] = sum_w x[h][w][c] softmax_w(l[h][.][c]) + pos_S[h][c],
+// e_T[w][c] = sum_h x[h][w][c] softmax_h(l[.][w][c]).  One block per (utterance, four channels): both maps' slices of that channel quad
+// sit in LDS ([H][W] float4 each), a thread owns whole rows (softmax over W) and then whole columns (softmax over H).
+__global__ __launch_bounds__(256) void rs_attn_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ l, const float* __restrict__ pos,
+                                                               float* __restrict__ eS, float* __restrict__ eT, int C, int H, int W, RsGeom q) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* LX = reinterpret_cast<f32x4*>(lds);
+    f32x4* LL = LX + H * W;
+    const int b = blockIdx.x, c4 = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)b * q.RPU * q.Wp;
+    for (int e = tid; e < H * W; e += 256) {
+        const int h = e / W, w = e - h * W;
+        const size_t g = base + (size_t)(h + 1) * q.Wp + (w + 1);
+        LX[e] = *reinterpret_cast<const f32x4*>(x + g * C + 4 * c4);
+        LL[e] = *reinterpret_cast<const f32x4*>(l + g * C + 4 * c4);
+    }
+    __syncthreads();
+    for (int r = tid; r < H + W; r += 256) {
+        const bool row = r < H;
+        const int n = row ? W : H, i0 = row ? r * W : r - H, st = row ? 1 : W;
+        f32x4 mx = LL[i0];
+        for (int k = 1; k < n; ++k) { const f32x4 v = LL[i0 + k * st]; for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[e]); }
+        f32x4 den = {0.f, 0.f, 0.f, 0.f}, num = den;
+        for (int k = 0; k < n; ++k) {
+            const f32x4 v = LL[i0 + k * st], xv = LX[i0 + k * st];
+            for (int e = 0; e < 4; ++e) { const float p = __expf(v[e] - mx[e]); den[e] += p; num[e] = fmaf(p, xv[e], num[e]); }
+        }
+        f32x4 o;
+        for (int e = 0; e < 4; ++e) o[e] = num[e] / den[e];
+        if (row) {
+            if (pos) o += *reinterpret_cast<const f32x4*>(pos + (size_t)r * C + 4 * c4);
+            *reinterpret_cast<f32x4*>(eS + ((size_t)b * H + r) * C + 4 * c4) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(eT + ((size_t)b * W + (r - H)) * C + 4 * c4) = o;
+        }
+    }
+}
+// backward: dx = deS[h] P1 + deT[w] P2;  dl = P1 (deS[h] x - <deS[h] x, P1>_w) + P2 (deT[w] x - <deT[w] x, P2>_h)     (bordered outputs, zero borders kept)
+// Four [H][W] slices per channel in LDS: a block takes TWO channels (42 x 66 x 2 x 4 arrays = 88 KiB).
+typedef __attribute__((ext_vector_type(2))) float rs_f32x2;
+__global__ __launch_bounds__(256) void rs_attn_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ l, const float* __restrict__ deS,
+                                                               const float* __restrict__ deT, float* __restrict__ dx, float* __restrict__ dl, int C, int H, int W, RsGeom q) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    rs_f32x2* LX = reinterpret_cast<rs_f32x2*>(lds);
+    rs_f32x2* LL = LX + H * W;
+    rs_f32x2* LDX = LL + H * W;
+    rs_f32x2* LDL = LDX + H * W;
+    const int b = blockIdx.x, c2 = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)b * q.RPU * q.Wp;
+    for (int e = tid; e < H * W; e += 256) {
+        const int h = e / W, w = e - h * W;
+        const size_t g = base + (size_t)(h + 1) * q.Wp + (w + 1);
+        LX[e] = *reinterpret_cast<const rs_f32x2*>(x + g * C + 2 * c2);
+        LL[e] = *reinterpret_cast<const rs_f32x2*>(l + g * C + 2 * c2);
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {      // rows first (they initialise LDX / LDL), then columns (they accumulate)
+        const int cnt = pass == 0 ? H : W;
+        for (int r = tid; r < cnt; r += 256) {
+            const bool row = pass == 0;
+            const int n = row ? W : H, i0 = row ? r * W : r, st = row ? 1 : W;
+            const rs_f32x2 de = row ? *reinterpret_cast<const rs_f32x2*>(deS + ((size_t)b * H + r) * C + 2 * c2)
+                                    : *reinterpret_cast<const rs_f32x2*>(deT + ((size_t)b * W + r) * C + 2 * c2);
+            rs_f32x2 mx = LL[i0];
+            for (int k = 1; k < n; ++k) { const rs_f32x2 v = LL[i0 + k * st]; mx[0] = fmaxf(mx[0], v[0]); mx[1] = fmaxf(mx[1], v[1]); }
+            rs_f32x2 den = {0.f, 0.f}, dot = den;
+            for (int k = 0; k < n; ++k) {
+                const rs_f32x2 v = LL[i0 + k * st], xv = LX[i0 + k * st];
+                for (int e = 0; e < 2; ++e) { const float p = __expf(v[e] - mx[e]); den[e] += p; dot[e] = fmaf(p, xv[e], dot[e]); }
+            }
+            rs_f32x2 inv, ex;      // ex = <x, P> (the forward value without pos_S)
+            for (int e = 0; e < 2; ++e) { inv[e] = 1.0f / den[e]; ex[e] = dot[e] * inv[e]; }
+            for (int k = 0; k < n; ++k) {
+                const int i = i0 + k * st;
+                const rs_f32x2 v = LL[i], xv = LX[i];
+                rs_f32x2 gx, gl;
+                for (int e = 0; e < 2; ++e) {
+                    const float p = __expf(v[e] - mx[e]) * inv[e];
+                    gx[e] = de[e] * p;
+                    gl[e] = p * de[e] * (xv[e] - ex[e]);
+                }
+                if (row) { LDX[i] = gx; LDL[i] = gl; } else { LDX[i] += gx; LDL[i] += gl; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < H * W; e += 256) {
+        const int h = e / W, w = e - h * W;
+        const size_t g = base + (size_t)(h + 1) * q.Wp + (w + 1);
+        *reinterpret_cast<rs_f32x2*>(dx + g * C + 2 * c2) = LDX[e];
+        *reinterpret_cast<rs_f32x2*>(dl + g * C + 2 * c2) = LDL[e];
     }
 }
 
@@ -519,7 +619,7 @@ int rs_conv_launch_t(const RsConvK& k, int grid, hipStream_t s) {
     size_t lds = lds_in > lds_out ? lds_in : lds_out;
     if (lds_st > lds) lds = lds_st;
     if (lds > 160 * 1024) { scl_set_error("rs_conv: tile + halo of %zu bytes exceeds the LDS", lds); return SCL_EINVAL; }
-    constexpr bool FWD = NT == 6 && COUT >= CIN, C2T = NT == 6 && CIN == COUT;
+    constexpr bool FWD = (NT == 6 && COUT >= CIN) || NT == 1, C2T = (NT == 6 || NT == 1) && CIN == COUT;
     if (k.stat_mode == 0) return rs_conv_launch_sm<CIN, COUT, NT, 0>(k, grid, lds, s);
     if constexpr (FWD) { if (k.stat_mode == 1) return rs_conv_launch_sm<CIN, COUT, NT, 1>(k, grid, lds, s); }
     if constexpr (C2T) { if (k.stat_mode == 2) return rs_conv_launch_sm<CIN, COUT, NT, 2>(k, grid, lds, s); }
@@ -549,7 +649,7 @@ bool rs_fill_geom(const SclRsGeom& g, RsGeom* q) {
     return true;
 }
 bool rs_shifts(const int* shift, int ntaps, int* dst, int* smin, int* span) {
-    if (ntaps != 3 && ntaps != 6) { scl_set_error("rs: ntaps must be 3 or 6"); return false; }
+    if (ntaps != 1 && ntaps != 3 && ntaps != 6) { scl_set_error("rs: ntaps must be 1, 3 or 6"); return false; }
     int lo = shift[0], hi = shift[0];
     for (int t = 0; t < 6; ++t) { dst[t] = t < ntaps ? shift[t] : 0; if (t < ntaps) { lo = shift[t] < lo ? shift[t] : lo; hi = shift[t] > hi ? shift[t] : hi; } }
     *smin = lo; *span = hi - lo;
@@ -565,7 +665,7 @@ extern "C" int scl_rs_pack_weights(const SclRsPackJob* jobs, int njobs, void* st
     int max_el = 0;
     for (int i = 0; i < njobs; ++i) {
         const SclRsPackJob& q = jobs[i];
-        SCL_REQUIRE(q.w && q.out && q.Co > 0 && q.Ci > 0 && (q.ntaps == 3 || q.ntaps == 6) && q.CINp % 16 == 0 && q.COUTp % 16 == 0, "rs_pack_weights: bad job %d", i);
+        SCL_REQUIRE(q.w && q.out && q.Co > 0 && q.Ci > 0 && (q.ntaps == 1 || q.ntaps == 3 || q.ntaps == 6) && q.CINp % 16 == 0 && q.COUTp % 16 == 0 && (q.ld == 0 || q.ld >= q.Ci), "rs_pack_weights: bad job %d", i);
         SCL_REQUIRE(q.transposed ? (q.Co <= q.CINp && q.Ci <= q.COUTp) : (q.Co <= q.COUTp && q.Ci <= q.CINp), "rs_pack_weights: padded sizes below the real ones (job %d)", i);
         pj.j[i] = q;
         const int n_el = (q.COUTp / 16) * q.ntaps * (q.CINp / 16) * 256;
@@ -582,11 +682,13 @@ extern "C" int scl_rs_conv(const SclRsConv* c, void* stream) {
     if (!rs_shifts(c->shift, c->ntaps, k.shift, &k.smin, &k.span)) return SCL_EINVAL;
     SCL_REQUIRE(c->stat_mode >= 0 && c->stat_mode <= 2, "rs_conv: stat_mode %d", c->stat_mode);
     SCL_REQUIRE(c->stat_mode == 0 || (c->acc && c->ticket && c->nvalid > 0), "rs_conv: statistics need accumulators, a ticket and the valid count");
-    SCL_REQUIRE(c->stat_mode != 2 || (c->act_a && c->y1 && c->bnstats && c->stats_out), "rs_conv: stat_mode 2 needs a, y1, the forward statistics and stats_out");
+    SCL_REQUIRE(c->stat_mode != 2 || (c->y1 && c->bnstats && c->stats_out), "rs_conv: stat_mode 2 needs y1, the forward statistics and stats_out");
+    SCL_REQUIRE(!c->epi_act || c->stat_mode != 2, "rs_conv: the SELU epilogue belongs to the forward modes");
     k.in = c->in; k.wpk = c->wpk; k.bias = c->bias; k.addend = c->addend; k.out = c->out; k.act_a = c->act_a; k.y1 = c->y1; k.bnstats = c->bnstats;
     k.acc = c->acc; k.ticket = c->ticket; k.gamma = c->gamma; k.beta = c->beta; k.run_mean = c->run_mean; k.run_var = c->run_var;
     k.nbt = (long long*)c->nbt; k.stats_out = c->stats_out; k.dgamma = c->dgamma; k.dbeta = c->dbeta;
     k.stat_mode = c->stat_mode; k.training = c->training; k.eps = c->eps; k.momentum = c->momentum; k.nvalid = c->nvalid;
+    k.epi_act = c->epi_act; k.act_a_none = (c->stat_mode == 2 && !c->act_a) ? 1 : 0;
     int grid = 0;          // chosen per instantiation (tile size, blocks per CU)
     hipStream_t s = (hipStream_t)stream;
     const int key = c->cin * 10000 + c->cout * 10 + c->ntaps;
@@ -601,6 +703,7 @@ extern "C" int scl_rs_conv(const SclRsConv* c, void* stream) {
         case 640326: return rs_conv_launch_t<64, 32, 6>(k, grid, s);
         case 320163: return rs_conv_launch_t<32, 16, 3>(k, grid, s);
         case 640323: return rs_conv_launch_t<64, 32, 3>(k, grid, s);
+        case 640641: return rs_conv_launch_t<64, 64, 1>(k, grid, s);
         default: break;
     }
     scl_set_error("rs_conv: no instantiation for %d -> %d channels, %d taps", c->cin, c->cout, c->ntaps);
@@ -628,34 +731,36 @@ extern "C" int scl_rs_wgrad(const float* in, const float* dout, int cin, int cou
         case 640646: return rs_wgrad_launch_t<64, 64, 6>(k, grid, s);
         case 160323: return rs_wgrad_launch_t<16, 32, 3>(k, grid, s);
         case 320643: return rs_wgrad_launch_t<32, 64, 3>(k, grid, s);
+        case 640641: return rs_wgrad_launch_t<64, 64, 1>(k, grid, s);
         default: break;
     }
     scl_set_error("rs_wgrad: no instantiation for %d -> %d channels, %d taps", cin, cout, ntaps);
     return SCL_EINVAL;
 }
 
-extern "C" int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, float* dw, void* stream) {
-    SCL_REQUIRE(part && dw && nslab > 0 && Co <= COUTp && Ci <= CINp, "rs_wgrad_reduce: bad arguments");
+extern "C" int scl_rs_wgrad_reduce(const float* part, int nslab, int ntaps, int CINp, int COUTp, int Co, int Ci, int ld, float* dw, void* stream) {
+    SCL_REQUIRE(part && dw && nslab > 0 && Co <= COUTp && Ci <= CINp && (ld == 0 || ld >= Ci), "rs_wgrad_reduce: bad arguments");
+    if (ld == 0) ld = Ci;
     const int n_el = ntaps * CINp * COUTp;
-    hipLaunchKernelGGL(rs_wgrad_reduce_kernel, dim3((n_el + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nslab, ntaps, CINp, COUTp, Co, Ci, dw);
+    hipLaunchKernelGGL(rs_wgrad_reduce_kernel, dim3((n_el + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nslab, ntaps, CINp, COUTp, Co, Ci, ld, dw);
     return scl_check_launch("rs_wgrad_reduce");
 }
 
-extern "C" int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, const SclRsGeom* geom, void* stream) {
+extern "C" int scl_rs_bn_act(const float* y, const float* stats, float* a, int C, int act, const SclRsGeom* geom, void* stream) {
     SCL_REQUIRE(y && stats && a && geom && C % 4 == 0, "rs_bn_act: bad arguments");
     RsGeom q;
     if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
     const long long n4 = (long long)q.G * (C / 4);
-    hipLaunchKernelGGL(rs_bn_act_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y, stats, a, C, q);
+    hipLaunchKernelGGL(rs_bn_act_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y, stats, a, C, act, q);
     return scl_check_launch("rs_bn_act");
 }
 
-extern "C" int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, const SclRsGeom* geom, void* stream) {
+extern "C" int scl_rs_bn_bwd_apply(float* dz, const float* y, const float* stats, const float* bstats, int C, int selu_in, const SclRsGeom* geom, void* stream) {
     SCL_REQUIRE(dz && y && stats && bstats && geom && C % 4 == 0, "rs_bn_bwd_apply: bad arguments");
     RsGeom q;
     if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
     const long long n4 = (long long)q.G * (C / 4);
-    hipLaunchKernelGGL(rs_bn_bwd_apply_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dz, y, stats, bstats, C, q);
+    hipLaunchKernelGGL(rs_bn_bwd_apply_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dz, y, stats, bstats, C, selu_in, q);
     return scl_check_launch("rs_bn_bwd_apply");
 }
 
@@ -675,4 +780,25 @@ extern "C" int scl_rs_copy(const float* src, float* dst, int Cs, int Cd, int to_
     const long long n = to_dense ? (long long)geom->B * H * q.W * Cd : (long long)q.G * Cd;
     hipLaunchKernelGGL(rs_copy_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, dst, Cs, Cd, H, to_dense ? 1 : 0, q);
     return scl_check_launch("rs_copy");
+}
+
+extern "C" int scl_rs_attn_pool_fwd(const float* x, const float* l, const float* pos, float* eS, float* eT, int C, const SclRsGeom* geom, void* stream) {
+    SCL_REQUIRE(x && l && eS && eT && geom && C % 4 == 0, "rs_attn_pool_fwd: bad arguments");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    const size_t lds = (size_t)2 * geom->H * geom->W * 16;
+    SCL_REQUIRE(lds <= 160 * 1024, "rs_attn_pool_fwd: map of %d x %d positions exceeds the LDS", geom->H, geom->W);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_attn_pool_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(rs_attn_pool_fwd_kernel, dim3(geom->B, C / 4), dim3(256), lds, (hipStream_t)stream, x, l, pos, eS, eT, C, geom->H, geom->W, q);
+    return scl_check_launch("rs_attn_pool_fwd");
+}
+extern "C" int scl_rs_attn_pool_bwd(const float* x, const float* l, const float* deS, const float* deT, float* dx, float* dl, int C, const SclRsGeom* geom, void* stream) {
+    SCL_REQUIRE(x && l && deS && deT && dx && dl && geom && C % 4 == 0, "rs_attn_pool_bwd: bad arguments");
+    RsGeom q;
+    if (!rs_fill_geom(*geom, &q)) return SCL_EINVAL;
+    const size_t lds = (size_t)4 * geom->H * geom->W * 8;
+    SCL_REQUIRE(lds <= 160 * 1024, "rs_attn_pool_bwd: map of %d x %d positions exceeds the LDS", geom->H, geom->W);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)rs_attn_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(rs_attn_pool_bwd_kernel, dim3(geom->B, C / 2), dim3(256), lds, (hipStream_t)stream, x, l, deS, deT, dx, dl, C, geom->H, geom->W, q);
+    return scl_check_launch("rs_attn_pool_bwd");
 }

@@ -43,14 +43,14 @@ class SclRsGeom(ctypes.Structure):
 
 class SclRsPackJob(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("Co", ctypes.c_int32), ("Ci", ctypes.c_int32), ("ntaps", ctypes.c_int32),
-                ("CINp", ctypes.c_int32), ("COUTp", ctypes.c_int32), ("transposed", ctypes.c_int32)]
+                ("CINp", ctypes.c_int32), ("COUTp", ctypes.c_int32), ("transposed", ctypes.c_int32), ("ld", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 class SclRsConv(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("inp", "wpk", "bias", "addend", "out", "act_a", "y1", "bnstats", "acc", "ticket", "gamma", "beta",
                                               "run_mean", "run_var", "nbt", "stats_out", "dgamma", "dbeta")] + \
                [("nvalid", ctypes.c_double), ("geom", SclRsGeom), ("shift", ctypes.c_int32 * 6), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
-                ("ntaps", ctypes.c_int32), ("stat_mode", ctypes.c_int32), ("training", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("ntaps", ctypes.c_int32), ("stat_mode", ctypes.c_int32), ("training", ctypes.c_int32), ("epi_act", ctypes.c_int32),
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
 
 
@@ -172,9 +172,11 @@ def _protos():
         "scl_rs_pack_weights": ([P(SclRsPackJob), _i32, _vp], _i32),
         "scl_rs_wgrad_nslabs": ([_i32, _i32], _i32),
         "scl_rs_wgrad": ([_vp, _vp, _i32, _i32, _i32, P(_i32), P(SclRsGeom), _vp, _vp, _vp, _vp, _vp], _i32),
-        "scl_rs_wgrad_reduce": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
-        "scl_rs_bn_act": ([_vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),
-        "scl_rs_bn_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),
+        "scl_rs_wgrad_reduce": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
+        "scl_rs_bn_act": ([_vp, _vp, _vp, _i32, _i32, P(SclRsGeom), _vp], _i32),
+        "scl_rs_bn_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, P(SclRsGeom), _vp], _i32),
+        "scl_rs_attn_pool_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),
+        "scl_rs_attn_pool_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, P(SclRsGeom), _vp], _i32),
         "scl_rs_bn_eval_stats": ([_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp], _i32),
         "scl_rs_copy": ([_vp, _vp, _i32, _i32, _i32, P(SclRsGeom), _vp], _i32),
         # graph.hip

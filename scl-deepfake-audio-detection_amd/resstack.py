@@ -91,6 +91,16 @@ class _Plan:
         """Pointer to flat position 0 of a bordered map with c channels."""
         return t.data_ptr() + 4 * self.slack * c
 
+    def attn_buffers(self):
+        """Maps and statistics of the attention block behind the stack (all 64 channels wide, the 128-channel middle as two planes)."""
+        if getattr(self, "at", None) is None:
+            z = lambda: torch.zeros((self.G + 2 * self.slack) * 64, device=self.dev)
+            f = lambda n: torch.zeros(n, device=self.dev)
+            self.at = dict(xa=z(), a1=[z(), z()], b1=[z(), z()], wl=z(), dxa=z(), dwl=z(), db1=[z(), z()], st_fb=f(256), st_a=[f(256), f(256)],
+                           bst_a=[f(128), f(128)], bst_fb=f(128), wpk=torch.empty(8 * 64 * 64, device=self.dev),
+                           job=(L.SclGraphReduceJob * 1)())
+        return self.at
+
 
 _PLANS = []
 
@@ -121,7 +131,8 @@ def _stream():
 
 
 def _conv(pl, inp, wpk, out, cin, cout, shifts, geom, *, bias=None, addend=None, stat_mode=0, nvalid=0.0, act_a=None, y1=None, bnstats=None,
-          gamma=None, beta=None, run_mean=None, run_var=None, nbt=None, stats_out=None, dgamma=None, dbeta=None, training=True, eps=1e-5, momentum=0.1):
+          gamma=None, beta=None, run_mean=None, run_var=None, nbt=None, stats_out=None, dgamma=None, dbeta=None, training=True, eps=1e-5, momentum=0.1,
+          epi_act=0):
     d = L.SclRsConv()
     d.inp, d.wpk, d.out = inp, wpk, out
     pt = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
@@ -134,7 +145,7 @@ def _conv(pl, inp, wpk, out, cin, cout, shifts, geom, *, bias=None, addend=None,
     for i, s in enumerate(shifts):
         d.shift[i] = s
     d.cin, d.cout, d.ntaps, d.stat_mode, d.training = cin, cout, len(shifts), stat_mode, 1 if training else 0
-    d.eps, d.momentum = eps, momentum
+    d.eps, d.momentum, d.epi_act = eps, momentum, epi_act
     ops._call("scl_rs_conv", ctypes.byref(d), _stream(), keep=d)
 
 
@@ -178,16 +189,20 @@ def _signature(blocks, training):
             _grad(blocks[-1].bn2.bias).data_ptr(), blocks[-1].bn2.running_mean.data_ptr())
 
 
-def _forward(pl, x0, blocks, training):
+def _forward(pl, x0, blocks, training, attn=None):
     """The first call of a (plan, parameter storage, mode) runs the launch sequence while ops records it; later calls patch the input /
     output pointers and replay the recorded C calls."""
     B, H, W = pl.B, pl.H, pl.W
     S = _stream
     c_last = pl.cps[-1]
-    out = torch.empty(B, H, W, c_last, device=pl.dev)
-    sig = _signature(blocks, training)
+    out = torch.empty(B, H, W, c_last, device=pl.dev) if attn is None else (torch.empty(B, H, c_last, device=pl.dev), torch.empty(B, W, c_last, device=pl.dev))
+    sig = _signature(blocks, training) + ((id(attn[0]), attn[2].data_ptr(), _grad(attn[2]).data_ptr(), _grad(attn[1][0].weight).data_ptr()) if attn is not None else ())
     if pl.sig == sig and pl.fwd_calls is not None:
-        pl.in_entry[1][0], pl.out_entry[1][1] = x0.data_ptr(), out.data_ptr()
+        pl.in_entry[1][0] = x0.data_ptr()
+        if attn is None:
+            pl.out_entry[1][1] = out.data_ptr()
+        else:
+            pl.pool_entry[1][3], pl.pool_entry[1][4] = out[0].data_ptr(), out[1].data_ptr()
         pl.live = (x0, out)
         ops.replay(pl.fwd_calls)
         return out
@@ -210,7 +225,7 @@ def _forward(pl, x0, blocks, training):
             _conv(pl, xin, wv[(i, "c1")], y1, ci, co, pl.s1, pl.gy, bias=blk.conv1.bias)
             ops._call("scl_rs_bn_eval_stats", bn2.weight.data_ptr(), bn2.bias.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(),
                       float(bn2.eps), co, pl.stats[i].data_ptr(), S())
-        ops._call("scl_rs_bn_act", y1, pl.stats[i].data_ptr(), a, co, ctypes.byref(pl.gy), S())
+        ops._call("scl_rs_bn_act", y1, pl.stats[i].data_ptr(), a, co, 1, ctypes.byref(pl.gy), S())
         if blk.downsample:
             tmp = pl.p(pl.tmp, co)
             _conv(pl, xin, wv[(i, "ds")], tmp, ci, co, pl.sd, pl.gx, bias=blk.conv_downsample.bias)
@@ -222,33 +237,120 @@ def _forward(pl, x0, blocks, training):
             bn1 = nxt.bn1
             _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend, stat_mode=1, nvalid=n_x,
                   run_mean=bn1.running_mean, run_var=bn1.running_var, nbt=bn1.num_batches_tracked, **_bn_args(bn1))
+        elif training and nxt is None and attn is not None:      # first_bn1 (model/wav2vec2_aasist.py:520) reads the stack output: its statistics ride here
+            fb1 = attn[0]
+            _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend, stat_mode=1, nvalid=n_x, gamma=fb1.weight, beta=fb1.bias,
+                  run_mean=fb1.running_mean, run_var=fb1.running_var, nbt=fb1.num_batches_tracked, stats_out=pl.attn_buffers()["st_fb"], **_bn_args(fb1))
         else:
             _conv(pl, a, wv[(i, "c2")], xout, co, co, pl.s2, pl.gx, bias=blk.conv2.bias, addend=addend)
-    pl.out_entry = ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S())
+    if attn is None:
+        pl.out_entry = ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S())
+    else:
+        _attn_forward(pl, attn, training, out)
     pl.live = (x0, out)
     if record:
         pl.fwd_calls = ops.stop_recording()
     return out
 
 
-def _wgrad(pl, inp, dout, cin, cout, shifts, w, bias, co_real, ci_real):
+def _attn_pack(pl, attn):
+    """Register images of the two 1x1 convolutions of the attention block, as 64 -> 64 planes: W1 [128, 64] by output rows, W3 [64, 128]
+    by input columns; forward and data-gradient images."""
+    at = pl.attn_buffers()
+    w1, w3 = attn[1][0].weight, attn[1][3].weight
+    arr = (L.SclRsPackJob * 8)()
+    views = {}
+    k = 0
+    for p in range(2):
+        for name, w, off, ld, tr in (("w1", w1, 64 * 64 * p, 64, 0), ("w1T", w1, 64 * 64 * p, 64, 1), ("w3", w3, 64 * p, 128, 0), ("w3T", w3, 64 * p, 128, 1)):
+            dst = at["wpk"].data_ptr() + 4 * k * 64 * 64
+            arr[k] = L.SclRsPackJob(w.data_ptr() + 4 * off, dst, 64, 64, 1, 64, 64, tr, ld, 0)
+            views[(name, p)] = dst
+            k += 1
+    ops._call("scl_rs_pack_weights", arr, 8, _stream(), keep=arr)
+    return views
+
+
+def _attn_forward(pl, attn, training, out):
+    """first_bn1 + SELU, attention = conv(64 -> 128) -> SELU -> BatchNorm(128) -> conv(128 -> 64), the two soft-max poolings (+ pos_S)
+    (model/wav2vec2_aasist.py:520-541) on the bordered maps; out = (e_S, e_T)."""
+    fb1, (a0, bnA, a3), pos_S = attn[0], (attn[1][0], attn[1][2], attn[1][3]), attn[2]
+    B, H, W = pl.B, pl.H, pl.W
+    S = _stream
+    at = pl.attn_buffers()
+    wv = _attn_pack(pl, attn)
+    pl.awv = wv
+    n_x = float(B * H * W)
+    P = lambda t: pl.p(t, 64)
+    x6 = P(pl.x[-1])
+    if not training:
+        ops._call("scl_rs_bn_eval_stats", fb1.weight.data_ptr(), fb1.bias.data_ptr(), fb1.running_mean.data_ptr(), fb1.running_var.data_ptr(), float(fb1.eps), 64,
+                  at["st_fb"].data_ptr(), S())
+    ops._call("scl_rs_bn_act", x6, at["st_fb"].data_ptr(), P(at["xa"]), 64, 1, ctypes.byref(pl.gx), S())
+    for p in range(2):
+        o = 4 * 64 * p
+        if training:
+            _conv(pl, P(at["xa"]), wv[("w1", p)], P(at["a1"][p]), 64, 64, [0], pl.gx, bias=a0.bias.data_ptr() + o, stat_mode=1, nvalid=n_x,
+                  gamma=bnA.weight.data_ptr() + o, beta=bnA.bias.data_ptr() + o, run_mean=bnA.running_mean.data_ptr() + o, run_var=bnA.running_var.data_ptr() + o,
+                  nbt=bnA.num_batches_tracked if p == 0 else None, stats_out=at["st_a"][p], epi_act=1, **_bn_args(bnA))
+        else:
+            _conv(pl, P(at["xa"]), wv[("w1", p)], P(at["a1"][p]), 64, 64, [0], pl.gx, bias=a0.bias.data_ptr() + o, epi_act=1)
+            ops._call("scl_rs_bn_eval_stats", bnA.weight.data_ptr() + o, bnA.bias.data_ptr() + o, bnA.running_mean.data_ptr() + o, bnA.running_var.data_ptr() + o,
+                      float(bnA.eps), 64, at["st_a"][p].data_ptr(), S())
+        ops._call("scl_rs_bn_act", P(at["a1"][p]), at["st_a"][p].data_ptr(), P(at["b1"][p]), 64, 0, ctypes.byref(pl.gx), S())
+    _conv(pl, P(at["b1"][0]), wv[("w3", 0)], P(at["wl"]), 64, 64, [0], pl.gx, bias=a3.bias)
+    _conv(pl, P(at["b1"][1]), wv[("w3", 1)], P(at["wl"]), 64, 64, [0], pl.gx, addend=P(at["wl"]))
+    pl.pool_entry = ops._call("scl_rs_attn_pool_fwd", P(at["xa"]), P(at["wl"]), pos_S.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), 64, ctypes.byref(pl.gx), S())
+
+
+def _attn_backward(pl, attn, training, deS, deT):
+    """Gradients of the attention block and of first_bn1 + SELU; leaves d(stack output) in pl.dx[-1]."""
+    fb1, (a0, bnA, a3), pos_S = attn[0], (attn[1][0], attn[1][2], attn[1][3]), attn[2]
+    B, H, W = pl.B, pl.H, pl.W
+    S = _stream
+    at, wv = pl.at, pl.awv
+    n_x = float(B * H * W)
+    P = lambda t: pl.p(t, 64)
+    x6, dz6 = P(pl.x[-1]), P(pl.dx[-1])
+    pl.poolb_entry = ops._call("scl_rs_attn_pool_bwd", P(at["xa"]), P(at["wl"]), deS.data_ptr(), deT.data_ptr(), P(at["dxa"]), P(at["dwl"]), 64, ctypes.byref(pl.gx), S())
+    job = at["job"]
+    job[0] = L.SclGraphReduceJob(deS.data_ptr(), _grad(pos_S).data_ptr(), H * 64, H * 64, B)      # d pos_S = sum_b d e_S
+    ops._call("scl_graph_reduce", job, 1, S(), keep=job)
+    for p in range(2):
+        o = 4 * 64 * p
+        _conv(pl, P(at["dwl"]), wv[("w3T", p)], P(at["db1"][p]), 64, 64, [0], pl.gx, stat_mode=2, nvalid=n_x, y1=P(at["a1"][p]), bnstats=at["st_a"][p],
+              dgamma=_grad(bnA.weight).data_ptr() + o, dbeta=_grad(bnA.bias).data_ptr() + o, stats_out=at["bst_a"][p], training=training)
+        _wgrad(pl, P(at["b1"][p]), P(at["dwl"]), 64, 64, [0], a3.weight, a3.bias if p == 0 else None, 64, 64, ld=128, w_off=64 * p)
+        ops._call("scl_rs_bn_bwd_apply", P(at["db1"][p]), P(at["a1"][p]), at["st_a"][p].data_ptr(), at["bst_a"][p].data_ptr(), 64, 1, ctypes.byref(pl.gx), S())
+        _wgrad(pl, P(at["xa"]), P(at["db1"][p]), 64, 64, [0], a0.weight, a0.bias, 64, 64, ld=64, w_off=64 * 64 * p, bias_off=64 * p)
+    _conv(pl, P(at["db1"][0]), wv[("w1T", 0)], dz6, 64, 64, [0], pl.gx, addend=P(at["dxa"]))
+    _conv(pl, P(at["db1"][1]), wv[("w1T", 1)], dz6, 64, 64, [0], pl.gx, addend=dz6, stat_mode=2, nvalid=n_x, act_a=P(at["xa"]), y1=x6, bnstats=at["st_fb"],
+          dgamma=_grad(fb1.weight), dbeta=_grad(fb1.bias), stats_out=at["bst_fb"], training=training)
+    ops._call("scl_rs_bn_bwd_apply", dz6, x6, at["st_fb"].data_ptr(), at["bst_fb"].data_ptr(), 64, 0, ctypes.byref(pl.gx), S())
+
+
+def _wgrad(pl, inp, dout, cin, cout, shifts, w, bias, co_real, ci_real, ld=0, w_off=0, bias_off=0):
     arr = (ctypes.c_int32 * 6)(*(list(shifts) + [0] * (6 - len(shifts))))
     nslab = L.load().scl_rs_wgrad_nslabs(cin, cout)
     ops._call("scl_rs_wgrad", inp, dout, cin, cout, len(shifts), arr, ctypes.byref(pl.gx), pl.part.data_ptr(), pl.acc.data_ptr(), pl.ticket.data_ptr(),
-              _grad(bias).data_ptr(), _stream(), keep=arr)
-    ops._call("scl_rs_wgrad_reduce", pl.part.data_ptr(), nslab, len(shifts), cin, cout, co_real, ci_real, _grad(w).data_ptr(), _stream())
+              None if bias is None else _grad(bias).data_ptr() + 4 * bias_off, _stream(), keep=arr)
+    ops._call("scl_rs_wgrad_reduce", pl.part.data_ptr(), nslab, len(shifts), cin, cout, co_real, ci_real, ld, _grad(w).data_ptr() + 4 * w_off, _stream())
 
 
-def _backward(pl, d_out, blocks, training, need_dx0):
+def _backward(pl, d_out, blocks, training, need_dx0, attn=None):
     B, H, W = pl.B, pl.H, pl.W
     S = _stream
     wv = pl.wv
     c_last = pl.cps[-1]
     n_y = float(B * (H + 1) * W)
-    d_out = d_out.contiguous().float()
+    d_out = d_out.contiguous().float() if attn is None else (d_out[0].contiguous().float(), d_out[1].contiguous().float())
     dx0 = torch.empty(B, H, W, 1, device=pl.dev) if need_dx0 else None
-    if pl.bwd_calls is not None and pl.bwd_need == need_dx0 and pl.sig == _signature(blocks, training):
-        pl.din_entry[1][0] = d_out.data_ptr()
+    if pl.bwd_calls is not None and pl.bwd_need == need_dx0 and pl.sig[: len(_signature(blocks, training))] == _signature(blocks, training):
+        if attn is None:
+            pl.din_entry[1][0] = d_out.data_ptr()
+        else:
+            pl.poolb_entry[1][2], pl.poolb_entry[1][3] = d_out[0].data_ptr(), d_out[1].data_ptr()
+            pl.at["job"][0].src = d_out[0].data_ptr()
         if need_dx0:
             pl.dout_entry[1][1] = dx0.data_ptr()
         pl.live_b = (d_out, dx0)
@@ -257,7 +359,10 @@ def _backward(pl, d_out, blocks, training, need_dx0):
     record = ops._rec() is None and pl.fwd_calls is not None
     if record:
         ops.start_recording()
-    pl.din_entry = ops._call("scl_rs_copy", d_out.data_ptr(), pl.p(pl.dx[-1], c_last), c_last, c_last, 0, ctypes.byref(pl.gx), S())
+    if attn is None:
+        pl.din_entry = ops._call("scl_rs_copy", d_out.data_ptr(), pl.p(pl.dx[-1], c_last), c_last, c_last, 0, ctypes.byref(pl.gx), S())
+    else:
+        _attn_backward(pl, attn, training, d_out[0], d_out[1])
     neg = lambda s: [-v for v in s]
     for i in reversed(range(len(blocks))):
         blk = blocks[i]
@@ -269,7 +374,7 @@ def _backward(pl, d_out, blocks, training, need_dx0):
         # conv2 data gradient x selu'(a) -> dz, its two batch sums -> dgamma / dbeta / the means of the BatchNorm backward
         _conv(pl, dcur, wv[(i, "c2T")], dz, co, co, neg(pl.s2), pl.gy, stat_mode=2, nvalid=n_y, act_a=a, y1=y1, bnstats=pl.stats[i],
               dgamma=_grad(bn2.weight), dbeta=_grad(bn2.bias), stats_out=pl.bstats, training=training)
-        ops._call("scl_rs_bn_bwd_apply", dz, y1, pl.stats[i].data_ptr(), pl.bstats.data_ptr(), co, ctypes.byref(pl.gy), S())      # dz is now d(conv1 output)
+        ops._call("scl_rs_bn_bwd_apply", dz, y1, pl.stats[i].data_ptr(), pl.bstats.data_ptr(), co, 0, ctypes.byref(pl.gy), S())      # dz is now d(conv1 output)
         _wgrad(pl, a, dcur, co, co, pl.s2, blk.conv2.weight, blk.conv2.bias, co, co)
         _wgrad(pl, xin, dz, ci, co, pl.s1, blk.conv1.weight, blk.conv1.bias, co, ci_real)
         if blk.downsample:
@@ -309,6 +414,45 @@ class _ResStackFn(torch.autograd.Function):
         finally:
             pl.busy = False
         return (dx0, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)      # parameter gradients were accumulated into p.grad by the kernels
+
+
+class _StackPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, blocks, attn, training, hold, *params):
+        B, H, W, _ = x0.shape
+        chans = [blocks[0].conv1.weight.shape[1]] + [b.conv1.weight.shape[0] for b in blocks]
+        pl = _acquire(B, H, W, chans, x0.device, hold)
+        e_S, e_T = _forward(pl, x0.contiguous().float(), blocks, training, attn)
+        ctx.pl, ctx.blocks, ctx.training, ctx.attn = pl, blocks, training, attn
+        return e_S, e_T
+
+    @staticmethod
+    def backward(ctx, deS, deT):
+        pl = ctx.pl
+        try:
+            dx0 = _backward(pl, (deS, deT), ctx.blocks, ctx.training, ctx.needs_input_grad[0], ctx.attn)
+        finally:
+            pl.busy = False
+        return (dx0, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+def attn_supported(first_bn1, attention, pos_S, c_last):
+    try:
+        return (c_last == 64 and tuple(attention[0].weight.shape) == (128, 64, 1, 1) and tuple(attention[3].weight.shape) == (64, 128, 1, 1)
+                and attention[2].weight.shape[0] == 128 and first_bn1.weight.shape[0] == 64 and pos_S.shape[-1] == 64)
+    except (AttributeError, IndexError):
+        return False
+
+
+def res_stack_pool(x0, blocks, first_bn1, attention, pos_S):
+    """The stack, first_bn1 + SELU, the attention block and the two attention poolings as one node:
+    x0 [B, H, W, 1] -> (e_S [B, H, 64] (pos_S added), e_T [B, W, 64])."""
+    blocks = list(blocks)
+    training = bool(blocks[0].training)
+    attn = (first_bn1, attention, pos_S)
+    params = [p for b in blocks for p in b.parameters()] + list(first_bn1.parameters()) + list(attention.parameters()) + [pos_S]
+    hold = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in params))
+    return _StackPoolFn.apply(x0, blocks, attn, training, hold, *params)
 
 
 def res_stack(x0, blocks):

@@ -256,7 +256,7 @@ def test_rs_wgrad_kernel_against_the_flat_shift_definition(cin, cout, nt):
     off = lambda t, c: t.data_ptr() + 4 * slack * c
     for rep in range(2):
         assert lib.scl_rs_wgrad(off(d_in, cin), off(d_dout, cout), cin, cout, nt, arr, ctypes.byref(geom), part.data_ptr(), acc.data_ptr(), ticket.data_ptr(), dbias.data_ptr(), st) == 0
-        assert lib.scl_rs_wgrad_reduce(part.data_ptr(), nsl, nt, cin, cout, cout, ci_real, dw.data_ptr(), st) == 0
+        assert lib.scl_rs_wgrad_reduce(part.data_ptr(), nsl, nt, cin, cout, cout, ci_real, 0, dw.data_ptr(), st) == 0
     torch.cuda.synchronize()
     do64 = dout.double()[slack:slack + G]
     ref = torch.stack([xin.double()[slack + s: slack + s + G].t() @ do64 for s in shifts])      # [t][c][n]

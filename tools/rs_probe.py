@@ -87,7 +87,7 @@ def run(lib, tag, B=64, H=42, W=66, cin=64, cout=64, nt=6, reps=30):
         dw = torch.zeros(cout * cin * nt, device=dev)
         e0.record()
         for _ in range(reps):
-            lib.scl_rs_wgrad_reduce(part.data_ptr(), nsl, nt, cin, cout, cout, cin, dw.data_ptr(), st)
+            lib.scl_rs_wgrad_reduce(part.data_ptr(), nsl, nt, cin, cout, cout, cin, 0, dw.data_ptr(), st)
         e1.record()
         torch.cuda.synchronize()
         print("%-14s wgrad reduce %d slabs %21.1f us" % (tag, nsl, e0.elapsed_time(e1) * 1e3 / reps))
