@@ -328,6 +328,10 @@ int scl_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int H, in
                  void* stream);
 /* bias_part (optional, f32 [B, 3*H*64]): per-utterance column sums of dqkv, from the f32 accumulators — summed over B (scl_colreduce_f32)
  * they are the q/k/v bias gradients, which otherwise cost a pass over dqkv. */
+/* fp8 variant of the forward (BASELINE.json configs[4]): K, V, Q and the probabilities as OCP e4m3 operands of v_mfma_f32_16x16x32_fp8_fp8,
+ * fp32 accumulation and soft-max statistics; same arguments and outputs as scl_attn_fwd without dropout.  Opt-in (SCL_ATTN_FP8=1: the
+ * encoder's no-grad bf16 forward); 6e-2 relative L2 of ctx against the fp32 arithmetic of the reference. */
+int scl_attn_fwd_fp8(const void* qkv, void* ctx, float* lse, int B, int T, int H, int D, float scale, void* stream);
 int scl_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, float* bias_part, int B, int T,
                  int H, int D, float scale, float drop_p, uint32_t drop_seed, void* stream);
 

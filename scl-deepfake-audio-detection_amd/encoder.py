@@ -37,6 +37,9 @@ POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
 # epilogue multiplies by the stored number; 0 = store the pre-activation and re-evaluate gelu' in the backward epilogue (rounds 1-2)
 GELU_DC2 = os.environ.get("SCL_GELU_DC2", "1") != "0"
+# BASELINE.json configs[4] names fp8 attention: csrc/attention_fp8.hip (e4m3 operands, fp32 accumulation) for the no-grad bf16 forward.  Opt-in:
+# the reference is fp32 and the fused forward is bound by its soft-max VALU work, not by the matrix pipe (profiles/r4_attn_fp8_probe.txt).
+ATTN_FP8 = os.environ.get("SCL_ATTN_FP8", "0") == "1"
 CONV_WGRAD_WIDE = os.environ.get("SCL_CONV_WGRAD_WIDE", "1") != "0"
 
 
@@ -412,7 +415,9 @@ class Encoder:
             ops.gemm(Op(d["h1"][n], E), self.W(pn + "self_attn.q_proj.weight", E), d["qkv"][n], M, 3 * E, E,
                      bias=self.b(pn + "self_attn.q_proj.bias"))  # q,k,v biases are adjacent in the flat buffer
             qkv = d["qkv"][n]
-            if d["fused_attn"]:
+            if d["fused_attn"] and ATTN_FP8 and not training and T <= 256:
+                ops.attn_fwd_fp8(qkv, d["ctx"][n], d["lse"][n], B, T, H, D, D ** -0.5)      # configs[4]'s fp8 attention (opt-in, no-grad forward)
+            elif d["fused_attn"]:
                 e = ops.attn_fwd(qkv, d["ctx"][n], d["lse"][n], B, T, H, D, D ** -0.5, drop_p=p_attn, drop_seed=sseed(n, self.SITE_ATTN))
                 if p_attn > 0:
                     self._slot(slots, e, ops.ATTN_FWD_SEED, n, self.SITE_ATTN)

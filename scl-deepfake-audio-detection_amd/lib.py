@@ -156,6 +156,7 @@ def _protos():
         "scl_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_softmax_fwd_f32": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
         "scl_attn_fwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp], _i32),
+        "scl_attn_fwd_fp8": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp], _i32),
         # conv0.hip
         "scl_conv0_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),

@@ -410,6 +410,11 @@ def attn_fwd(qkv, ctx, lse, B, T, H, D, scale, drop_p=0.0, drop_seed=0):
     return _call("scl_attn_fwd", _p(qkv), _p(ctx), _p(lse), B, T, H, D, scale, float(drop_p), int(drop_seed), _stream())
 
 
+def attn_fwd_fp8(qkv, ctx, lse, B, T, H, D, scale):
+    """fp8 (e4m3) operands, fp32 accumulation: the configs[4] variant of the fused attention forward (no dropout)."""
+    return _call("scl_attn_fwd_fp8", _p(qkv), _p(ctx), _p(lse), B, T, H, D, float(scale), _stream())
+
+
 def attn_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, scale, bias_part=None, drop_p=0.0, drop_seed=0):
     """bias_part: optional f32 [B, 3*H*D] — per-utterance column sums of dqkv (colreduce over B gives the q/k/v bias gradients)."""
     return _call("scl_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(bias_part), B, T, H, D, scale, float(drop_p), int(drop_seed), _stream())

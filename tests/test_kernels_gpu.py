@@ -357,6 +357,28 @@ def test_fused_attention_fwd_bwd(dev, B, T, H):
     assert rel(part, exact) < 2.5e-2
 
 
+@pytest.mark.parametrize("B,T,H", [(2, 199, 3), (1, 201, 2), (3, 49, 2), (2, 16, 1), (1, 256, 1), (2, 208, 16)])
+def test_fp8_attention_forward_against_fp32(dev, B, T, H):
+    """scl_attn_fwd_fp8 (BASELINE.json configs[4]: K, V, Q and the probabilities as e4m3 MFMA operands, fp32 accumulation) against fp32
+    soft-max attention on the same q, k, v: 6e-2 relative L2 on the context (e4m3 carries 3 mantissa bits: 2^-4 per operand element,
+    averaged over the 64-deep and T-deep contractions), 2e-2 absolute on the row log-sum-exp; and within 6e-2 of the bf16 kernel."""
+    D, E = 64, H * 64
+    qkv = (0.7 * torch.randn(B, T, 3, H, D, generator=g(11))).to(torch.bfloat16).to(dev)
+    ctx = torch.full((B, T, E), float("nan"), dtype=torch.bfloat16, device=dev)
+    lse = torch.full((B, H, T), float("nan"), device=dev)
+    scale = D ** -0.5
+    ops.attn_fwd_fp8(qkv, ctx, lse, B, T, H, D, scale)
+    q, k, v = (qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * scale
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, T, E)
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse).all()
+    assert rel(ctx, ref) < 6e-2, rel(ctx, ref)
+    assert float((lse - torch.logsumexp(s, -1)).abs().max()) < 2e-2
+    ctx16 = torch.empty_like(ctx); lse16 = torch.empty_like(lse)
+    ops.attn_fwd(qkv, ctx16, lse16, B, T, H, D, scale)
+    assert rel(ctx, ctx16.float()) < 6e-2
+
+
 @pytest.mark.parametrize("B,T,K,G", [(3, 199, 128, 16), (2, 208, 128, 2), (2, 49, 128, 16), (1, 7, 16, 1), (2, 100, 32, 3)])
 def test_posconv_mfma_equals_the_grouped_gemm(dev, B, T, K, G):
     """csrc/posconv.hip (utterance slab resident in LDS, weights streamed tap by tap) against the same contraction through
