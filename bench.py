@@ -267,17 +267,19 @@ def main():
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # HBM traffic per GEMM launch cannot be read live (PMC needs rocprofv3): take it from the committed counter pass of this
-    # same command (profiles/r3_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
+    # same command (profiles/r4_pmc_hbm_traffic.json, or the previous round's; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
     # while the GEMM sources are the ones that pass was taken with (its "gemm_src_sha"), else null
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")) as f:
-            pmc = json.load(f)
-        if (B == pmc.get("batch", 32) and L == 64000 and not args.tiny and args.model == "wav2vec2_linear_nll"
-                and pmc.get("gemm_src_sha") == gemm_source_sha()):
-            traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    for tag in ("r4", "r3"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)) as f:
+                pmc = json.load(f)
+            if (B == pmc.get("batch", 32) and L == 64000 and not args.tiny and args.model == "wav2vec2_linear_nll"
+                    and pmc.get("gemm_src_sha") == gemm_source_sha()):
+                traffic = (2.0 * pmc["FETCH_SIZE"]["gemm"][0] + pmc["WRITE_SIZE"]["gemm"][0]) * 1024.0
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     res = {
         "metric": "train-step utterances/sec (64000-sample clips)", "value": utt_s, "unit": "utterances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -41,15 +41,41 @@ def gen_notch_coeffs(nBands, minF, maxF, minBW, maxBW, minCoeff, maxCoeff, minG,
     return np.asarray(pow(10, G / 20) * b / np.amax(np.abs(h)), dtype=np.float64).ravel()
 
 
+def _draw_notch_params(nBands, minF, maxF, minBW, maxBW, minCoeff, maxCoeff, minG, maxG):
+    """The random draws of genNotchCoeffs (RawBoost.py:25-47) in its order — per band fc, bw, c, then G — without the filter design."""
+    fc, bw, c = np.empty(nBands), np.empty(nBands), np.empty(nBands, dtype=np.int64)
+    for k in range(nBands):
+        fc[k] = _rand_range(minF, maxF, 0)[0]
+        bw[k] = _rand_range(minBW, maxBW, 0)[0]
+        ck = _rand_range(minCoeff, maxCoeff, 1)
+        c[k] = ck + 1 if ck / 2 == int(ck / 2) else ck
+    G = _rand_range(minG, maxG, 0)[0]
+    return fc, bw, c, G
+
+
+# SCL_RAWBOOST_SCIPY=1: design every notch filter with scipy.signal.firwin / np.convolve / freqz exactly as the reference does (one call
+# chain per band: 100 firwin calls per 11-view pack = 40 % of the pack builder's host time, profiles/r4_pack_builder.txt).  Default: the
+# same draws in the same order, the filters of a clip designed at once in closed form (design_notch_filters: tests/test_host_cpu.py pins
+# it to the scipy chain at 1e-12; the RawBoost goldens hold at their 3e-5 bar either way).
+_SCIPY_DESIGN = __import__("os").environ.get("SCL_RAWBOOST_SCIPY", "0") == "1"
+
+
 def _draw_lnl(a, fs):
     taps = []
     minG, maxG = a.minG, a.maxG
+    draws = []
     for i in range(a.N_f):
         if i == 1:
             minG = minG - a.minBiasLinNonLin
             maxG = maxG - a.maxBiasLinNonLin
-        taps.append(gen_notch_coeffs(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, minG, maxG, fs))
-    return taps
+        if _SCIPY_DESIGN:
+            taps.append(gen_notch_coeffs(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, minG, maxG, fs))
+        else:
+            draws.append(_draw_notch_params(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, minG, maxG))
+    if _SCIPY_DESIGN:
+        return taps
+    return design_notch_filters(np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws]), np.stack([d[2] for d in draws]),
+                                np.array([d[3] for d in draws]), fs)
 
 
 def _draw_isd(a, L):
@@ -62,7 +88,11 @@ def _draw_isd(a, L):
 
 def _draw_ssi(a, L, fs):
     noise = np.random.normal(0, 1, L)
-    b = gen_notch_coeffs(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, a.minG, a.maxG, fs)
+    if _SCIPY_DESIGN:
+        b = gen_notch_coeffs(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, a.minG, a.maxG, fs)
+    else:
+        fc, bw, c, G = _draw_notch_params(a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, a.minG, a.maxG)
+        b = design_notch_filters(fc[None], bw[None], c[None], np.array([G]), fs)[0]
     snr = _rand_range(a.SNRmin, a.SNRmax, 0)
     return noise.astype(np.float32), b, float(snr[0])
 

@@ -14,14 +14,26 @@ def write_wav(path, x, sr=16000):
         w.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
 
 
+def write_flac(path, x, sr=16000):
+    """The corpus files are FLAC (ASVspoof 2019 LA): through tests/flac_writer.py, so that the pack builder's own decoder (csrc/flac.hip) is on the clock."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import flac_writer
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    pcm = (np.clip(x, -1, 1) * 32767).astype(np.int64)
+    with open(path, "wb") as f:
+        f.write(flac_writer.write_flac(pcm, sample_rate=sr, bps=16))
+
+
 tmp = tempfile.mkdtemp()
 root = os.path.join(tmp, "data") + "/"
 rs = np.random.RandomState(0)
-ids = ["u%d.wav" % i for i in range(8)]
+EXT = os.environ.get("PACK_EXT", "flac")
+ids = ["u%d.%s" % (i, EXT) for i in range(8)]
+wr = write_flac if EXT == "flac" else write_wav
 for u in ids:
-    write_wav(os.path.join(root, "bonafide", u), 0.1 * rs.randn(70000 + 3000 * int(u[1])))
+    wr(os.path.join(root, "bonafide", u), 0.1 * rs.randn(70000 + 3000 * int(u[1])))
     for v in ("hifigan", "hn-sinc-nsf-hifi", "waveglow"):
-        write_wav(os.path.join(root, "vocoded", v + "_" + u), 0.1 * rs.randn(66000))
+        wr(os.path.join(root, "vocoded", v + "_" + u), 0.1 * rs.randn(66000))
 for i in range(4):
     write_wav(os.path.join(root, "musan", "n%d.wav" % i), 0.05 * rs.randn(160000))
     write_wav(os.path.join(root, "rirs", "r%d.wav" % i), np.exp(-np.arange(8000) / 1200.0) * rs.randn(8000) * 0.3)
