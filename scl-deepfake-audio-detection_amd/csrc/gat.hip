@@ -204,6 +204,206 @@ __global__ void gat_dx_kernel(const float* __restrict__ dP, const float* __restr
     if (jl == 0) dx[((int64_t)b * N + i) * D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
 }
 
+// ---- matrix-core forms (D in {32, 64}, Do in {32, 64}) ----------------------------------------------------------------------------------
+// The pre-activation of a pair is a [pairs x D] x [D x Do] product whose left operand is formed on the fly (x_i * x_j): on
+// v_mfma_f32_16x16x4_f32 (exact fp32) a wave takes one node i and 16 nodes j at a time — rows = the 16 pairs, k = the feature index,
+// columns = 16 outputs — with the whole of W in registers (Do * D / 64 per lane, loaded once per block), so the N * N * D * Do
+// multiply-adds leave the vector ALU, which keeps the N * N * Do tanh evaluations.  Backward, per 16 pairs: the same pre-activations
+// again, then dW += dpre^T p (rows = outputs, k = pairs: the accumulators of the first product ARE the left operand) into Do * D / 64
+// accumulators per lane that live for the whole block, and dp^T = W^T dpre^T after one trip of the dpre tile through LDS (the only
+// transposition); dP goes to HBM for gat_dx_kernel as before.  Blocks = scl_gat_score_nblocks(N) per graph, nodes i dealt out evenly,
+// so the partial-sum layout the callers reduce is unchanged.
+template <int D>
+__device__ __forceinline__ void gat_stage_x(float* xs, const float* __restrict__ xb, int N) {      // [N + 16][D + 1], rows >= N zero
+    for (int e = threadIdx.x; e < (N + 16) * D; e += GAT_PAIRS) { const int r = e / D, d = e - r * D; xs[r * (D + 1) + d] = r < N ? xb[e] : 0.f; }
+}
+
+template <int D, int Do>
+__global__ __launch_bounds__(GAT_PAIRS, 1) void gat_score_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                         const float* __restrict__ bias, const float* __restrict__ a,
+                                                                         float* __restrict__ s, int N, int n1) {
+    constexpr int NS = D / 4, NOB = Do / 16, XP = D + 1;
+    extern __shared__ float sm[];
+    float* xs = sm;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    gat_stage_x<D>(xs, x + (int64_t)b * N * D, N);
+    float wr[NOB][NS], bo[NOB], av[3][NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * ob + li;
+        bo[ob] = bias[o];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) av[t][ob] = a[t * Do + o];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) wr[ob][k] = W[(size_t)o * D + 4 * k + g];
+    }
+    __syncthreads();
+    const int nblk = gridDim.x, ipb = (N + nblk - 1) / nblk;
+    const int i0 = blockIdx.x * ipb, i1 = min(N, i0 + ipb), njb = (N + 15) / 16;
+    for (int u = wave; u < (i1 - i0) * njb; u += GAT_PAIRS / 64) {
+        const int i = i0 + u / njb, j0 = (u % njb) * 16;
+        f32x4 acc[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float pv = xs[i * XP + 4 * k + g] * xs[(j0 + li) * XP + 4 * k + g];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, wr[ob][k], acc[ob], 0, 0, 0);
+        }
+        float sc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * g + r;
+            const int ty = gat_type(i, j < N ? j : 0, n1);
+            float v = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) v += gat_tanh(acc[ob][r] + bo[ob]) * (ty == 0 ? av[0][ob] : (ty == 1 ? av[1][ob] : av[2][ob]));
+            sc[r] = lanes16_sum(v);
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int j = j0 + 4 * g + r; if (j < N) s[((int64_t)b * N + i) * N + j] = sc[r]; }
+        }
+    }
+}
+
+template <int D, int Do>
+__global__ __launch_bounds__(GAT_PAIRS, 1) void gat_score_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                         const float* __restrict__ bias, const float* __restrict__ a,
+                                                                         const float* __restrict__ ds, float* __restrict__ dP,
+                                                                         float* __restrict__ part, int N, int n1) {
+    constexpr int NS = D / 4, NOB = Do / 16, NDB = D / 16, NSO = Do / 4, XP = D + 1, TP = Do + 1;
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    float* xs = sm;                                        // [N + 16][XP]
+    float* Tw = sm + (N + 16) * XP + wave * 16 * TP;       // this wave's dpre tile [16 pairs][TP]
+    float* red = sm + (N + 16) * XP + 4 * 16 * TP;         // [4 waves][4 * Do]: db | da0 | da1 | da2
+    gat_stage_x<D>(xs, x + (int64_t)b * N * D, N);
+    float wr[NOB][NS], wt[NDB][NSO], bo[NOB], av[3][NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * ob + li;
+        bo[ob] = bias[o];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) av[t][ob] = a[t * Do + o];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) wr[ob][k] = W[(size_t)o * D + 4 * k + g];
+    }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int k = 0; k < NSO; ++k) wt[db][k] = W[(size_t)(4 * k + g) * D + 16 * db + li];      // W^T: row d = 16 db + li, k <-> o = 4 k + g
+    f32x4 dwa[NOB][NDB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) dwa[ob][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbs[NOB], das[3][NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) { dbs[ob] = 0.f; das[0][ob] = 0.f; das[1][ob] = 0.f; das[2][ob] = 0.f; }
+    __syncthreads();
+    const int nblk = gridDim.x, ipb = (N + nblk - 1) / nblk;
+    const int i0 = blockIdx.x * ipb, i1 = min(N, i0 + ipb), njb = (N + 15) / 16;
+    for (int u = wave; u < (i1 - i0) * njb; u += GAT_PAIRS / 64) {
+        const int i = i0 + u / njb, j0 = (u % njb) * 16;
+        f32x4 acc[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float pv = xs[i * XP + 4 * k + g] * xs[(j0 + li) * XP + 4 * k + g];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, wr[ob][k], acc[ob], 0, 0, 0);
+        }
+        // this lane: outputs o = 16 ob + li of the pairs (i, j0 + 4 g + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * g + r;
+            const float gd = j < N ? ds[((int64_t)b * N + i) * N + j] : 0.f;
+            const int ty = gat_type(i, j < N ? j : 0, n1);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const float h = gat_tanh(acc[ob][r] + bo[ob]);
+                const float at = ty == 0 ? av[0][ob] : (ty == 1 ? av[1][ob] : av[2][ob]);
+                const float gh = gd * h;
+                das[0][ob] += ty == 0 ? gh : 0.f; das[1][ob] += ty == 1 ? gh : 0.f; das[2][ob] += ty == 2 ? gh : 0.f;
+                const float dpre = gd * at * (1.0f - h * h);
+                dbs[ob] += dpre;
+                acc[ob][r] = dpre;
+                Tw[(4 * g + r) * TP + 16 * ob + li] = dpre;
+            }
+        }
+        // dW[o][d] += sum_pairs dpre[pair][o] p[pair][d]:  rows = o, k = pairs (k index g <-> pair 4 g + r), columns = d
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const float pv = xs[i * XP + 16 * db + li] * xs[(j0 + 4 * g + r) * XP + 16 * db + li];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) dwa[ob][db] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[ob][r], pv, dwa[ob][db], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile's writes are this wave's own: in order, complete before the reads below
+        // dp^T[d][pair] = sum_o W[o][d] dpre[pair][o]:  rows = d, k = o, columns = pairs (j0 + li)
+        f32x4 dpa[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) dpa[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NSO; ++k) {
+            const float tv = Tw[li * TP + 4 * k + g];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) dpa[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[db][k], tv, dpa[db], 0, 0, 0);
+        }
+        if (j0 + li < N) {
+            float* out = dP + (((int64_t)b * N + i) * N + j0 + li) * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) *reinterpret_cast<f32x4*>(out + 16 * db + 4 * g) = dpa[db];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next unit overwrites the tile
+    }
+    // ---- block partials: dW from the accumulators (rows o = 16 ob + 4 g + r', column d = 16 db + li), four waves summed through LDS in order
+    float* pb = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)Do * D + 4 * Do);
+    __syncthreads();
+    float* wsum = sm;                                      // [Do * D] (x is no longer needed)
+    for (int w4 = 0; w4 < 4; ++w4) {
+        if (wave == w4) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (16 * ob + 4 * g + r) * D + 16 * db + li;
+                        wsum[idx] = (w4 == 0 ? 0.f : wsum[idx]) + dwa[ob][db][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < Do * D; e += GAT_PAIRS) pb[e] = wsum[e];
+    __syncthreads();      // small graphs: the sums' staging area below may overlap wsum
+    // db / da: sum over the four lane groups g (they hold different pairs of the same output), then over the waves
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        float v[4] = {dbs[ob], das[0][ob], das[1][ob], das[2][ob]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] += __shfl_xor(v[q], 16, 64);
+            v[q] += __shfl_xor(v[q], 32, 64);
+            if (g == 0) red[wave * 4 * Do + q * Do + 16 * ob + li] = v[q];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 4 * Do; e += GAT_PAIRS) pb[(size_t)Do * D + e] = (red[e] + red[4 * Do + e]) + (red[8 * Do + e] + red[12 * Do + e]);
+}
+
+template <int D, int Do>
+size_t gat_mfma_lds(int N, bool bwd) {
+    size_t f = (size_t)(N + 16) * (D + 1);
+    if (bwd) { f += 4 * 16 * (Do + 1) + 16 * Do; if (f < (size_t)Do * D) f = (size_t)Do * D; }
+    return f * sizeof(float);
+}
+
 }  // namespace
 
 extern "C" int scl_gat_score_nblocks(int N) { return (N * N + GAT_PAIRS - 1) / GAT_PAIRS; }
@@ -215,6 +415,11 @@ extern "C" int scl_gat_score_fwd(const float* x, const float* W, const float* bi
                 "gat_score_fwd: need D in {32, 64}, Do <= 64, N <= 128 (D=%d Do=%d N=%d)", D, Do, N);
     dim3 grid(scl_gat_score_nblocks(N), B), block(GAT_PAIRS);
     hipStream_t st = (hipStream_t)stream;
+#define GAT_FWD_MFMA(DD, OO) hipLaunchKernelGGL((gat_score_fwd_mfma_kernel<DD, OO>), grid, block, (gat_mfma_lds<DD, OO>(N, false)), st, x, W, bias, a, s, N, n1)
+    if (D == 64 && Do == 64) { GAT_FWD_MFMA(64, 64); return scl_check_launch("scl_gat_score_fwd"); }
+    if (D == 64 && Do == 32) { GAT_FWD_MFMA(64, 32); return scl_check_launch("scl_gat_score_fwd"); }
+    if (D == 32 && Do == 32) { GAT_FWD_MFMA(32, 32); return scl_check_launch("scl_gat_score_fwd"); }
+#undef GAT_FWD_MFMA
     if (D == 64) {
         const size_t lds = GatSmem<64>::floats(Do, N) * sizeof(float);
         hipLaunchKernelGGL((gat_score_fwd_kernel<64>), grid, block, lds, st, x, W, bias, a, s, N, Do, n1);
@@ -240,6 +445,16 @@ extern "C" int scl_gat_score_bwd(const float* x, const float* W, const float* bi
         hipFuncSetAttribute((const void*)gat_score_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+#define GAT_BWD_MFMA(DD, OO)                                                                                                                             \
+    do {                                                                                                                                                  \
+        hipLaunchKernelGGL((gat_score_bwd_mfma_kernel<DD, OO>), grid, block, (gat_mfma_lds<DD, OO>(N, true)), st, x, W, bias, a, ds, dP, part, N, n1);      \
+        hipLaunchKernelGGL((gat_dx_kernel<DD>), dim3(N, B), dim3(4 * DD), 0, st, dP, x, dx, N);                                                           \
+        return scl_check_launch("scl_gat_score_bwd");                                                                                                   \
+    } while (0)
+    if (D == 64 && Do == 64) GAT_BWD_MFMA(64, 64);
+    if (D == 64 && Do == 32) GAT_BWD_MFMA(64, 32);
+    if (D == 32 && Do == 32) GAT_BWD_MFMA(32, 32);
+#undef GAT_BWD_MFMA
     if (D == 64) {
         const size_t lds = (((GatSmem<64>::floats(Do, N) + 3) & ~(size_t)3) + (size_t)GAT_PAIRS * GAT_DPS + 16 * Do) * sizeof(float) + 2 * GAT_PAIRS;
         SCL_REQUIRE(lds <= 160 * 1024, "gat_score_bwd: LDS tile too large");
