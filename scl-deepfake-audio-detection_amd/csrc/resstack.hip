@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 1 : 2)) void rs_conv_kernel(const
             for (int r = 0; r < RBG; ++r)
                 *reinterpret_cast<f32x4*>(lds + (((rg * RPW + gp * RBG + r) * 16) + li) * OPITCH + 16 * cb + 4 * g4) = acc[gp][r];
         __syncthreads();
-        constexpr int NPASS = RS_MT * N4 / 256, EB = NPASS < 4 ? NPASS : 4;
+        // epilogue operands (addend, a, y1) of EB passes are requested together: one memory latency per batch.  The 64-channel form owns
+        // the CU's 512 registers and takes all of a tile's passes in one batch; the two-blocks-per-CU forms four at a time.
+        constexpr int NPASS = RS_MT * N4 / 256, EB = CIN >= 64 ? (SM == 2 ? NPASS / 2 : NPASS) : (NPASS < 4 ? NPASS : 4);
 #ifdef RS_NO_EPI
         if (d.q.G > 0) { if (tid == 0) d.out[(size_t)g0 * COUT] = lds[tid]; __syncthreads(); continue; }
 #endif
