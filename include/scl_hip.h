@@ -586,6 +586,37 @@ int scl_phase_vocoder_c64(const void* D_c64, int nframes, double rate, void* out
 int scl_istft_f32(const void* D_c64, int nframes, float* frames_ws, float* y, int length, void* stream);
 int scl_resample_sinc_f32(const float* x, int n_in, double ratio, float* out, int n_out, void* stream);
 
+/* ---- Conformer block (csrc/conformer.hip; BASELINE.json configs[4]'s head: model/conformer.py:180-216, importable although the
+ * BTSE plugin that would call it is not) --------------------------------------------------------------------------------------------
+ * Everything fp32, channels-last.  The block's Linear / 1x1-Conv1d / attention contractions run on scl_gemm_bf16 with f32 operands
+ * (SCL_GEMM_AB_F32), its LayerNorms on scl_layernorm_*, its BatchNorm1d on scl_bn_*; these are the remaining operators.
+ * Swish: y = x sigmoid(x) (conformer.py:25-27).  GLU over the last dimension of [M, 2C] (conformer.py:29-36, dim = channels):
+ * y[m][c] = x[m][c] sigmoid(x[m][C + c]).  scl_axpby_f32: out = sa a + sb b (b may be null) — Scale(0.5, .) and the halved biases. */
+int scl_swish_fwd(const float* x, float* y, int64_t n, void* stream);
+int scl_swish_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int scl_glu_fwd(const float* x, float* y, int64_t M, int C, void* stream);
+int scl_glu_bwd(const float* dy, const float* x, float* dx, int64_t M, int C, void* stream);
+int scl_axpby_f32(const float* a, const float* b, float sa, float sb, float* out, int64_t n, void* stream);
+/* DepthWiseConv1d (conformer.py:38-46): y[b][t][c] = bias[c] + sum_j w[c][j] x[b][t + j - pad_l][c] on [B, n, C] maps, zero outside the
+ * utterance, output length n (pad_l + pad_r = k - 1), k <= 32 taps.  flip = 1 reads the taps back to front: the data gradient is
+ * scl_dwconv1d_fwd(dy, w, NULL, dx, ..., pad_l' = k - 1 - pad_l, flip = 1).  scl_dwconv1d_wgrad: part f32
+ * [scl_dwconv1d_wgrad_nslabs(B, n)][k + 1][C] scratch; writes dw [C][k] and (optional) db [C], slabs summed in index order. */
+int scl_dwconv1d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int n, int C, int k, int pad_l, int flip, void* stream);
+int scl_dwconv1d_wgrad_nslabs(int B, int n);
+int scl_dwconv1d_wgrad(const float* x, const float* dy, float* part, float* dw, float* db, int B, int n, int C, int k, int pad_l, void* stream);
+/* Shaw's relative positions (conformer.py:98-106: dist = clamp(i - j, -max_pos, max_pos) + max_pos; pos_attn = q . rel_pos_emb(dist)).
+ * scl_relpos_gather: Eu[r'] = E[clamp(r' - (n - 1)) + max_pos] for the 2n - 1 distances that occur (rows 2n - 1 .. Nr - 1 zero), so that
+ * R = q Eu^T is one GEMM and pos_attn[i][j] = R[i][i - j + n - 1].  scl_relpos_softmax_fwd: P[(b,h,i)][j] = softmax_j(scale S + scale R
+ * skewed), optional byte mask [B][n] (pairs with mask[b][i] & mask[b][j] == 0 take -FLT_MAX: conformer.py:108-113), columns n .. ldP - 1
+ * zero; n <= 1024.  scl_relpos_softmax_bwd: dS (pitch ldP) and the skewed dR (pitch ldR), every element written.
+ * scl_relpos_scatter_grad: dE [2 max_pos + 1][D] from dEu [2n - 1][D] (the clamped ends sum their run in order). */
+int scl_relpos_gather(const float* E, float* Eu, int n, int Nr, int D, int max_pos, void* stream);
+int scl_relpos_scatter_grad(const float* dEu, float* dE, int n, int D, int max_pos, void* stream);
+int scl_relpos_softmax_fwd(const float* S, const float* R, const uint8_t* mask, float* P, int B, int H, int n, int ldS, int ldR, int ldP,
+                           float scale, void* stream);
+int scl_relpos_softmax_bwd(const float* P, const float* dP, const uint8_t* mask, float* dS, float* dR, int B, int H, int n, int ldP, int ldR,
+                           float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

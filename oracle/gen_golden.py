@@ -596,6 +596,63 @@ def gen_audioop():
     print("audioop.npz", len(out), "arrays")
 
 
+def gen_conformer():
+    """Reference model/conformer.py::ConformerBlock (imported from the file: the module needs einops only).  Parameters by
+    oracle/aasist.py::fill_state, four cases: `a` train mode (gradients of the small tensors whole, fingerprints = norm, sum, first 16 values of the large ones); `b` eval mode with a key / query mask (one
+    utterance fully masked: the uniform rows of masked_fill(-max)); `c` the causal form (no BatchNorm, even kernel, padding (k - 1, 0));
+    `d` n = 600 > max_pos_emb + 1, so that the distances clamp at both ends of the relative-position table.  The tests rebuild the
+    parameters with the same fill_state(shapes, seed) call.  Also the state dict a
+    seeded construction gives (a fingerprint), for the "same seed, same initial weights" property of the HIP block."""
+    import importlib.util
+    from oracle.aasist import fill_state
+    spec = importlib.util.spec_from_file_location("ref_conformer", os.path.join(REF, "model", "conformer.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    cases = {
+        "a": dict(cfg=dict(dim=64, dim_head=16, heads=4), B=3, n=50, train=True, mask=False),
+        "b": dict(cfg=dict(dim=64, dim_head=16, heads=4), B=3, n=37, train=False, mask=True),
+        "c": dict(cfg=dict(dim=32, dim_head=32, heads=2, ff_mult=2, conv_kernel_size=8, conv_causal=True), B=2, n=21, train=True, mask=False),
+        "d": dict(cfg=dict(dim=32, dim_head=16, heads=2, ff_mult=2, conv_expansion_factor=1, conv_kernel_size=5), B=1, n=600, train=True, mask=False),
+    }
+    out = {}
+    for name, c in cases.items():
+        blk = M.ConformerBlock(**c["cfg"])
+        sd = blk.state_dict()
+        filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=31 + ord(name))
+        blk.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+        blk.train() if c["train"] else blk.eval()
+        rs = np.random.RandomState(100 + ord(name))
+        x0 = rs.standard_normal((c["B"], c["n"], c["cfg"]["dim"])).astype(np.float32)
+        wout = rs.standard_normal(x0.shape).astype(np.float32)
+        mask = None
+        if c["mask"]:
+            mk = rs.rand(c["B"], c["n"]) > 0.3
+            mk[1, :] = False
+            mask = torch.from_numpy(mk)
+            out[name + ":mask"] = mk
+        x = torch.from_numpy(x0).clone().requires_grad_(True)
+        y = blk(x, mask=mask)
+        (y * torch.from_numpy(wout)).sum().backward()
+        out[name + ":cfg"] = np.array(repr(sorted(c["cfg"].items())))
+        out[name + ":x"], out[name + ":wout"], out[name + ":y"], out[name + ":grad_x"] = x0, wout, y.detach().numpy(), x.grad.numpy()
+        out[name + ":seed"] = np.array(31 + ord(name))          # the parameters are fill_state(shapes, seed): not stored
+        for k, p_ in blk.named_parameters():
+            g = p_.grad.numpy()
+            if g.size <= (8192 if name == "a" else 4096) or (k == "attn.fn.rel_pos_emb.weight" and name in "ad"):
+                out[name + ":grad:" + k] = g
+            else:
+                out[name + ":gradfp:" + k] = np.concatenate([[np.sqrt((g.astype(np.float64) ** 2).sum()), g.astype(np.float64).sum()], g.flatten()[:16]]).astype(np.float64)
+        if c["train"] and not c["cfg"].get("conv_causal", False):
+            for k in ("conv.net.5.running_mean", "conv.net.5.running_var", "conv.net.5.num_batches_tracked"):
+                out[name + ":buf:" + k] = blk.state_dict()[k].numpy()
+    torch.manual_seed(1234)
+    blk = M.ConformerBlock(dim=64, dim_head=16, heads=4)
+    out["init:keys"] = np.array(list(blk.state_dict().keys()))
+    out["init:fp"] = np.array([float(v.double().sum()) for v in blk.state_dict().values()])
+    np.savez_compressed(os.path.join(OUT, "conformer.npz"), **out)
+    print("conformer.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
@@ -604,6 +661,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop), ("conformer", gen_conformer)):
         if want(name):
             fn()

@@ -217,6 +217,18 @@ def _protos():
         "scl_phase_vocoder_c64": ([_vp, _i32, _f64, _vp, _i32, _vp], _i32),
         "scl_istft_f32": ([_vp, _i32, _vp, _vp, _i32, _vp], _i32),
         "scl_resample_sinc_f32": ([_vp, _i32, _f64, _vp, _i32, _vp], _i32),
+        "scl_swish_fwd": ([_vp, _vp, _i64, _vp], _i32),
+        "scl_swish_bwd": ([_vp, _vp, _vp, _i64, _vp], _i32),
+        "scl_glu_fwd": ([_vp, _vp, _i64, _i32, _vp], _i32),
+        "scl_glu_bwd": ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
+        "scl_axpby_f32": ([_vp, _vp, _f32, _f32, _vp, _i64, _vp], _i32),
+        "scl_dwconv1d_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_dwconv1d_wgrad_nslabs": ([_i32, _i32], _i32),
+        "scl_dwconv1d_wgrad": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_relpos_gather": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_relpos_scatter_grad": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
+        "scl_relpos_softmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        "scl_relpos_softmax_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
     }
 
 

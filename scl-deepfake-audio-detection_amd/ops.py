@@ -599,3 +599,52 @@ def avgpool_fwd(x, B, R, C, y):
 
 def avgpool_bwd(dy, B, R, C, dx):
     _call("scl_avgpool_bwd", _p(dy), B, R, C, _p(dx), _stream())
+
+
+# ---- Conformer block operators (csrc/conformer.hip) ---------------------------------------------------------------------------------
+def swish_fwd(x, y, n):
+    _call("scl_swish_fwd", _p(x), _p(y), n, _stream())
+
+
+def swish_bwd(dy, x, dx, n):
+    _call("scl_swish_bwd", _p(dy), _p(x), _p(dx), n, _stream())
+
+
+def glu_fwd(x, y, M, C):
+    _call("scl_glu_fwd", _p(x), _p(y), M, C, _stream())
+
+
+def glu_bwd(dy, x, dx, M, C):
+    _call("scl_glu_bwd", _p(dy), _p(x), _p(dx), M, C, _stream())
+
+
+def axpby(a, b, sa, sb, out, n):
+    _call("scl_axpby_f32", _p(a), _p(b), float(sa), float(sb), _p(out), n, _stream())
+
+
+def dwconv1d_fwd(x, w, bias, y, B, n, C, k, pad_l, flip=False):
+    _call("scl_dwconv1d_fwd", _p(x), _p(w), _p(bias), _p(y), B, n, C, k, pad_l, int(flip), _stream())
+
+
+def dwconv1d_wgrad_nslabs(B, n):
+    return L.load().scl_dwconv1d_wgrad_nslabs(B, n)
+
+
+def dwconv1d_wgrad(x, dy, part, dw, db, B, n, C, k, pad_l):
+    _call("scl_dwconv1d_wgrad", _p(x), _p(dy), _p(part), _p(dw), _p(db), B, n, C, k, pad_l, _stream())
+
+
+def relpos_gather(E, Eu, n, Nr, D, max_pos):
+    _call("scl_relpos_gather", _p(E), _p(Eu), n, Nr, D, max_pos, _stream())
+
+
+def relpos_scatter_grad(dEu, dE, n, D, max_pos):
+    _call("scl_relpos_scatter_grad", _p(dEu), _p(dE), n, D, max_pos, _stream())
+
+
+def relpos_softmax_fwd(S, R, mask, P, B, H, n, ldS, ldR, ldP, scale):
+    _call("scl_relpos_softmax_fwd", _p(S), _p(R), _p(mask), _p(P), B, H, n, ldS, ldR, ldP, float(scale), _stream())
+
+
+def relpos_softmax_bwd(P, dP, mask, dS, dR, B, H, n, ldP, ldR, scale):
+    _call("scl_relpos_softmax_bwd", _p(P), _p(dP), _p(mask), _p(dS), _p(dR), B, H, n, ldP, ldR, float(scale), _stream())
