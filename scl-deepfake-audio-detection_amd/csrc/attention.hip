@@ -148,6 +148,24 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
     char* Kt = asmem;                 // [rows][128 B] row-read image
     char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lc = lane & 15, g = lane >> 4;
+    // the wave's first query tile is requested ahead of the K / V staging (one memory round trip instead of two in a row), the next one
+    // while the current tile is multiplied
+    bf16x8 qf[2];
+    auto load_q = [&](int qb, bf16x8 (&dst)[2]) {
+        const int q = qb * 16 + lc;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (q < T) u = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 32 * ks + 8 * g);
+            dst[ks] = __builtin_bit_cast(bf16x8, u);
+        }
+    };
+#ifndef ATT_NO_QPRE
+    load_q(wave, qf);
+#endif
     // K / V staging: all of a thread's loads are requested before the first LDS write (a rolled load -> write loop paid one memory
     // round trip per iteration; rows * 8 <= 2048 vectors = 4 per thread)
     {
@@ -156,7 +174,11 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
         for (int it = 0; it < 4; ++it) {
             const int idx = threadIdx.x + 512 * it, key = idx >> 3, c = idx & 7;
             kv[it] = make_uint4(0, 0, 0, 0); vv[it] = make_uint4(0, 0, 0, 0);
+#ifndef ATT_ABL_NOSTAGE
             if (idx < rows * 8 && key < T) {
+#else
+            if (idx < rows * 8 && key < T && T < 0) {
+#endif
                 kv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + E + 8 * c);
                 vv[it] = *reinterpret_cast<const uint4*>(base + (int64_t)key * 3 * E + 2 * E + 8 * c);
             }
@@ -171,27 +193,28 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lc = lane & 15, g = lane >> 4;
     const float sl2 = scale * 1.4426950408889634f;
     for (int qb = wave; qb < NT; qb += (int)(blockDim.x >> 6)) {      // 8 waves: two blocks per CU = 4 waves per SIMD
         const int q = qb * 16 + lc;
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (q < T) u = *reinterpret_cast<const uint4*>(base + (int64_t)q * 3 * E + 32 * ks + 8 * g);
-            qf[ks] = __builtin_bit_cast(bf16x8, u);
-        }
+#ifdef ATT_NO_QPRE
+        load_q(qb, qf);
+#else
+        bf16x8 qn[2] = {qf[0], qf[1]};
+        if (qb + (int)(blockDim.x >> 6) < NT) load_q(qb + (int)(blockDim.x >> 6), qn);
+#endif
         f32x4 s[NTB + 1];
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NTB; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < NT) {
+#ifdef ATT_ABL_NOQK
+                s[t] = f32x4{(float)lane, __builtin_bit_cast(float, __builtin_bit_cast(u32x4a, qf[0])[0]), 2.f, (float)t};
+#else
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows(Kt, t, ks, lane), qf[ks], s[t], 0, 0, 0);
+#endif
                 if (t == NT - 1) {      // only the last key tile can hold keys >= T (the softmax below is VALU-bound: no per-element test elsewhere)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -209,7 +232,11 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
         for (int t = 0; t < NTB; ++t) {
             if (t < NT) {
 #pragma unroll
+#ifdef ATT_ABL_NOEXP
+                for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_fmaf(s[t][r], sl2, msl) * 1e-3f; l += s[t][r]; }
+#else
                 for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, msl)); l += s[t][r]; }      // = exp(scale * (s - m))
+#endif
             }
         }
         l += __shfl_xor(l, 16, 64);
@@ -242,7 +269,11 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
+#ifdef ATT_ABL_NOPV
+                    o[dt][0] += __builtin_bit_cast(float, pk[dt]);
+#else
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_tr(Vt, 16 * ta, 16 * tb, dt, lane), pf, o[dt], 0, 0, 0);
+#endif
                 if (NTC) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -252,6 +283,9 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
         }
+#ifndef ATT_NO_QPRE
+        qf[0] = qn[0]; qf[1] = qn[1];
+#endif
     }
 }
 
