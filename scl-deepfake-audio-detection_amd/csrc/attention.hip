@@ -133,6 +133,108 @@ __device__ __forceinline__ bf16x8 att_frag_tr(const char* tile, int rowa, int ro
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// One 16-query tile of the forward against the staged K / V images: scores, soft-max, P V, ctx and log-sum-exp stores.
+template <bool DROP, int NTC>
+__device__ __forceinline__ void att_fwd_tile(const char* Kt, const char* Vt, bf16x8 (&qf)[2], const bf16_t* qnext, int qb, int b, int h, int T, int H,
+                                             int NT, float scale, float sl2, float drop_p, uint32_t drop_seed, bf16_t* __restrict__ ctx,
+                                             float* __restrict__ lse, int lane) {
+    constexpr int NTB = NTC ? NTC : ATT_NTMAX, NT2B = (NTB + 1) / 2;      // unroll bounds
+    const int NT2 = (NT + 1) / 2, E = H * ATT_D;
+    const int lc = lane & 15, g = lane >> 4;
+    const int q = qb * 16 + lc;
+    f32x4 s[NTB + 1];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < NT) {
+#ifdef ATT_ABL_NOQK
+            s[t] = f32x4{(float)lane, __builtin_bit_cast(float, __builtin_bit_cast(u32x4a, qf[0])[0]), 2.f, (float)t};
+#else
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows(Kt, t, ks, lane), qf[ks], s[t], 0, 0, 0);
+#endif
+            if (t == NT - 1) {      // only the last key tile can hold keys >= T (the softmax below is VALU-bound: no per-element test elsewhere)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
+            }
+            m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            if (NTC && (t & 1)) __builtin_amdgcn_sched_barrier(0);      // keeps the K-fragment reads of later tiles from being hoisted (128-register budget)
+        }
+    }
+#ifndef ATT_NO_QPRE
+    // the query fragments are dead from here: the lane's row of the NEXT tile this wave will work on (qnext; null = none) travels
+    // under the soft-max and the P V products
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (qnext) u = *reinterpret_cast<const uint4*>(qnext + 32 * ks + 8 * g);
+        qf[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+#endif
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+    const float msl = -m * sl2;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+        if (t < NT) {
+#pragma unroll
+#ifdef ATT_ABL_NOEXP
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_fmaf(s[t][r], sl2, msl) * 1e-3f; l += s[t][r]; }
+#else
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, msl)); l += s[t][r]; }      // = exp(scale * (s - m))
+#endif
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (g == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = scale * m + __logf(l);
+    if (DROP) {      // attention dropout (fairseq MultiheadAttention dropout_module on the probabilities): keep-mask by (row, key)
+        const uint64_t rowbase = (((uint64_t)b * H + h) * T + (uint64_t)(q < T ? q : 0)) * T;
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] *= dropout_scale(drop_seed, rowbase + (uint64_t)(16 * t + 4 * g + r), drop_p);
+            }
+        }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NT2B; ++u) {
+        if (u < NT2) {
+            const int ta = 2 * u, tb = 2 * u + 1;
+            // the un-normalised exponentials (<= 1) are the B operand; 1 / l multiplies the 16 outputs instead of the 4 NT probabilities
+            float pb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (tb < NT) { pb[0] = s[tb][0]; pb[1] = s[tb][1]; pb[2] = s[tb][2]; pb[3] = s[tb][3]; }
+            u32x4a pk;
+            pk[0] = pack_bf2(s[ta][0], s[ta][1]); pk[1] = pack_bf2(s[ta][2], s[ta][3]);
+            pk[2] = pack_bf2(pb[0], pb[1]); pk[3] = pack_bf2(pb[2], pb[3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#ifdef ATT_ABL_NOPV
+                o[dt][0] += __builtin_bit_cast(float, pk[dt]);
+#else
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_tr(Vt, 16 * ta, 16 * tb, dt, lane), pf, o[dt], 0, 0, 0);
+#endif
+            if (NTC) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (q < T) {
+        bf16_t* dst = ctx + ((int64_t)b * T + q) * E + h * ATT_D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+    }
+}
+
 // NTC: number of 16-key tiles as a compile-time constant (0 = run time).  With a run-time tile count every step of the unrolled tile
 // loops is predicated (v_cndmask on 4 x 16 score registers, the tile counter and masks in SGPRs that spill to lanes: 150 cndmask +
 // 300 readlane / writelane in a 1300-instruction kernel that is VALU-bound); the encoder's lengths give 13 tiles (T = 193 .. 208: 64000- and
@@ -144,7 +246,6 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
     const int E = H * ATT_D;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int NT = NTC ? NTC : (T + 15) / 16, NT2 = (NT + 1) / 2, rows = 32 * NT2;
-    constexpr int NTB = NTC ? NTC : ATT_NTMAX, NT2B = (NTB + 1) / 2;      // unroll bounds
     char* Kt = asmem;                 // [rows][128 B] row-read image
     char* Vt = asmem + rows * 128;    // [rows][128 B] tr-read image
     const bf16_t* base = qkv + (int64_t)b * T * 3 * E + h * ATT_D;
@@ -195,101 +296,21 @@ __global__ __launch_bounds__(512, DROP ? 2 : 4) void attn_fwd_kernel(const bf16_
     __syncthreads();
     const float sl2 = scale * 1.4426950408889634f;
     for (int qb = wave; qb < NT; qb += (int)(blockDim.x >> 6)) {      // 8 waves: two blocks per CU = 4 waves per SIMD
-        const int q = qb * 16 + lc;
 #ifdef ATT_NO_QPRE
         load_q(qb, qf);
-#else
-        bf16x8 qn[2] = {qf[0], qf[1]};
-        if (qb + (int)(blockDim.x >> 6) < NT) load_q(qb + (int)(blockDim.x >> 6), qn);
 #endif
-        f32x4 s[NTB + 1];
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NTB; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < NT) {
-#ifdef ATT_ABL_NOQK
-                s[t] = f32x4{(float)lane, __builtin_bit_cast(float, __builtin_bit_cast(u32x4a, qf[0])[0]), 2.f, (float)t};
-#else
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows(Kt, t, ks, lane), qf[ks], s[t], 0, 0, 0);
-#endif
-                if (t == NT - 1) {      // only the last key tile can hold keys >= T (the softmax below is VALU-bound: no per-element test elsewhere)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * g + r >= T) s[t][r] = -INFINITY;
-                }
-                m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-                if (NTC && (t & 1)) __builtin_amdgcn_sched_barrier(0);      // keeps the K-fragment reads of later tiles from being hoisted (128-register budget)
-            }
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-        const float msl = -m * sl2;
-#pragma unroll
-        for (int t = 0; t < NTB; ++t) {
-            if (t < NT) {
-#pragma unroll
-#ifdef ATT_ABL_NOEXP
-                for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_fmaf(s[t][r], sl2, msl) * 1e-3f; l += s[t][r]; }
-#else
-                for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, msl)); l += s[t][r]; }      // = exp(scale * (s - m))
-#endif
-            }
-        }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        if (g == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = scale * m + __logf(l);
-        if (DROP) {      // attention dropout (fairseq MultiheadAttention dropout_module on the probabilities): keep-mask by (row, key)
-            const uint64_t rowbase = (((uint64_t)b * H + h) * T + (uint64_t)(q < T ? q : 0)) * T;
-#pragma unroll
-            for (int t = 0; t < NTB; ++t) {
-                if (t < NT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[t][r] *= dropout_scale(drop_seed, rowbase + (uint64_t)(16 * t + 4 * g + r), drop_p);
-                }
-            }
-        }
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < NT2B; ++u) {
-            if (u < NT2) {
-                const int ta = 2 * u, tb = 2 * u + 1;
-                // the un-normalised exponentials (<= 1) are the B operand; 1 / l multiplies the 16 outputs instead of the 4 NT probabilities
-                float pb[4] = {0.f, 0.f, 0.f, 0.f};
-                if (tb < NT) { pb[0] = s[tb][0]; pb[1] = s[tb][1]; pb[2] = s[tb][2]; pb[3] = s[tb][3]; }
-                u32x4a pk;
-                pk[0] = pack_bf2(s[ta][0], s[ta][1]); pk[1] = pack_bf2(s[ta][2], s[ta][3]);
-                pk[2] = pack_bf2(pb[0], pb[1]); pk[3] = pack_bf2(pb[2], pb[3]);
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#ifdef ATT_ABL_NOPV
-                    o[dt][0] += __builtin_bit_cast(float, pk[dt]);
-#else
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_tr(Vt, 16 * ta, 16 * tb, dt, lane), pf, o[dt], 0, 0, 0);
-#endif
-                if (NTC) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (q < T) {
-            bf16_t* dst = ctx + ((int64_t)b * T + q) * E + h * ATT_D + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
-        }
-#ifndef ATT_NO_QPRE
-        qf[0] = qn[0]; qf[1] = qn[1];
-#endif
+        const int qn = (qb + (int)(blockDim.x >> 6)) * 16 + lc;      // this lane's query of the wave's next tile
+        const bf16_t* qnext = (qb + (int)(blockDim.x >> 6) < NT && qn < T) ? base + (int64_t)qn * 3 * E : nullptr;
+        att_fwd_tile<DROP, NTC>(Kt, Vt, qf, qnext, qb, b, h, T, H, NT, scale, sl2, drop_p, drop_seed, ctx, lse, lane);
     }
 }
 
 
+// Workgroup barrier for LDS hand-offs only: __syncthreads() also drains vmcnt (its release fence covers global memory), which made
+// every step of the backward wait for the acknowledgement of its dQ stores (barrier A), for the query-tile loads it had just
+// requested for the NEXT step (barrier B), and the bias-sum tail for the dK / dV stores.  Here: this wave's LDS operations retired,
+// then s_barrier; global loads stay in flight (the compiler still waits for them where their registers are first used).
+#define ATT_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // -----------------------------------------------------------------------------------------------------
 // Backward, one workgroup per (utterance, head), T <= 224.  A wave OWNS a block of keys and keeps dK^T and dV^T of those keys
 // in accumulator registers while the workgroup sweeps the queries 32 at a time:
@@ -333,11 +354,6 @@ __device__ __forceinline__ int att_s_off(int q, int key32) {   // dS sub-image [
     return q * 64 + ((((key32 >> 3) ^ (q >> 2)) & 3) << 4) + ((key32 & 7) << 1);
 }
 
-// Workgroup barrier for LDS hand-offs only: __syncthreads() also drains vmcnt (its release fence covers global memory), which made
-// every step of the backward wait for the acknowledgement of its dQ stores (barrier A), for the query-tile loads it had just
-// requested for the NEXT step (barrier B), and the bias-sum tail for the dK / dV stores.  Here: this wave's LDS operations retired,
-// then s_barrier; global loads stay in flight (the compiler still waits for them where their registers are first used).
-#define ATT_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 template <bool DROP, int NTC>      // attention dropout compiled in only where asked for; NTC: compile-time key-tile count (0 = run time), as in attn_fwd_kernel
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
