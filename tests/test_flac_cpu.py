@@ -1,5 +1,9 @@
 """csrc/flac.hip (host code: runs without a GPU) against streams written by tests/flac_writer.py: every subframe type, residual
-coding and stereo mode decodes to the encoder's input exactly, CRC / MD5 corruption is detected, and pack.load_audio reads .flac."""
+coding and stereo mode decodes to the encoder's input exactly, CRC / MD5 corruption is detected, and pack.load_audio reads .flac.
+No third-party FLAC encoder exists in this image (`import soundfile`, `flac`, `ffmpeg`, `sox`: all absent, no .flac file on the disk), so
+the streams here that were NOT written by this repository's own encoder are the three examples of the format specification (RFC 9639,
+appendix D.1 - D.3, typed from the published text): their frame CRC-8s, CRC-16s and the MD5s of the audio were produced by the reference
+encoder ("reference libFLAC 1.3.3 20190804" in the second one's comment block), and the decoder verifies every one of them."""
 import ctypes
 import os
 
@@ -143,3 +147,47 @@ def test_offline_cache_keeps_the_source_name_but_holds_wav_bytes(tmp_path):
     assert torch.equal(got, y / 32768.0)
     again = pack._offline_cached("reverb", None, args, 16000, "/corpus/LA_T_1.flac", lambda: 1 / 0, int16_values=True)   # a hit: make() not called
     assert np.array_equal(np.asarray(again.cpu()), (y / 32768.0).numpy())
+
+
+def test_stream_from_the_format_specification():
+    """RFC 9639 appendix D.1: 44.1 kHz, 2 channels, 16 bits, one inter-channel sample, verbatim subframes with wasted bits.  The decoder
+    checks the frame header's CRC-8 (0xbf), the frame's CRC-16 (0xaa9a) and STREAMINFO's MD5 of the decoded audio — three numbers this
+    repository did not produce."""
+    raw = bytes.fromhex("664c614380000022100010000000 0f00000f0ac442f0000000013e84b41807dc690307586a3dad1a2e0f"
+                        "fff869180000bf0358fd03128baa9a".replace(" ", ""))
+    assert len(raw) == 57
+    pcm, fs, bits = decode(raw, check_md5=1)
+    assert (fs, bits) == (44100, 16) and pcm.shape == (1, 2)
+    assert pcm.tolist() == [[25588, 10416]]
+    bad = bytearray(raw)
+    bad[-4] ^= 1                      # one bit of the second subframe: the frame CRC-16 must catch it
+    with pytest.raises(L.SclError):
+        decode(bytes(bad))
+
+
+def test_second_and_third_streams_from_the_format_specification():
+    """RFC 9639 appendix D.2: STREAMINFO + SEEKTABLE + VORBIS_COMMENT + PADDING, two frames (16 and 3 inter-channel samples), side-channel
+    stereo, fixed predictors of order 1 / 2 / 3, Rice partitions, a wasted-bits verbatim frame.  D.3: 32 kHz, one channel, 8 bits, one
+    frame of 24 samples with a quantised linear predictor of order 3 (precision 4, shift 2) and an escaped-free Rice partition."""
+    d2 = bytes.fromhex(
+        "66 4c 61 43 00 00 00 22 00 10 00 10 00 00 17 00 00 44 0a c4 42 f0 00 00 00 13 d5 b0 56 49 75 e9 8b 8d 8b 93 04 22 75 7b 81 03"
+        "03 00 00 12 00 00 00 00 00 00 00 00 00 00 00 00 00 00 00 00 00 10"
+        "04 00 00 3a 20 00 00 00 72 65 66 65 72 65 6e 63 65 20 6c 69 62 46 4c 41 43 20 31 2e 33 2e 33 20 32 30 31 39 30 38 30 34"
+        "01 00 00 00 0e 00 00 00 54 49 54 4c 45 3d d7 a9 d7 9c d7 95 d7 9d"
+        "81 00 00 06 00 00 00 00 00 00"
+        "ff f8 69 98 00 0f 99 12 08 67 01 62 3d 14 42 99 8f 5d f7 0d 6f e0 0c 17 ca eb 21 00 0e e7 a7 7a 24 a1 59 0c 12 17 b6 03 09 7b 78 4f"
+        "aa 9a 33 d2 85 e0 70 ad 5b 1b 48 51 b4 01 0d 99 d2 cd 1a 68 f1 e6 b8 10"
+        "ff f8 69 18 01 02 a4 02 c3 82 c4 0b c1 4a 03 ee 48 dd 03 b6 7c 13 30")
+    assert len(d2) == 227
+    pcm, fs, bits = decode(d2, check_md5=1)
+    assert (fs, bits) == (44100, 16) and pcm.shape == (19, 2)
+    assert pcm[:, 0].tolist() == [10372, 18041, 14942, 17876, 15627, 17899, 16242, 18077, 16824, 18263, 17295, -14418, -15201, -14508, -15195,
+                                  -14818, -15486, -15349, -16054]
+    assert pcm[:, 1].tolist() == [6070, 10545, 8743, 10449, 9143, 10463, 9502, 10569, 9840, 10680, 10113, -8428, -8895, -8476, -8896, -8653,
+                                  -9072, -8958, -9410]
+    d3 = bytes.fromhex("66 4c 61 43 80 00 00 22 10 00 10 00 00 00 1f 00 00 1f 07 d0 00 70 00 00 00 18 f8 f9 e3 96 f5 cb cf c6 dc 80 7f 99 77 90 6b 32"
+                       "ff f8 68 02 00 17 e9 44 00 4f 6f 31 3d 10 47 d2 27 cb 6d 09 08 31 45 2b dc 28 22 22 80 57 a3")
+    assert len(d3) == 73
+    pcm, fs, bits = decode(d3, check_md5=1)
+    assert (fs, bits) == (32000, 8) and pcm.shape == (24, 1)
+    assert pcm[:, 0].tolist() == [0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5, 0]
