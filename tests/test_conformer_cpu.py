@@ -33,3 +33,24 @@ def test_oracle_conformer_block_matches_the_reference(case):
 def test_shapes_table_is_the_reference_state_dict():
     g = CC.load()
     assert sorted(g["init:keys"]) == sorted(CC.shapes_of(dict(dim=64, dim_head=16, heads=4)))
+
+
+def test_hip_block_has_the_reference_state_dict_and_refuses_cpu_tensors():
+    """Host logic of scl_amd/conformer.py (no kernel runs): the module tree gives the reference's state-dict keys in the reference's order,
+    a seeded construction gives the reference's initial weights (same torch modules created in the same order), and a CPU tensor is
+    refused — there is no CPU fallback."""
+    from scl_amd import conformer as C
+    g = CC.load()
+    torch.manual_seed(1234)
+    blk = C.ConformerBlock(dim=64, dim_head=16, heads=4)
+    sd = blk.state_dict()
+    assert list(sd.keys()) == list(g["init:keys"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["init:fp"], rtol=0, atol=0)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in CC.shapes_of(dict(dim=64, dim_head=16, heads=4)).items()}
+    causal = C.ConformerBlock(dim=32, dim_head=32, heads=2, ff_mult=2, conv_kernel_size=8, conv_causal=True)
+    assert sorted(causal.state_dict().keys()) == sorted(CC.shapes_of(CC.cfg_of(g, "c")))
+    assert causal.pad == (7, 0) and blk.pad == (15, 15) and C.ConformerBlock(dim=32, conv_kernel_size=8).pad == (4, 3)
+    with pytest.raises(RuntimeError):
+        blk(torch.zeros(1, 4, 64))
+    net = C.Conformer(32, depth=2, dim_head=16, heads=2)
+    assert len(net.layers) == 2 and list(net.state_dict().keys())[0] == "layers.0.ff1.fn.fn.net.0.weight"
