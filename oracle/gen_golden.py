@@ -653,6 +653,77 @@ def gen_conformer():
     print("conformer.npz", len(out), "arrays")
 
 
+def gen_btse():
+    """Reference model/wav2vec2_btse/model.py::Model (BASELINE configs[4]) — imported with a stand-in for the `biosegment` package (a
+    dangling symlink in the reference: only the tokeniser class `Wav2bioCNN` lives there, and Model.forward takes the bio tokens as an
+    argument) and the SSL encoder injected as identity, as for the other plugins.  Parameters by oracle/aasist.py::fill_state over the
+    reference's own state-dict shapes.  model.train() with every Dropout p = 0 (the plugin has no BatchNorm: train == eval then).
+    Cases: `cat` (conf-5-btse-trans64.yaml: concat, lengths 17 / 9 / 1 / 17 of 17 — full, padded tail, length 1), `add` (is_add with
+    bio_out = 128, the only width at which the reference's fc2 accepts the sum), `short` (3 tokens < window + 1: the slice branch of
+    _get_relative_embeddings), `one` (a single token)."""
+    import importlib
+    from oracle.aasist import fill_state
+    st = types.ModuleType("model.wav2vec2_btse.biosegment")
+    st.Wav2bioCNN = type("Wav2bioCNN", (), {"__init__": lambda self, device=None: None})
+    sys.modules["model.wav2vec2_btse.biosegment"] = st
+    M = importlib.import_module("model.wav2vec2_btse.model")          # `model.wav2vec2_btse` the attribute is the class (model/__init__.py:2)
+    BK = importlib.import_module("model.wav2vec2_btse.backend")
+    E = 16
+
+    class Enc(torch.nn.Module):
+        out_dim = E
+
+        def extract_feat(self, x, is_train=True):
+            return x
+
+    BK.SSLModel = lambda device: Enc()
+    base = dict(flag_fix_ssl=False, contra_mode="all", loss_type=1, bio_out=64, nb_classes=2, is_add=False, bio_hid=256, n_heads=4,
+                pf_dim=128, n_layers=3, n_bios=3, bio_dim=32)
+    cases = {"cat": dict(args={}, B=4, T=20, L=17, lens=[17, 9, 1, 17]),
+             "add": dict(args=dict(is_add=True, bio_out=128), B=3, T=7, L=12, lens=[12, 12, 5]),
+             "short": dict(args={}, B=2, T=5, L=3, lens=[3, 2]),
+             "one": dict(args={}, B=2, T=6, L=1, lens=[1, 1])}
+    out = {}
+    for ci, (name, c) in enumerate(cases.items()):
+        args = dict(base, **c["args"])
+        m = M.Model(args, "cpu")
+        sd = m.state_dict()
+        filled = fill_state({k: tuple(v.shape) for k, v in sd.items()}, seed=41 + ci)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        rs = np.random.RandomState(200 + ci)
+        x0 = rs.standard_normal((c["B"], c["T"], E)).astype(np.float32)
+        bio = rs.randint(0, 3, size=(c["B"], c["L"])).astype(np.int32)
+        lens = np.array(c["lens"], dtype=np.int32)
+        x = torch.from_numpy(x0).clone().requires_grad_(True)
+        logp, feats, b = m(x, torch.from_numpy(bio), torch.from_numpy(lens))
+        wl, wf, wb = (rs.standard_normal(tuple(t.shape)).astype(np.float32) for t in (logp, feats, b))
+        (logp * torch.from_numpy(wl)).sum().add((feats * torch.from_numpy(wf)).sum()).add((b * torch.from_numpy(wb)).sum()).backward()
+        out[name + ":keys"] = np.array(list(sd.keys()))
+        out[name + ":shapes"] = np.array([repr(tuple(v.shape)) for v in sd.values()])
+        out[name + ":args"] = np.array(repr(sorted(c["args"].items())))
+        out[name + ":seed"] = np.array(41 + ci)
+        out.update({name + ":x": x0, name + ":bio": bio, name + ":lens": lens, name + ":w_logp": wl, name + ":w_feats": wf, name + ":w_b": wb,
+                    name + ":logp": logp.detach().numpy(), name + ":feats": feats.detach().numpy(), name + ":b": b.detach().numpy(),
+                    name + ":grad_x": x.grad.numpy()})
+        for k, p_ in m.named_parameters():
+            if p_.grad is None:
+                assert "m_utt_level" in k, k          # its logits are discarded (model.py:324): no gradient, AdamW leaves it alone
+                continue
+            g = p_.grad.numpy()
+            if g.size <= 4224:
+                out[name + ":grad:" + k] = g
+            else:
+                out[name + ":gradfp:" + k] = np.concatenate([[np.sqrt((g.astype(np.float64) ** 2).sum()), g.astype(np.float64).sum()], g.flatten()[:16]]).astype(np.float64)
+        m.is_train = False
+        assert torch.equal(m(torch.from_numpy(x0), torch.from_numpy(bio), torch.from_numpy(lens)), logp.detach())   # eval contract: log-probs only
+    np.savez_compressed(os.path.join(OUT, "btse.npz"), **out)
+    print("btse.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])     # e.g. `python oracle/gen_golden.py aasist` regenerates one fixture
@@ -661,6 +732,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop), ("conformer", gen_conformer)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop), ("conformer", gen_conformer), ("btse", gen_btse)):
         if want(name):
             fn()

@@ -1,0 +1,95 @@
+"""Pins the ORACLE restatement of the wav2vec2_btse plugin (oracle/btse.py, plain torch on the CPU) to the reference's own
+model/wav2vec2_btse/model.py::Model via tests/golden/btse.npz (oracle/gen_golden.py::gen_btse: the reference imported with a stand-in
+for its absent `biosegment` tokeniser package, the SSL encoder injected as identity).  fp32 on both sides, 2e-4 of each tensor's
+largest magnitude; the same comparison in float64 bounds the restatement's own round-off.  The product head (scl_amd/btse_head.py,
+HIP kernels) meets the same vectors on the GPU in tests/test_btse_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import btse as OB
+from oracle.aasist import fill_state
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "btse.npz"))
+CASES = ["cat", "add", "short", "one"]
+TOL = 2e-4
+
+
+def case_args(case):
+    return OB.default_args(**dict(eval(str(G[case + ":args"]))))
+
+
+def case_state(case, dtype=torch.float32):
+    args = case_args(case)
+    shapes = OB.state_shapes(args, 16)
+    assert list(shapes) == list(G[case + ":keys"]), "state-dict keys / order differ from the reference's"
+    assert [repr(tuple(v)) for v in shapes.values()] == list(G[case + ":shapes"])
+    filled = fill_state(shapes, seed=int(G[case + ":seed"]))
+    return args, {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in filled.items()}
+
+
+def _close(a, b, name, tol=TOL, floor=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, name
+    err = np.abs(a - b).max() / max(np.abs(b).max(), floor)
+    assert err < tol, "%s: rel err %.3e" % (name, err)
+
+
+def check_grads(case, grads, tol=TOL):
+    """grads: {state-dict key: array}.  Whole tensors or (norm, sum, first 16 values) fingerprints, as the generator stored them."""
+    n = 0
+    # a gradient tensor that is round-off around zero on both sides (e.g. layer 0's key projection in `short`: 3e-9 against 0.8 for
+    # the value projection) is measured against 1e-4 of the case's largest gradient instead of against itself
+    floor = 1e-4 * max(np.abs(G[k]).max() for k in G.files if k.startswith(case + ":grad:"))
+    for key in G.files:
+        if key.startswith(case + ":grad:"):
+            k = key.split(":", 2)[2]
+            if k.endswith("conv_k.bias"):
+                # soft-max is invariant to a constant added to every key (q_i . b_k is the same for all j, masked entries are
+                # REPLACED by -1e4): this gradient is exactly zero in exact arithmetic and pure round-off on both sides — bounded
+                # against the query bias gradient of the same layer instead of compared
+                scale = np.abs(G[key.replace("conv_k.bias", "conv_q.bias")]).max()
+                assert np.abs(G[key]).max() < 1e-4 * max(scale, 1e-6) or scale == 0, k
+                assert np.abs(np.asarray(grads[k])).max() <= max(20 * tol * scale, 1e-30) or scale == 0, k
+            else:
+                _close(grads[k], G[key], k, tol, floor)
+            n += 1
+        elif key.startswith(case + ":gradfp:"):
+            k = key.split(":", 2)[2]
+            g = np.asarray(grads[k], dtype=np.float64)
+            fp = np.concatenate([[np.sqrt((g ** 2).sum()), g.sum()], g.flatten()[:16]])
+            ref = G[key]
+            assert abs(fp[0] - ref[0]) < tol * ref[0], k
+            assert abs(fp[1] - ref[1]) < tol * max(ref[0], 1e-6), k
+            _close(fp[2:], ref[2:], k, tol * max(1.0, np.abs(g).max() / max(np.abs(ref[2:]).max(), 1e-9)))
+            n += 1
+    return n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case, dtype):
+    args, sd = case_state(case, dtype)
+    x = torch.from_numpy(G[case + ":x"]).to(dtype).requires_grad_(True)
+    logp, feats, b = OB.forward(sd, args, x, torch.from_numpy(G[case + ":bio"]), torch.from_numpy(G[case + ":lens"]))
+    w = lambda n: torch.from_numpy(G[case + ":" + n]).to(dtype)
+    ((logp * w("w_logp")).sum() + (feats * w("w_feats")).sum() + (b * w("w_b")).sum()).backward()
+    _close(logp.detach(), G[case + ":logp"], "logp")
+    _close(feats.detach(), G[case + ":feats"], "feats")
+    _close(b.detach(), G[case + ":b"], "b")
+    _close(x.grad, G[case + ":grad_x"], "grad_x")
+    grads = {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}
+    assert not any("m_utt_level" in k for k in grads)          # model.py:324 discards the MLP's own logits
+    assert check_grads(case, grads) == len(sd) - 2
+
+
+def test_short_sequences_score_zero():
+    """model.py:236 reads the LAST padded position times its mask: an utterance shorter than the batch's longest gets an all-zero
+    bio score (and no gradient reaches the bio encoder from it)."""
+    args, sd = case_state("cat")
+    s = OB.bio_encoder(sd, args, torch.from_numpy(G["cat:bio"]), torch.from_numpy(G["cat:lens"]))
+    lens = G["cat:lens"]
+    assert (s[lens < lens.max()] == 0).all() and (s[lens == lens.max()].abs().sum(1) > 0).all()
+    assert np.abs(G["cat:b"][lens < lens.max(), 128:]).max() == 0
