@@ -617,6 +617,42 @@ int scl_relpos_softmax_fwd(const float* S, const float* R, const uint8_t* mask, 
 int scl_relpos_softmax_bwd(const float* P, const float* dP, const uint8_t* mask, float* dS, float* dR, int B, int H, int n, int ldP, int ldR,
                            float scale, void* stream);
 
+/* ---- BTSE plugin (csrc/btse.hip; BASELINE.json configs[4]: model/wav2vec2_btse/model.py:210-238,321-343) ---------------------------
+ * The "bio" branch of the reference's wav2vec2_btse Model: bioEncoderTransformersmall = Embedding(n_bios, 32) * sqrt(32) ->
+ * transformer.Encoder (transformer.py:17-52: n_layers post-LN layers of MultiHeadAttention with window_size 4 relative keys AND values
+ * shared by the heads, :105-260, and a kernel-1 ReLU FFN, :261-306; LayerNorm over channels modules.py:27-39) -> Conv1d(32, bio_out, 1)
+ * -> the LAST padded position times its mask (model.py:234-236).  One workgroup per utterance runs the whole encoder: K / V of the
+ * layer in LDS, one wave per query row (the L x L scores never leave registers), weights in registers per phase, everything fp32.
+ * Shapes served: bio_dim 32, 4 heads of 8, pf_dim 128, window 4, 1..8 layers, 1 <= L <= 512 tokens, bio_out <= 256; anything else is
+ * refused (SCL_EUNSUPPORTED) — scl_btse_bio_supported answers without launching.
+ *   lw[l][]: Wq bq Wk bk Wv bv Wo bo emb_rel_k emb_rel_v gamma1 beta1 W1 c1 W2 c2 gamma2 beta2 of layer l, torch layouts ([out][in] rows,
+ *            emb_rel_* [9][8]); go[l][] / go_emb / go_Ws / go_bs: element offsets of their gradients inside one slab row.
+ *   bio [B][L] int32 tokens (clamped to [0, n_bios)), lens [B] int32; out [B][out_ld] f32: columns 0..bio_out-1 of row b are written
+ *   (out may point into the concatenated [emb | bio] row, model.py:333).
+ *   ws: f32 scratch, scl_btse_bio_ws_floats(n_layers, L) per utterance (the forward leaves every layer's activations there for the
+ *   backward; floats [n_layers * 392 * L, +32 L) of an utterance hold the encoder's output x * mask, transformer.py:51).
+ * scl_btse_bio_bwd: d_out [B][dout_ld] -> slab [B][slab_ld]: row b = utterance b's contribution to every parameter gradient at the
+ * go_* offsets (zeros where the read-out position is padding: model.py:236 multiplies by the mask); sum the rows in index order
+ * (scl_reduce_slabs_f32) for the batch gradient. */
+typedef struct SclBtseBio {
+    const float* emb; const float* lw[8][18]; const float* Ws; const float* bs;
+    const int32_t* bio; const int32_t* lens;
+    float* ws; float* out; const float* d_out; float* slab;
+    int64_t ws_stride, slab_ld;
+    int32_t go[8][18]; int32_t go_emb, go_Ws, go_bs;
+    int32_t n_layers, n_bios, bio_out, L, B, out_ld, dout_ld, bio_dim, n_heads, pf_dim, window;
+} SclBtseBio;
+int scl_btse_bio_supported(int bio_dim, int n_heads, int pf_dim, int n_layers, int window, int bio_out, int L);
+int64_t scl_btse_bio_ws_floats(int n_layers, int L);
+int scl_btse_bio_fwd(const SclBtseBio* p, void* stream);
+int scl_btse_bio_bwd(const SclBtseBio* p, void* stream);
+/* model.py:329-335, the join in front of fc2.  is_add == 0: b[r] = [emb[r] (C) | s[r] (bio_out)] — emb is copied, the s columns are
+ * expected in place already (scl_btse_bio_fwd writes them), bwd: demb = db[:, :C], ds = db[:, C:].  is_add != 0: b = fc1(emb) + s
+ * (fc1: [bio_out][C]); bwd also writes dW1 / db1.  All f32, B <= 4096. */
+int scl_btse_join_fwd(const float* emb, const float* s, const float* W1, const float* b1, float* b, int B, int C, int bio_out, int is_add, void* stream);
+int scl_btse_join_bwd(const float* db, const float* emb, const float* W1, float* demb, float* ds, float* dW1, float* db1, int B, int C, int bio_out,
+                      int is_add, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

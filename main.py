@@ -27,8 +27,10 @@ from torch.utils.data import DataLoader, Subset
 from model.wav2vec2_aasist import Model as wav2vec2_aasist
 from model.wav2vec2_linear_nll import Model as wav2vec2_linear_nll
 from model.wav2vec2_resnet_nll import Model as wav2vec2_resnet_nll
+from model.wav2vec2_btse import wav2vec2_btse
 
-MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll, "wav2vec2_aasist": wav2vec2_aasist, "wav2vec2_resnet_nll": wav2vec2_resnet_nll}
+MODEL_REGISTRY = {"wav2vec2_linear_nll": wav2vec2_linear_nll, "wav2vec2_aasist": wav2vec2_aasist, "wav2vec2_resnet_nll": wav2vec2_resnet_nll,
+                  "wav2vec2_btse": wav2vec2_btse}
 
 
 class EarlyStop:

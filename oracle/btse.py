@@ -109,8 +109,9 @@ def attention(sd, pre, x, attn_mask, n_heads):
     return F.linear(out, sd[pre + "conv_o.weight"][:, :, 0], sd[pre + "conv_o.bias"])   # :146
 
 
-def bio_encoder(sd, args, bio, bio_lengths):
-    """model.py:227-238 -> [B, bio_out]: the scoring conv's output at the LAST (padded) position, times its mask."""
+def bio_encoder(sd, args, bio, bio_lengths, return_x=False):
+    """model.py:227-238 -> [B, bio_out]: the scoring conv's output at the LAST (padded) position, times its mask
+    (return_x: also the encoder output x * mask [B, L, D], transformer.py:51)."""
     D, H, NL = args["bio_dim"], args["n_heads"], args["n_layers"]
     B, L = bio.shape
     e = sd["bioScoring.bio_embedding.weight"][bio.long()] * math.sqrt(D)                # :228
@@ -128,7 +129,7 @@ def bio_encoder(sd, args, bio, bio_lengths):
         x = F.layer_norm(x + y, (D,), sd[p + "norm_layers_2.%d.gamma" % i], sd[p + "norm_layers_2.%d.beta" % i], LN_EPS)
     x = x * m3                                                                          # transformer.py:51
     s = F.linear(x, sd["bioScoring.bio_scoring.weight"][:, :, 0], sd["bioScoring.bio_scoring.bias"]) * m3   # model.py:234
-    return s[:, -1, :]                                                                  # :236
+    return (s[:, -1, :], x) if return_x else s[:, -1, :]                                # :236
 
 
 def forward(sd, args, x_ssl, bio, bio_lengths, dropout_masks=None):

@@ -89,13 +89,14 @@ def load_pretrained_into(model, path):
     tensors, probs = read_fairseq_checkpoint(path)
     own = model.state_dict()
     sd, skipped = {}, []
+    prefix = getattr(model, "front_prefix", "") + PREFIX        # wav2vec2_btse keeps its encoder under backend.ssl_model.model.
     for k, v in tensors.items():
-        name = PREFIX + k
+        name = prefix + k
         if name in own and tuple(own[name].shape) == tuple(v.shape):
             sd[name] = v.float()
         else:
             skipped.append(k)
-    missing = [k for k in own if k.startswith(PREFIX) and k not in sd]
+    missing = [k for k in own if k.startswith(prefix) and k not in sd]
     if missing:
         raise ValueError("pre-trained checkpoint %s lacks %d encoder tensors of this architecture (first: %s)" % (path, len(missing), missing[:3]))
     model.load_state_dict(sd, strict=False)

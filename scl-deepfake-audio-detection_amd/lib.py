@@ -54,6 +54,15 @@ class SclRsConv(ctypes.Structure):
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
 
 
+class SclBtseBio(ctypes.Structure):
+    """include/scl_hip.h SclBtseBio: the bio transformer of the wav2vec2_btse plugin (csrc/btse.hip)."""
+    _fields_ = [("emb", ctypes.c_void_p), ("lw", (ctypes.c_void_p * 18) * 8), ("Ws", ctypes.c_void_p), ("bs", ctypes.c_void_p),
+                ("bio", ctypes.c_void_p), ("lens", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("d_out", ctypes.c_void_p), ("slab", ctypes.c_void_p), ("ws_stride", ctypes.c_int64), ("slab_ld", ctypes.c_int64),
+                ("go", (ctypes.c_int32 * 18) * 8), ("go_emb", ctypes.c_int32), ("go_Ws", ctypes.c_int32), ("go_bs", ctypes.c_int32)] + \
+               [(n, ctypes.c_int32) for n in ("n_layers", "n_bios", "bio_out", "L", "B", "out_ld", "dout_ld", "bio_dim", "n_heads", "pf_dim", "window")]
+
+
 class SclGemmDesc(ctypes.Structure):
     _fields_ = [("A", SclOperand), ("B", SclOperand), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
                 ("R", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -229,6 +238,13 @@ def _protos():
         "scl_relpos_scatter_grad": ([_vp, _vp, _i32, _i32, _i32, _vp], _i32),
         "scl_relpos_softmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
         "scl_relpos_softmax_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp], _i32),
+        # btse.hip
+        "scl_btse_bio_supported": ([_i32, _i32, _i32, _i32, _i32, _i32, _i32], _i32),
+        "scl_btse_bio_ws_floats": ([_i32, _i32], _i64),
+        "scl_btse_bio_fwd": ([P(SclBtseBio), _vp], _i32),
+        "scl_btse_bio_bwd": ([P(SclBtseBio), _vp], _i32),
+        "scl_btse_join_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_btse_join_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], _i32),
     }
 
 

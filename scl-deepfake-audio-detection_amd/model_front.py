@@ -55,6 +55,7 @@ class _HeadRunner(nn.Module):
 
 class FrontHeadModel(nn.Module):
     flag_fix_ssl = False
+    front_prefix = ""        # module path of `ssl_model` / `LL` in the state dict ("backend." for wav2vec2_btse, backend.py:31-33)
 
     def _build_head(self, args):
         raise NotImplementedError
@@ -84,9 +85,9 @@ class FrontHeadModel(nn.Module):
         torch.set_rng_state(rng_state)
         head_params = list(head.named_parameters())
         specs = param_specs(self.cfg) + [("LL.weight", (FEAT_DIM, self.cfg.embed), True), ("LL.bias", (FEAT_DIM,), True)] + \
-            [(n, tuple(p.shape), True) for n, p in head_params]
+            [(n, tuple(p.shape), n not in getattr(head, "frozen_names", ())) for n, p in head_params]      # frozen: no gradient in the reference
         self.P = FlatParams(specs, self.device)
-        self._head_lo = self.P.off(head_params[0][0])
+        self._head_lo = self.P.off(next(n for n, _ in head_params if n not in getattr(head, "frozen_names", ())))
         init_parameters_(self.P, self.cfg, seed)
         for n, p in head_params:
             self.P.f32(n).copy_(p.detach().to(self.device))
@@ -99,7 +100,7 @@ class FrontHeadModel(nn.Module):
             self.add_module(n, child)
         for name, p in self.P.params.items():
             if name.startswith("ssl_model.") or name.startswith("LL."):
-                register_by_name(self, name, p)
+                register_by_name(self, self.front_prefix + name, p)
             else:
                 mod = self
                 parts = name.split(".")

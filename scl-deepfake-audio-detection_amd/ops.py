@@ -648,3 +648,28 @@ def relpos_softmax_fwd(S, R, mask, P, B, H, n, ldS, ldR, ldP, scale):
 
 def relpos_softmax_bwd(P, dP, mask, dS, dR, B, H, n, ldP, ldR, scale):
     _call("scl_relpos_softmax_bwd", _p(P), _p(dP), _p(mask), _p(dS), _p(dR), B, H, n, ldP, ldR, float(scale), _stream())
+
+
+# ---- csrc/btse.hip ------------------------------------------------------------------------------------------------------------------------
+def btse_bio_supported(bio_dim, n_heads, pf_dim, n_layers, window, bio_out, n_tokens):
+    return bool(L.load().scl_btse_bio_supported(bio_dim, n_heads, pf_dim, n_layers, window, bio_out, n_tokens))
+
+
+def btse_bio_ws_floats(n_layers, L_tokens):
+    return L.load().scl_btse_bio_ws_floats(n_layers, L_tokens)
+
+
+def btse_bio_fwd(desc):
+    return _call("scl_btse_bio_fwd", ctypes.byref(desc), _stream(), keep=desc)
+
+
+def btse_bio_bwd(desc):
+    return _call("scl_btse_bio_bwd", ctypes.byref(desc), _stream(), keep=desc)
+
+
+def btse_join_fwd(emb, s, W1, b1, b, B, C, bio_out, is_add):
+    _call("scl_btse_join_fwd", _p(emb), _p(s), _p(W1), _p(b1), _p(b), B, C, bio_out, int(is_add), _stream())
+
+
+def btse_join_bwd(db, emb, W1, demb, ds, dW1, db1, B, C, bio_out, is_add):
+    _call("scl_btse_join_bwd", _p(db), _p(emb), _p(W1), _p(demb), _p(ds), _p(dW1), _p(db1), B, C, bio_out, int(is_add), _stream())

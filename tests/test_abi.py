@@ -34,6 +34,9 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(lib.SclGemmDesc) == 2 * 56 + 4 * 8 + 5 * 8 + 8 * 4 + 4 * 4 + 8 + 8  # pointers, strides, ints, floats/seed/pad, colsum_part
     assert lib.SclGemmDesc.colsum_part.offset == ctypes.sizeof(lib.SclGemmDesc) - 8
     assert lib.SclGemmDesc.C.offset == 112 and lib.SclGemmDesc.flags.offset == 112 + 32 + 40 + 32
+    # SclBtseBio: 147 + 6 pointers, two int64, 147 + 11 int32
+    assert ctypes.sizeof(lib.SclBtseBio) == 153 * 8 + 16 + 158 * 4 and lib.SclBtseBio.go.offset == 153 * 8 + 16
+    assert lib.SclBtseBio.n_layers.offset == 153 * 8 + 16 + 147 * 4 and lib.SclBtseBio.bio.offset == 147 * 8
 
 
 def test_argument_validation_returns_error_codes_without_touching_the_gpu():

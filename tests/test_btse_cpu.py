@@ -53,6 +53,10 @@ def check_grads(case, grads, tol=TOL):
                 scale = np.abs(G[key.replace("conv_k.bias", "conv_q.bias")]).max()
                 assert np.abs(G[key]).max() < 1e-4 * max(scale, 1e-6) or scale == 0, k
                 assert np.abs(np.asarray(grads[k])).max() <= max(20 * tol * scale, 1e-30) or scale == 0, k
+            elif k.endswith("conv_k.weight"):
+                # the key projection's gradient is what survives the same cancellation (only the DIFFERENCES between keys matter to a
+                # soft-max): 100x smaller than the query / value gradients of its layer, so fp32 round-off is 5x larger relative to it
+                _close(grads[k], G[key], k, 5 * tol, floor)
             else:
                 _close(grads[k], G[key], k, tol, floor)
             n += 1
