@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (configs[2]: 64; configs[1]: 32)")
     ap.add_argument("--samples", type=int, default=64000)
     ap.add_argument("--rawboost", type=int, default=5, help="RawBoost algo applied on the GPU inside the step (configs[2]: 5; 0 = off)")
-    ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist", "wav2vec2_resnet_nll"], default="wav2vec2_linear_nll",
-                    help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet are extra workloads")
+    ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist", "wav2vec2_resnet_nll", "wav2vec2_btse"], default="wav2vec2_linear_nll",
+                    help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet / btse (configs[3], configs[4]) are extra workloads")
+    ap.add_argument("--bio-tokens", type=int, default=199, help="wav2vec2_btse: synthetic bio tokens per utterance (the reference's tokeniser is absent)")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -74,8 +75,12 @@ def launch_ranks(args):
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else None))
-    out = procs[0].stdout.read().decode("utf-8", "replace")
-    # a rank that dies before the rendezvous leaves the others blocked in it: once one child has failed, the rest get a grace period
+    # rank 0's stdout is drained on a thread, so that the poll loop below runs WHILE the ranks run: a rank (any rank) that dies before
+    # the rendezvous leaves the others blocked in it — once one child has failed, the rest get a grace period and are killed
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     codes = [None] * len(procs)
     deadline = None
     while any(c is None for c in codes):
@@ -83,13 +88,15 @@ def launch_ranks(args):
             if codes[i] is None:
                 codes[i] = p.poll()
         if any(c not in (None, 0) for c in codes) and deadline is None:
-            deadline = time.time() + 30.0
+            deadline = time.time() + float(os.environ.get("SCL_BENCH_GRACE_S", "30"))
         if deadline is not None and time.time() > deadline:
             for i, p in enumerate(procs):
                 if codes[i] is None:
                     p.kill()                      # exactly the children started above
                     codes[i] = p.wait()
         time.sleep(0.05)
+    reader.join(10.0)
+    out = b"".join(chunks).decode("utf-8", "replace")
     lines = [l for l in out.splitlines() if l.strip()]
     for l in lines[:-1]:
         print(l)
@@ -186,6 +193,8 @@ def main():
         from scl_amd.model_aasist import Model
     elif args.model == "wav2vec2_resnet_nll":
         from scl_amd.model_resnet import Model
+    elif args.model == "wav2vec2_btse":
+        from scl_amd.model_btse import Model
     else:
         from scl_amd.model_linear import Model
     from scl_amd.optim import FusedAdamW
@@ -206,6 +215,9 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     x = (0.1 * torch.randn(B, L, generator=g)).to(dev)       # resident in HBM before the timed region
     y = torch.tensor(([1] * ((5 * B + 10) // 11) + [0] * B)[:B], device=dev)
+    fwd_extra = ()
+    if args.model == "wav2vec2_btse":       # bio tokens are an input of the plugin (model/wav2vec2_btse/model.py:321); synthetic, resident like x
+        fwd_extra = (torch.randint(0, 3, (B, args.bio_tokens), generator=g, dtype=torch.int32).to(dev), torch.full((B,), args.bio_tokens, dtype=torch.int32, device=dev))
     rb_args = None
     if args.rawboost:
         from scl_amd.datautils_common import default_rawboost_args
@@ -213,7 +225,7 @@ def main():
 
     def step():
         xs = augment.rawboost_batch(x, rb_args, args.rawboost, 16000, sampler="fast") if args.rawboost else x
-        out, feats, emb = model(xs)
+        out, feats, emb = model(xs, *fwd_extra)
         losses = model.loss(out, feats, emb, y, conf)
         total = None
         for v in losses.values():

@@ -129,12 +129,15 @@ def design_notch_filters(fc, bw, c, G, fs):
     win = 0.54 - 0.46 * np.cos(2.0 * np.pi * idx / np.maximum(c[..., None] - 1, 1))   # symmetric Hamming of length c
     h = np.where(valid, h * win, 0.0)
     h = h / h.sum(axis=-1, keepdims=True)                       # unity gain at DC
-    nfft = 1024
-    spec = np.fft.rfft(h, nfft, axis=-1).prod(axis=1)           # product of the nBands sections
-    b = np.fft.irfft(spec, nfft, axis=-1)                       # [n, 1024]; exact linear convolution (total length <= 501)
-    Hmag = np.abs(np.fft.rfft(b, nfft, axis=-1)[:, :512]).max(axis=-1)   # freqz(b, 1, fs): 512 points on [0, fs/2)
-    b = (10.0 ** (G / 20.0) / Hmag)[:, None] * b
     lens = c.sum(axis=1) - nb + 1
+    nfft = 1024
+    while nfft < int(lens.max()):                               # non-default --nBands / --maxCoeff: the circular product must not alias
+        nfft *= 2
+    spec = np.fft.rfft(h, nfft, axis=-1).prod(axis=1)           # product of the nBands sections
+    b = np.fft.irfft(spec, nfft, axis=-1)                       # [n, nfft]; exact linear convolution (total length <= nfft; 501 by default)
+    # freqz(b, 1, fs): 512 points on [0, fs/2) = every (nfft / 1024)-th bin of the nfft-point transform
+    Hmag = np.abs(np.fft.rfft(b, nfft, axis=-1)[:, ::nfft // 1024][:, :512]).max(axis=-1)
+    b = (10.0 ** (G / 20.0) / Hmag)[:, None] * b
     return [b[i, :lens[i]].copy() for i in range(n)]
 
 

@@ -10,6 +10,7 @@ dropout probabilities and the training flag.  Dropout masks are counter hashes o
 training and recomputed in the backward; in eval mode BatchNorm uses the running statistics.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -92,19 +93,44 @@ def _acquire(head, B, nS, nT, dev, hold):
     for pl in _PLANS:
         if pl.key == key and pl.dev == dev and not pl.busy:
             pl.busy = hold
+            pl.gen = getattr(pl, "gen", 0) + 1
             return pl
+    # never hand out a plan whose backward is still pending (its saved maps, statistics, dropout seeds and recorded pointers belong to
+    # that node): a further forward of the same shape gets a fresh plan, up to a hard cap.  Plans of nodes that are freed without a
+    # backward are released by the finalizer _hold() attaches to the node.
     same = [pl for pl in _PLANS if pl.key == key and pl.dev == dev]
-    if len(same) >= 3:
-        pl = same[0]
-        _PLANS.remove(pl)
-        _PLANS.append(pl)
-        pl.busy = hold
-        return pl
-    if len(_PLANS) >= 8:
-        _PLANS.pop(0)
+    if len(same) >= MAX_LIVE_PLANS:
+        raise RuntimeError("%d forward passes of shape %r are waiting for their backward; run the backwards (or drop the graphs) "
+                           "before another forward of this shape" % (len(same), key))
+    idle = [pl for pl in _PLANS if not pl.busy]
+    if len(_PLANS) >= 8 and idle:
+        _PLANS.remove(idle[0])
     pl = _Plan(head, B, nS, nT, dev)
     pl.busy = hold
+    pl.gen = 1
     _PLANS.append(pl)
+    return pl
+
+
+MAX_LIVE_PLANS = 16
+
+
+def _release(pl, gen):
+    if pl.gen == gen:
+        pl.busy = False
+
+
+def _hold(ctx, pl):
+    """Ties the plan to the autograd node: generation stamp for the backward's ownership check, release when the node dies unused."""
+    ctx.pl, ctx.gen = pl, pl.gen
+    if pl.busy:
+        weakref.finalize(ctx, _release, pl, pl.gen)
+
+
+def _owned(ctx):
+    pl = ctx.pl
+    if pl.gen != ctx.gen:
+        raise RuntimeError("this node's plan was re-used by a later forward (generation %d, node holds %d): its saved activations are gone" % (pl.gen, ctx.gen))
     return pl
 
 
@@ -445,12 +471,13 @@ class _GraphFn(torch.autograd.Function):
     def forward(ctx, e_S, e_T, head, training, hold, *params):
         pl = _acquire(head, e_S.shape[0], e_S.shape[1], e_T.shape[1], e_S.device, hold)
         logits, hidden = _forward(pl, head, e_S.contiguous().float(), e_T.contiguous().float(), training)
-        ctx.pl, ctx.head, ctx.training = pl, head, training
+        _hold(ctx, pl)
+        ctx.head, ctx.training = head, training
         return logits, hidden
 
     @staticmethod
     def backward(ctx, d_logits, d_hidden):
-        pl = ctx.pl
+        pl = _owned(ctx)
         try:
             deS, deT = _backward(pl, ctx.head, d_logits, d_hidden, ctx.training)
         finally:

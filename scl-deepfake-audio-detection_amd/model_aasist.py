@@ -12,10 +12,17 @@ returns the triple main.py and Model.loss need — feats is the LL output, exact
 """
 from .aasist_head import UPSTREAM_AASIST, AasistHead
 from .model_front import FrontHeadModel
-from .model_linear import loss_custom
+from .model_linear import dropout_stream_seed, loss_custom
 
 
 class Model(FrontHeadModel):
+    def __init__(self, args, device, is_train=True, w2v_cfg=None, seed=0, rank=0):
+        super().__init__(args, device, is_train=is_train, w2v_cfg=w2v_cfg, seed=seed, rank=rank)
+        # the fused graph module draws its dropout masks (input_drop, GraphPool, drop_way, read-out) from a counter-hash stream:
+        # start it from --seed and the data-parallel rank, like the encoder's (model_front.py)
+        from . import graph
+        graph.seed(dropout_stream_seed(seed, rank) ^ 0x3C6EF372)
+
     def _build_head(self, args):
         return AasistHead(args.get("aasist") or UPSTREAM_AASIST)
 

@@ -123,15 +123,18 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model.optimizer_stepped(bf16_fresh=True)
         return None
 
-    def state_dict(self):
+    def consolidate_state(self):
+        """COLLECTIVE (every rank must call it): after sharded steps (SCL_DP_MODE=shard) a rank has updated the moments of its own
+        shards only (the buffers are full-size on every rank: what the mode divides by the world size is the optimizer's HBM traffic
+        and arithmetic, not its allocation) — collect the owners' values, so that a following state_dict() holds the whole optimizer.
+        A no-op in the all-reduce mode.  state_dict() itself is local, so `if rank == 0: torch.save(opt.state_dict())` cannot deadlock."""
         gs = self.grad_sync
         if gs is not None and getattr(gs, "mode", "allreduce") == "shard" and gs.active:
-            # sharded step: a rank has updated the moments of its own shards only (the buffers are full-size on every rank: what the mode
-            # divides by the world size is the optimizer's HBM traffic and arithmetic, not its allocation) — collect the owners' values so
-            # that the saved state is the whole optimizer on every rank
             lo, hi = self.model.trainable_range() if hasattr(self.model, "trainable_range") else (0, self.P.n_train)
             gs.gather_params(self.exp_avg[lo:hi])
             gs.gather_params(self.exp_avg_sq[lo:hi])
+
+    def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 

@@ -13,6 +13,7 @@ still updated in training — here from the statistics the previous block's conv
 computed (it is round-off around zero: BatchNorm cancels the bias) because the reference computes it.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -110,19 +111,44 @@ def _acquire(B, H, W, chans, dev, hold):
     for pl in _PLANS:
         if pl.key == key and pl.dev == dev and not pl.busy:
             pl.busy = hold
+            pl.gen = getattr(pl, "gen", 0) + 1
             return pl
+    # never hand out a plan whose backward is still pending (its saved maps, statistics, dropout seeds and recorded pointers belong to
+    # that node): a further forward of the same shape gets a fresh plan, up to a hard cap.  Plans of nodes that are freed without a
+    # backward are released by the finalizer _hold() attaches to the node.
     same = [pl for pl in _PLANS if pl.key == key and pl.dev == dev]
-    if len(same) >= 3:          # forwards whose backward never came (eval-style use under grad mode): recycle the oldest
-        pl = same[0]
-        _PLANS.remove(pl)
-        _PLANS.append(pl)
-        pl.busy = hold
-        return pl
-    if len(_PLANS) >= 8:
-        _PLANS.pop(0)
+    if len(same) >= MAX_LIVE_PLANS:
+        raise RuntimeError("%d forward passes of shape %r are waiting for their backward; run the backwards (or drop the graphs) "
+                           "before another forward of this shape" % (len(same), key))
+    idle = [pl for pl in _PLANS if not pl.busy]
+    if len(_PLANS) >= 8 and idle:
+        _PLANS.remove(idle[0])
     pl = _Plan(B, H, W, chans, dev)
     pl.busy = hold
+    pl.gen = 1
     _PLANS.append(pl)
+    return pl
+
+
+MAX_LIVE_PLANS = 16
+
+
+def _release(pl, gen):
+    if pl.gen == gen:
+        pl.busy = False
+
+
+def _hold(ctx, pl):
+    """Ties the plan to the autograd node: generation stamp for the backward's ownership check, release when the node dies unused."""
+    ctx.pl, ctx.gen = pl, pl.gen
+    if pl.busy:
+        weakref.finalize(ctx, _release, pl, pl.gen)
+
+
+def _owned(ctx):
+    pl = ctx.pl
+    if pl.gen != ctx.gen:
+        raise RuntimeError("this node's plan was re-used by a later forward (generation %d, node holds %d): its saved activations are gone" % (pl.gen, ctx.gen))
     return pl
 
 
@@ -403,12 +429,13 @@ class _ResStackFn(torch.autograd.Function):
         chans = [blocks[0].conv1.weight.shape[1]] + [b.conv1.weight.shape[0] for b in blocks]
         pl = _acquire(B, H, W, chans, x0.device, hold)
         out = _forward(pl, x0.contiguous().float(), blocks, training)
-        ctx.pl, ctx.blocks, ctx.training = pl, blocks, training
+        _hold(ctx, pl)
+        ctx.blocks, ctx.training = blocks, training
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        pl = ctx.pl
+        pl = _owned(ctx)
         try:
             dx0 = _backward(pl, d_out, ctx.blocks, ctx.training, ctx.needs_input_grad[0])
         finally:
@@ -423,12 +450,13 @@ class _StackPoolFn(torch.autograd.Function):
         chans = [blocks[0].conv1.weight.shape[1]] + [b.conv1.weight.shape[0] for b in blocks]
         pl = _acquire(B, H, W, chans, x0.device, hold)
         e_S, e_T = _forward(pl, x0.contiguous().float(), blocks, training, attn)
-        ctx.pl, ctx.blocks, ctx.training, ctx.attn = pl, blocks, training, attn
+        _hold(ctx, pl)
+        ctx.blocks, ctx.training, ctx.attn = blocks, training, attn
         return e_S, e_T
 
     @staticmethod
     def backward(ctx, deS, deT):
-        pl = ctx.pl
+        pl = _owned(ctx)
         try:
             dx0 = _backward(pl, (deS, deT), ctx.blocks, ctx.training, ctx.needs_input_grad[0], ctx.attn)
         finally:

@@ -69,6 +69,37 @@ def test_launcher_fails_when_a_rank_fails():
     assert r.returncode == 1 and "(2, 7)" in r.stderr, (r.returncode, r.stderr)
 
 
+_REAL = r'''
+import subprocess, sys, time
+sys.argv = ["bench.py", "--gpus", "2"]
+sys.path.insert(0, %(root)r)
+import bench
+real = subprocess.Popen
+def popen(cmd, env=None, stdout=None):
+    # rank 0 blocks "in the rendezvous" with its stdout pipe open; rank 1 dies at once (bad GPU index, import error, ...)
+    body = "import time; time.sleep(600)" if env["RANK"] == "0" else "import sys; sys.exit(3)"
+    return real([sys.executable, "-c", body], env=env, stdout=stdout)
+subprocess.Popen = popen
+t0 = time.time()
+try:
+    bench.main()
+except SystemExit as e:
+    print("ELAPSED %%.1f" %% (time.time() - t0), file=sys.stderr)
+    sys.exit(e.code)
+'''
+
+
+def test_launcher_does_not_hang_when_a_rank_other_than_0_dies_early():
+    """Real child processes: rank 0 sits in its rendezvous holding the relayed pipe open, rank 1 exits non-zero straight away.  The launcher
+    must notice (it drains rank 0's stdout on a thread, so its poll loop runs meanwhile), wait the grace period, kill rank 0 and fail."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SCL_BENCH_GRACE_S"] = "1.5"
+    r = subprocess.run([sys.executable, "-c", _REAL % {"root": ROOT}], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 1 and "(1, 3)" in r.stderr, (r.returncode, r.stderr)
+    elapsed = float([l for l in r.stderr.splitlines() if l.startswith("ELAPSED ")][0].split()[1])
+    assert elapsed < 20.0, elapsed
+
+
 def test_under_a_launcher_bench_is_a_rank_not_a_launcher():
     """WORLD_SIZE in the environment (torch.distributed.run) -> no children; checked without a GPU by the failure mode: the
     process goes on to initialise the backend itself (here it has no GPU and must fail, not spawn)."""

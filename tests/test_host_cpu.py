@@ -4,6 +4,7 @@ import os
 import wave
 
 import numpy as np
+import pytest
 import torch
 import yaml
 
@@ -73,15 +74,19 @@ def test_configs_keep_the_reference_keys():
         assert os.path.exists(os.path.join(ROOT, "datautils", plugin + ".py"))
 
 
-def test_batched_notch_design_matches_scipy_per_filter_design():
+@pytest.mark.parametrize("nb,cmax", [(5, 100), (12, 100), (9, 260)])
+def test_batched_notch_design_matches_scipy_per_filter_design(nb, cmax):
     """The throughput-mode sampler designs all notch filters of a batch at once (closed-form firwin, FFT product,
-    FFT freqz); given the same (fc, bw, c, G) it must reproduce genNotchCoeffs (RawBoost.py:28-48) to round-off."""
+    FFT freqz); given the same (fc, bw, c, G) it must reproduce genNotchCoeffs (RawBoost.py:28-48) to round-off — also for
+    non-default --nBands / --maxCoeff whose convolved length exceeds 1024 taps (the FFT size grows with it)."""
     from scipy import signal
     from scl_amd import augment
     rs = np.random.RandomState(0)
-    n, nb, fs = 12, 5, 16000
+    n, fs = 12, 16000
     fc = rs.uniform(20, 8000, (n, nb)); bw = rs.uniform(100, 1000, (n, nb))
-    c = rs.uniform(10, 100, (n, nb)).astype(np.int64); c = np.where(c % 2 == 0, c + 1, c)
+    c = rs.uniform(10, cmax, (n, nb)).astype(np.int64); c = np.where(c % 2 == 0, c + 1, c)
+    if nb > 5:
+        c[0] = cmax + 1 - cmax % 2          # one filter at the largest length of the configuration
     G = rs.uniform(-20, 0, n)
     got = augment.design_notch_filters(fc, bw, c, G, fs)
     for i in range(n):

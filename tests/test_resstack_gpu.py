@@ -122,6 +122,47 @@ def test_two_forwards_then_backwards_keep_their_own_activations():
     assert torch.isfinite(xb.grad).all() and float(xb.grad.abs().max()) > 0
 
 
+def test_many_pending_forwards_never_share_a_plan():
+    """Five grad-mode forwards before any backward (micro-batch loops, retained graphs): every node keeps its own plan, so each
+    backward reproduces the gradient of a lone forward + backward of the same input; graphs that are dropped without a backward give
+    their plans back; past the hard cap a forward raises instead of overwriting somebody's activations."""
+    import gc
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    blocks = [Residual_block(f, first=(i == 0)).to(dev) for i, f in enumerate([[1, 32], [32, 32]])]
+    for b in blocks:
+        b.eval()          # batch statistics would couple the comparison to the running buffers' history
+    xs = [torch.randn(2, 5, 9, 1, device=dev, requires_grad=True) for _ in range(5)]
+    lone = []
+    for x in xs:
+        resstack.res_stack(x, blocks).square().sum().backward()
+        lone.append(x.grad.clone())
+        x.grad = None
+    busy = lambda: sum(1 for pl in resstack._PLANS if pl.busy)
+    busy0 = busy()          # plans other tests' still-alive graphs hold
+    outs = [resstack.res_stack(x, blocks) for x in xs]
+    assert busy() == busy0 + 5
+    for o in reversed(outs):
+        o.square().sum().backward()
+    torch.cuda.synchronize()
+    for x, g in zip(xs, lone):
+        assert torch.allclose(x.grad, g, rtol=1e-4, atol=1e-6)
+    del outs, o
+    gc.collect()
+    assert busy() == busy0
+    held = [resstack.res_stack(x, blocks) for x in xs[:3]]
+    assert busy() == busy0 + 3
+    del held
+    gc.collect()
+    assert busy() == busy0          # released by the nodes' finalizers
+    held = [resstack.res_stack(xs[0], blocks) for _ in range(resstack.MAX_LIVE_PLANS)]
+    with pytest.raises(RuntimeError, match="waiting for their backward"):
+        resstack.res_stack(xs[0], blocks)
+    del held
+    gc.collect()
+    resstack.res_stack(xs[0], blocks).sum().backward()
+
+
 # ---- kernel level: scl_rs_conv / scl_rs_wgrad on random bordered maps against the flat-shift definition evaluated with torch in float64 ----
 import ctypes  # noqa: E402
 
