@@ -187,6 +187,29 @@ def last_tap_total():
     return _LAST_TAP_TOTAL
 
 
+def _h2d_pack(arrays, dev):
+    """Several host arrays -> device tensors through ONE pinned staging buffer and ONE asynchronous copy.
+    A `.to(device)` of pageable memory is a blocking hipMemcpy: it returns only after everything queued on the stream before it has run,
+    i.e. the host re-joined the GPU at the start of every train step (and once more inside the loss), and the GPU then idled through
+    the host's filter design and launch work: 2 - 3 ms of every 45 ms step (profiles/r5_bench_default_gaps.txt).  Pinned memory from
+    torch's caching host allocator + non_blocking keeps the copy stream-ordered without stopping the host; the allocator re-uses a
+    block only after the copy that reads it has completed."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    offs, pos = [], 0
+    for a in arrays:
+        offs.append(pos)
+        pos += (a.nbytes + 15) // 16 * 16
+    host = torch.empty(max(pos, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, o in zip(arrays, offs):
+        hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+    d = host.to(dev, non_blocking=True)
+    return [d[o:o + a.nbytes].view(_TORCH_DT[a.dtype.type]).view(a.shape) for a, o in zip(arrays, offs)]
+
+
+_TORCH_DT = {np.float32: torch.float32, np.int32: torch.int32, np.int64: torch.int64, np.float64: torch.float64}
+
+
 def _taps_to_device(taps_per_clip, dev, centred=True):
     """taps_per_clip: list (clips) of lists (filters) of float64 arrays."""
     global _LAST_TAP_TOTAL
@@ -200,8 +223,7 @@ def _taps_to_device(taps_per_clip, dev, centred=True):
             ln.append(len(b))
             hh.append((len(b) + 1) // 2 if centred else 0)
             pos += len(b)
-    t = lambda arr, dt: torch.from_numpy(np.asarray(arr, dtype=dt)).to(dev)
-    return t(np.concatenate(flat), np.float32), t(off, np.int32), t(ln, np.int32), t(hh, np.int32)
+    return tuple(_h2d_pack([np.concatenate(flat), np.asarray(off, dtype=np.int32), np.asarray(ln, dtype=np.int32), np.asarray(hh, dtype=np.int32)], dev))
 
 
 def _lnl_stage(x, taps_per_clip):
@@ -223,9 +245,9 @@ def _isd_stage(x, draws, g_sd):
     for i, (p, _) in enumerate(draws):
         offs[i + 1] = offs[i] + len(p)
     if offs[-1] > 0:
-        pos = torch.from_numpy(np.concatenate([p for p, _ in draws]).astype(np.int32)).to(x.device)
-        fr = torch.from_numpy(np.concatenate([f for _, f in draws]).astype(np.float32)).to(x.device)
-        ops.isd_scatter(y, L, pos, fr, torch.from_numpy(offs).to(x.device), n, int(np.diff(offs).max()), float(g_sd))
+        pos, fr, offs_d = _h2d_pack([np.concatenate([p for p, _ in draws]).astype(np.int32), np.concatenate([f for _, f in draws]).astype(np.float32),
+                                     offs], x.device)
+        ops.isd_scatter(y, L, pos, fr, offs_d, n, int(np.diff(offs).max()), float(g_sd))
     part = torch.empty(n * ops.fir_nblocks(L) * 4, device=x.device)
     ops.clip_stats(y, L, L, n, part)
     out = torch.empty_like(x)
@@ -237,9 +259,8 @@ def _ssi_stage(x, draws):
     n, L = x.shape
     dev = x.device
     nblk = ops.fir_nblocks(L)
-    noise = torch.from_numpy(np.stack([d[0] for d in draws])).to(dev)
+    noise, snr = _h2d_pack([np.stack([d[0] for d in draws]).astype(np.float32), np.asarray([d[2] for d in draws], dtype=np.float32)], dev)
     taps, off, ln, hh = _taps_to_device([[d[1]] for d in draws], dev)
-    snr = torch.tensor([d[2] for d in draws], dtype=torch.float32, device=dev)
     nf = torch.empty_like(x)
     part_n = torch.empty(n * nblk * 4, device=dev)
     ops.fir_multi(noise, L, L, taps, off, ln, hh, n, 1, False, nf, L, L, part_n)

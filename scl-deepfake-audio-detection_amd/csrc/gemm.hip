@@ -753,13 +753,11 @@ static int gemm_colsum_rows(const SclGemmDesc& d) {
 }
 extern "C" int scl_gemm_colsum_rows(const SclGemmDesc* dp) { return dp ? gemm_colsum_rows(*dp) : 0; }
 
-extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
-    SCL_REQUIRE(dp, "gemm: null desc");
-    const SclGemmDesc& d = *dp;
+// descriptor -> kernel argument block (validation included): shared by scl_gemm_bf16 and scl_gemm_bf16_group
+static int gemm_fill_k(const SclGemmDesc& d, GemmK& k) {
     SCL_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: M,N,K must be positive (%d,%d,%d)", d.M, d.N, d.K);
     SCL_REQUIRE(d.nb1 >= 1 && d.nb2 >= 1 && d.splitk >= 1, "gemm: nb1/nb2/splitk must be >= 1");
     const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
-    GemmK k;
     const bool f32ab = d.flags & SCL_GEMM_AB_F32;
     if (!f32ab) {
         if (!fill_operand(d.A, "A", at ? d.K : d.M, at ? d.M : d.K, &k.A, 2)) return SCL_EINVAL;
@@ -773,7 +771,6 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
     SCL_REQUIRE(d.splitk == 1 || ((d.flags & SCL_GEMM_C_F32) && rmode == 0 && !(d.flags & (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2))
                                   && ((d.flags >> SCL_GEMM_ACT_SHIFT) & 0xF) == 0),
                 "gemm: split-K needs a plain f32 slab output");
-    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
     SCL_REQUIRE(zdim <= 65535, "gemm: batch*splitk too large (%lld)", zdim);
     k.C = d.C; k.C2 = d.C2; k.R = d.R; k.bias = d.bias; k.colsum = d.colsum_part;
@@ -793,6 +790,53 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
                al(d.R, (d.flags & SCL_GEMM_R_F32) ? 16 : 8) && al(d.bias, 16);
     // the wide epilogue writes its column-sum partial rows from the 8-column vector path only: without it the rows would stay unwritten
     SCL_REQUIRE(!d.colsum_part || k.vec_ok, "gemm: colsum_part needs 16-byte aligned C / C2 / R / bias and strides that are multiples of 4");
+    return SCL_OK;
+}
+
+// Several independent weight-gradient problems in ONE launch (gemm_w8.hip: scl_gemm_w8s_group_kernel): every member has both operands
+// transposed (C = A^T B over the K rows), flat K rows, K % 64 == 0, no batching, no split-K and a plain f32 output.  _ok answers whether
+// a descriptor list qualifies (1) without launching; scl_gemm_bf16_group returns SCL_EUNSUPPORTED for a list that does not.
+static int gemm_group_prepare(const SclGemmDesc* descs, int n, GemmK* ks) {
+    if (!descs || n < 1 || n > W8_GROUP_MAX) return SCL_EUNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+        const SclGemmDesc& d = descs[i];
+        if (d.flags & SCL_GEMM_AB_F32) return SCL_EUNSUPPORTED;
+        const int rc = gemm_fill_k(d, ks[i]);
+        if (rc != SCL_OK) return rc;
+        if (!scl_gemm_w8_group_member_ok(ks[i], d.flags & SCL_GEMM_A_T, d.flags & SCL_GEMM_B_T, d)) return SCL_EUNSUPPORTED;
+    }
+    return SCL_OK;
+}
+extern "C" int scl_gemm_bf16_group_ok(const SclGemmDesc* descs, int n) {
+    GemmK ks[W8_GROUP_MAX];
+    return gemm_group_prepare(descs, n, ks) == SCL_OK ? 1 : 0;
+}
+extern "C" int scl_gemm_bf16_group(const SclGemmDesc* descs, int n, void* stream) {
+    GemmK ks[W8_GROUP_MAX];
+    const int rc = gemm_group_prepare(descs, n, ks);
+    if (rc == SCL_EUNSUPPORTED) scl_set_error("gemm group: 1..%d members, each A^T B with flat K rows, K %% 64 == 0, no batch / split-K, plain f32 output", W8_GROUP_MAX);
+    if (rc != SCL_OK) return rc;
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) flops += 2.0 * descs[i].M * descs[i].N * (double)descs[i].K;
+    {
+        SclProfScope prof(SCL_KID_GEMM, (hipStream_t)stream, flops, true);
+        scl_gemm_w8_group_launch(ks, n, (hipStream_t)stream);
+    }
+    return scl_check_launch("scl_gemm_bf16_group");
+}
+
+extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
+    SCL_REQUIRE(dp, "gemm: null desc");
+    const SclGemmDesc& d = *dp;
+    GemmK k;
+    {
+        const int rc = gemm_fill_k(d, k);
+        if (rc != SCL_OK) return rc;
+    }
+    const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
+    const bool f32ab = d.flags & SCL_GEMM_AB_F32;
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
     dim3 grid(tiles, 1, (unsigned)zdim), block(256);
     const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = (hipStream_t)stream;

@@ -491,9 +491,10 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
     }
 }
 
+// One output tile of the single-barrier loop: `bid` of `nblk` blocks in x (the tile id within ITS problem), `bz` the batch / split-K index.
+// The plain kernel passes its own block indices; the grouped kernel (several problems in one launch) passes the position inside the member.
 template <bool AT, bool BT, int RB0, int RB1>
-__global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void w8s_tile(const GemmK& d, char* smem, const int bid, const int nblk, const int bz) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int wr = wave >> 2, wc = wave & 3;
@@ -501,16 +502,16 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
 #ifdef SCL_EXPERIMENTS
     // experiment (SCL_W8_STAGGER, units of s_sleep 127 ~ 3.9 us): the first-round blocks of every other XCD start late, so that the
     // epilogues of the two halves of the chip do not hit HBM at the same moment for the rest of the launch
-    if ((d.debug >> 8) && (blockIdx.x & 1) && blockIdx.x < 256 && blockIdx.z == 0) {
+    if ((d.debug >> 8) && (bid & 1) && bid < 256 && bz == 0) {
         for (int i = 0; i < (d.debug >> 8); ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
     const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn, d.group_m);
+    tile_coords(bid, nblk, tiles_m, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * d.tile_m, n0 = tn * W8_BN;
     const int mlimit = min(d.M, m0 + d.tile_m);
-    int z = blockIdx.z;
+    int z = bz;
     const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;      // uniform, but integer division runs on the vector ALU: back to an SGPR
     const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
     const int nk_total = d.K / BK;
@@ -542,6 +543,38 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
     } else {
         w8s_body<AT, BT, RB1>(d, smem, la, lb, nk, soffA, soffB, RB0, m0, n0, mlimit, z1, z2, ksplit, lane, wave, wc);
     }
+}
+
+template <bool AT, bool BT, int RB0, int RB1>
+__global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    w8s_tile<AT, BT, RB0, RB1>(d, smem, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+// ---- grouped launch: up to W8_GROUP_MAX independent problems, one block per tile, ONE kernel -----------------------------------------
+// Why: the four weight gradients of a transformer layer (out-proj 16 tiles, QKV 48, fc1 64, fc2 64 of 256 x 256 at E = 1024, F = 4096) each
+// fill the 256 CUs only through split-K: 4 - 16 slabs of f32 partial sums per gradient (written, read back and summed by a fifth launch:
+// 1.5 ms and 6 GB of HBM traffic per step at batch 64).  Together they are 192 tiles: one launch, every block walks the WHOLE reduction
+// (M = 12736 rows = 199 K steps instead of 12 - 50, so prologue, epilogue and the launch boundary are paid once per 199 steps) and stores
+// the finished gradient tile straight into the flat gradient buffer — no slabs, no reduction pass, five launches become one.
+// A block finds its problem from blockIdx.x and the members' first-tile table, and reads that member's descriptor from the
+// kernel-argument segment with scalar loads (uniform index): nothing of the descriptor is copied, nothing goes to scratch.
+struct GemmGroupK {
+    GemmK k[W8_GROUP_MAX];
+    int first[W8_GROUP_MAX + 1];
+    int n;
+};
+typedef const __attribute__((address_space(4))) GemmGroupK* W8GArg;
+template <bool AT, bool BT, int RB0, int RB1>
+__global__ __launch_bounds__(512, 2) void scl_gemm_w8s_group_kernel(const GemmGroupK g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    W8GArg gp = (W8GArg)__builtin_amdgcn_kernarg_segment_ptr();
+    int mem = 0;
+#pragma unroll
+    for (int i = 1; i < W8_GROUP_MAX; ++i) mem += (i < g.n && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
+    mem = __builtin_amdgcn_readfirstlane(mem);
+    const int lo = gp->first[mem], hi = gp->first[mem + 1];
+    w8s_tile<AT, BT, RB0, RB1>(*(const GemmK*)&gp->k[mem], smem, (int)blockIdx.x - lo, hi - lo, 0);
 }
 
 #ifdef SCL_EXPERIMENTS      // opt-in experiment, not part of the shipped library (see gemm.hip)
@@ -794,6 +827,39 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
         }
     }
     return true;
+}
+
+// Grouped launch of weight-gradient problems (both operands transposed, whole reduction per block, plain f32 store): see
+// scl_gemm_w8s_group_kernel.  The caller (gemm.hip: scl_gemm_bf16_group) has checked every member with scl_gemm_w8_group_member_ok.
+bool scl_gemm_w8_group_member_ok(const GemmK& k, bool at, bool bt, const SclGemmDesc& d) {
+    if (!at || !bt || d.nb1 != 1 || d.nb2 != 1 || d.splitk != 1 || (d.K % BK) != 0 || d.K / BK < 3) return false;
+    if ((long long)d.A.rpb < (long long)d.K || (long long)d.B.rpb < (long long)d.K) return false;      // flat K rows only (no utterance batching)
+    if ((d.M % 8) || (d.N % 8) || !k.vec_ok) return false;
+    const int plain = SCL_GEMM_A_T | SCL_GEMM_B_T | SCL_GEMM_C_F32;
+    return (d.flags & ~(SCL_GEMM_NO_DMA | SCL_GEMM_NO_W8)) == plain && !d.colsum_part;
+}
+
+int scl_gemm_w8_group_launch(GemmK* ks, int n, hipStream_t s) {
+    GemmGroupK g = GemmGroupK();
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmK& k = ks[i];
+        const int ntm = (k.M + 255) / 256;
+        k.tile_m = (k.M + ntm - 1) / ntm;
+        k.debug = 0;
+        g.k[i] = k;
+        g.first[i] = total;
+        total += ntm * ((k.N + W8_BN - 1) / W8_BN);
+    }
+    for (int i = n; i <= W8_GROUP_MAX; ++i) g.first[i] = total;
+    g.n = n;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_group_kernel<true, true, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        attr_set = true;
+    }
+    SCL_LAUNCH((scl_gemm_w8s_group_kernel<true, true, 8, 8>), dim3((unsigned)total), dim3(512), W8_LDS, s, g);
+    return 0;
 }
 
 static long long w8p_launches = 0;

@@ -32,6 +32,11 @@ BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
 # its own slab buffer until then) instead of one launch behind every weight-gradient GEMM: 72 kernel boundaries per step less
 # (SCL_BATCH_SLABS=0: as before; bit-identical either way)
 BATCH_SLABS = os.environ.get("SCL_BATCH_SLABS", "1") != "0"
+# the four weight gradients of a transformer layer as ONE grouped launch at the end of the layer's backward (ops.gemm_group: 16 + 48 + 64 + 64
+# tiles of 256 x 256, every block walks the whole reduction, finished tiles go straight into the flat gradient buffer): no split-K slabs, no
+# slab reduction, 5 launches -> 1.  SCL_WGRAD_GROUP=0: one split-K launch per gradient + the layer's slab combine, as rounds 2-4 ran.
+# Engaged when the group covers at least 3/8 of the CUs (batch-sized M; a pack-sized step keeps split-K: its 199 x 11 rows are few K steps).
+WGRAD_GROUP = os.environ.get("SCL_WGRAD_GROUP", "1") != "0"
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
 POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
@@ -300,6 +305,9 @@ class Encoder:
         """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small.
         slot (0..3, BATCH_SLABS): the slabs stay in their own buffer and the combine is queued for _flush_slabs (end of the layer)."""
         ksteps = (Kr + 63) // 64
+        if WGRAD_GROUP and slot is not None and not kw and Kr % 64 == 0 and ksteps >= 48:
+            d.setdefault("wgrad_group", []).append((A, B_, out, Mo, No, Kr, slot))      # launched by _flush_slabs at the end of the layer
+            return
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128) * kw.get("nb2", 1)
         sk = _splitk(tiles, ksteps)
         # wide tiles (gemm_w8.hip: 256 x 256 output tiles, one 8-wave block per CU): size the split for one round of the 256 CUs
@@ -332,7 +340,23 @@ class Encoder:
         ops.reduce_slabs(d["slab"], out, n, sk, n)
 
     def _flush_slabs(self, d):
-        """The queued split-K combines of this layer, one launch (on the stream the weight gradients ran on)."""
+        """The queued weight gradients of this layer as one grouped launch (or, if the list does not qualify, one by one on the split-K
+        path), then the queued split-K combines, one launch (on the stream the weight gradients ran on)."""
+        group = d.get("wgrad_group")
+        if group:
+            d["wgrad_group"] = []
+            tiles = sum(((Mo + 255) // 256) * ((No + 255) // 256) for _, _, _, Mo, No, _, _ in group)
+            with self._side():
+                done = tiles >= 96 and ops.gemm_group([g[:6] for g in group])
+            if not done:
+                global WGRAD_GROUP
+                saved, WGRAD_GROUP = WGRAD_GROUP, False
+                try:
+                    with self._side():
+                        for A, B_, out, Mo, No, Kr, slot in group:
+                            self._wgrad(d, A, B_, out, Mo, No, Kr, slot=slot)
+                finally:
+                    WGRAD_GROUP = saved
         jobs = d.get("slab_jobs")
         if jobs:
             with self._side():

@@ -351,6 +351,18 @@ class Model(nn.Module):
         return loss_custom(output, feats, emb, labels, config)
 
 
+_LOSS_SCALE = {}
+
+
+def _loss_scale(bz, dev):
+    """[1, 1/bz, 1/bz] on the device, built once per (batch, device): torch.tensor(..., device=) is a blocking host-to-device copy, and
+    one per step in the middle of the forward -> backward hand-over stalled the launch thread until the GPU had caught up."""
+    key = (bz, dev.type, dev.index)
+    if key not in _LOSS_SCALE:
+        _LOSS_SCALE[key] = torch.tensor([1.0, 1.0 / bz, 1.0 / bz], device=dev)
+    return _LOSS_SCALE[key]
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, output, feats, emb, labels):
@@ -369,7 +381,7 @@ class _LossFn(torch.autograd.Function):
         ops.supcon_fwd(F2, labels, bz, K2, K2, K2, 0.07, ws, G2, res[2:3])   # emb as [bz,1,128,1]: T' = 128, d = 1
         ctx.save_for_backward(coef, G1, G2, F1, F2)
         ctx.dims = (bz, Tq, dq, K1, K2)
-        scale = torch.tensor([1.0, 1.0 / bz, 1.0 / bz], device=dev)   # Model.loss multiplies the SupCon terms by 1/bz
+        scale = _loss_scale(bz, dev)   # Model.loss multiplies the SupCon terms by 1/bz
         out = res * scale
         return out[0], out[1], out[2]
 

@@ -139,6 +139,19 @@ def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R
     return d
 
 
+def gemm_group(problems):
+    """problems: list of (A, B, C, M, N, K) weight-gradient contractions C[M, N] (f32) = A^T B over K rows — one launch, whole reduction per
+    block, no split-K slabs (include/scl_hip.h: scl_gemm_bf16_group).  Returns False (nothing launched) when the list does not qualify."""
+    arr = (L.SclGemmDesc * len(problems))()
+    for i, (A, B, C, M, N, K) in enumerate(problems):
+        d = _gemm_desc(A, B, C, M, N, K, a_t=True, b_t=True)
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(d), ctypes.sizeof(L.SclGemmDesc))
+    if len(problems) > 4 or not L.load().scl_gemm_bf16_group_ok(arr, len(problems)):
+        return False
+    _call("scl_gemm_bf16_group", arr, len(problems), _stream(), keep=arr)
+    return True
+
+
 def gemm_colsum_rows(A, B, C, M, N, K, **kw):
     """Partial rows [rows, N] f32 a gemm(..., colsum_part=...) with the same arguments writes (sum them with colreduce); 0 when the
     call would not run on the wide tiles, which alone produce the fused column sums."""

@@ -761,3 +761,38 @@ def test_wide_tile_epilogue_kinds_equal_the_128_tile_kernel(dev, monkeypatch, M,
             ops._call("scl_gemm_bf16", ops.ctypes.byref(d), ops._stream(), keep=d)
             parts.append((C, part))
         assert torch.equal(parts[0][0], parts[1][0]) and torch.equal(parts[0][1], parts[1][1])
+
+
+@pytest.mark.parametrize("Kr", [192, 448, 12736])
+def test_grouped_weight_gradient_launch_equals_the_single_launches(dev, Kr):
+    """scl_gemm_bf16_group: four A^T B problems of different output shapes in ONE launch (one block per 256 x 256 tile, whole reduction per
+    block).  Every member must equal, BIT FOR BIT, the single wide-tile launch of the same problem without split-K (same tile, same K order,
+    same epilogue) and torch's fp32 product of the bf16 operands to accumulation round-off; lists that do not qualify are refused."""
+    E, Fd = (1024, 4096) if Kr > 1000 else (256, 512)
+    shapes = [(E, Fd), (Fd, E), (E, E), (3 * E, E)]          # fc2, fc1, out-proj, qkv weight gradients: [rows of dY, rows of X]
+    probs, refs, singles = [], [], []
+    for i, (Mo, No) in enumerate(shapes):
+        A = _rand((Kr, Mo), dev, 10 + i, 0.5)                  # dY [Kr, Mo]
+        B = _rand((Kr, No), dev, 20 + i, 0.5)                  # X  [Kr, No]
+        C = torch.full((Mo, No), float("nan"), device=dev)
+        probs.append((ops.Op(A, Mo), ops.Op(B, No), C, Mo, No, Kr))
+        refs.append(A.float().t() @ B.float())
+        S = torch.empty(Mo, No, device=dev)
+        ops.gemm(ops.Op(A, Mo), ops.Op(B, No), S, Mo, No, Kr, a_t=True, b_t=True, force_w8=True)
+        singles.append(S)
+    assert ops.gemm_group(probs) is True
+    torch.cuda.synchronize()
+    for (A, B, C, Mo, No, _), ref, S in zip(probs, refs, singles):
+        _close(C, ref, 2e-5 * math.sqrt(Kr), "group vs fp32 (%d x %d)" % (Mo, No))
+        assert torch.equal(C, S), "group member [%d, %d] differs from its single launch" % (Mo, No)
+    # one member alone, and the refusals: K not a multiple of 64, fewer than 3 K steps, five members, a bias
+    C1 = torch.empty_like(probs[2][2])
+    assert ops.gemm_group([probs[2][:2] + (C1,) + probs[2][3:]]) and torch.equal(C1, probs[2][2])
+    A, B, C, Mo, No, _ = probs[0]
+    assert ops.gemm_group([(A, B, C, Mo, No, Kr - 32)]) is False
+    assert ops.gemm_group([(A, B, C, Mo, No, 128)]) is False
+    assert ops.gemm_group(probs + [probs[0]]) is False
+    import ctypes
+    d = ops._gemm_desc(A, B, C, Mo, No, Kr, a_t=True, b_t=True, bias=torch.zeros(No, device=dev))
+    assert ops.L.load().scl_gemm_bf16_group_ok(ctypes.byref(d), 1) == 0
+    assert ops.L.load().scl_gemm_bf16_group(ctypes.byref(d), 1, None) == -3
