@@ -35,8 +35,9 @@ BATCH_SLABS = os.environ.get("SCL_BATCH_SLABS", "1") != "0"
 # the four weight gradients of a transformer layer as ONE grouped launch at the end of the layer's backward (ops.gemm_group: 16 + 48 + 64 + 64
 # tiles of 256 x 256, every block walks the whole reduction, finished tiles go straight into the flat gradient buffer): no split-K slabs, no
 # slab reduction, 5 launches -> 1.  SCL_WGRAD_GROUP=0: one split-K launch per gradient + the layer's slab combine, as rounds 2-4 ran.
-# Engaged when the group covers at least 3/8 of the CUs (batch-sized M; a pack-sized step keeps split-K: its 199 x 11 rows are few K steps).
+# Engaged when the group covers at least 3/8 of the CUs and the reduction has at least WGRAD_GROUP_MIN_KSTEPS steps of 64 rows.
 WGRAD_GROUP = os.environ.get("SCL_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_MIN_KSTEPS = 16      # from 1024 rows on (measured: 11 x 199 rows 16.2 -> 14.2 ms per step, 16 x 199 20.8 -> 17.6, 32 x 199 29.1 -> 26.1, 64 x 199 44.1 -> 42.5)
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
 POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
@@ -186,7 +187,12 @@ class Encoder:
         Tp = (T + 7) // 8 * 8
         bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        d = {"Ts": Ts, "T": T, "M": M, "Tp": Tp}
+        # The operands of a layer's weight gradients (reduction over the M rows) carry zero rows up to the next multiple of 64: no kernel
+        # ever writes past row M (tile rows beyond it are masked), so the rows stay zero and the gradient GEMMs may walk Mp rows — which
+        # puts them on the wide tiles / the grouped launch (K % 64 == 0) at batch sizes like 32 x 199 = 6368 rows too.
+        Mp = (M + 63) // 64 * 64
+        d = {"Ts": Ts, "T": T, "M": M, "Tp": Tp, "Mp": Mp}
+        bfz = lambda rows, width, extra=0: torch.zeros(rows * width + extra, dtype=torch.bfloat16, device=dev)
         slack = 128 * max(C, E)  # tail slack: tile rows past the last frame are clamped/masked, never dereferenced past this
         d["z"] = [bf(B * t * C + slack) for t in Ts]
         d["y"] = [None] + [f32(B * t * C) for t in Ts[1:]]   # pre-LayerNorm conv outputs stay fp32 (fairseq's Fp32LayerNorm input)
@@ -197,7 +203,7 @@ class Encoder:
         d["xpad"] = bf(B * (T + K) * E + slack)
         d["pc_pre"] = bf(M * E)
         d["xin"] = [f32(M * E) for _ in range(cfg.layers + 1)]
-        d["h1"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["h1"] = [bfz(Mp, E) for _ in range(cfg.layers)]
         d["m1"], d["r1"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
         d["qkv"] = [bf(M * 3 * E + slack) for _ in range(cfg.layers)]
         d["fused_attn"] = (E // H == 64) and T <= 224      # scores stay on chip (csrc/attention.hip); else materialised path
@@ -206,20 +212,20 @@ class Encoder:
         else:
             d["S"] = f32(B * H * T * Tp)   # row stride Tp keeps the 4-wide epilogue stores aligned
             d["P"] = [bf(B * H * T * Tp + 1024) for _ in range(cfg.layers)]
-        d["ctx"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["ctx"] = [bfz(Mp, E) for _ in range(cfg.layers)]
         d["x1"] = [f32(M * E) for _ in range(cfg.layers)]
         d["m2"], d["r2"] = [f32(M) for _ in range(cfg.layers)], [f32(M) for _ in range(cfg.layers)]
-        d["h2"] = [bf(M * E) for _ in range(cfg.layers)]
+        d["h2"] = [bfz(Mp, E) for _ in range(cfg.layers)]
         d["f"] = [bf(M * Fd) for _ in range(cfg.layers)]
-        d["a"] = [bf(M * Fd) for _ in range(cfg.layers)]
+        d["a"] = [bfz(Mp, Fd) for _ in range(cfg.layers)]
         d["out"], d["omean"], d["orstd"] = bf(M * E), f32(M), f32(M)
         # backward scratch (shared by all layers)
         d["dx_a"], d["dx_b"], d["dx_c"] = f32(M * E), f32(M * E), f32(M * E)
-        d["dxbf_a"], d["dxbf_b"], d["dxbf_c"] = bf(M * E + slack), bf(M * E + slack), bf(M * E + slack)
-        d["d_f"] = bf(M * Fd + slack)
+        d["dxbf_a"], d["dxbf_b"], d["dxbf_c"] = bfz(Mp, E, slack), bfz(Mp, E, slack), bfz(Mp, E, slack)
+        d["d_f"] = bfz(Mp, Fd, slack)
         d["d_h"] = bf(M * E + slack)
         d["d_ctx"] = bf(M * E + slack)
-        d["dqkv"] = bf(M * 3 * E + slack)
+        d["dqkv"] = bfz(Mp, 3 * E, slack)
         d["dS"] = None if d["fused_attn"] else bf(B * H * T * Tp + 1024)
         d["dcpad"] = bf(B * (T + K) * E + slack)
         d["dz"] = [bf(B * t * C + slack) for t in Ts]
@@ -305,7 +311,7 @@ class Encoder:
         """out[Mo, No] (f32, contiguous) = A^T B over the Kr reduction rows; split-K when the output is small.
         slot (0..3, BATCH_SLABS): the slabs stay in their own buffer and the combine is queued for _flush_slabs (end of the layer)."""
         ksteps = (Kr + 63) // 64
-        if WGRAD_GROUP and slot is not None and not kw and Kr % 64 == 0 and ksteps >= 48:
+        if WGRAD_GROUP and slot is not None and not kw and Kr % 64 == 0 and ksteps >= WGRAD_GROUP_MIN_KSTEPS:
             d.setdefault("wgrad_group", []).append((A, B_, out, Mo, No, Kr, slot))      # launched by _flush_slabs at the end of the layer
             return
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128) * kw.get("nb2", 1)
@@ -555,7 +561,9 @@ class Encoder:
         d, x, B, L = ctx["d"], ctx["x"], ctx["B"], ctx["L"]
         C, E, H, Fd, K, G = cfg.conv_dim, cfg.embed, cfg.heads, cfg.ffn, cfg.pos_k, cfg.pos_groups
         D, Cg = E // H, E // G
-        Ts, T, M, Tp = d["Ts"], d["T"], d["M"], d["Tp"]
+        Ts, T, M, Tp, Mp = d["Ts"], d["T"], d["M"], d["Tp"], d["Mp"]
+        if not (WGRAD_GROUP and Mp // 64 >= WGRAD_GROUP_MIN_KSTEPS):
+            Mp = M      # short reductions stay on the split-K path, which is faster on the exact row count (pack of 11: 16.2 vs 17.6 ms per step)
         nlnM = ops.layernorm_bwd_nparts(M)
         p_res, p_attn, p_act, p_in = ctx.get("drop", (0.0, 0.0, 0.0, 0.0))
         step_seed = ctx.get("step_seed", 0)
@@ -590,7 +598,7 @@ class Encoder:
             xin = d["xin"][n]
             # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
             with self._side():
-                self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, M, slot=0)
+                self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, Mp, slot=0)
             # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
             fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=RACT_STORED if GELU_DC2 else ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
             nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
@@ -608,7 +616,7 @@ class Encoder:
             with self._side():
                 if not nrows:
                     self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
-                self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, M, slot=1)
+                self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, Mp, slot=1)
             ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
             # dres = d(xout): fc2.bias.grad = colsum(dres x dropout3 mask); the bf16 output d(x1) feeds out_proj's gradients: dropout1 mask
@@ -626,7 +634,7 @@ class Encoder:
             (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
             with self._side():
-                self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, M, slot=2)
+                self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, Mp, slot=2)
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
             qkv, dqkv = d["qkv"][n], d["dqkv"]
             if d["fused_attn"]:
@@ -664,7 +672,7 @@ class Encoder:
             with self._side():
                 if not (FUSED_BIAS_GRAD and d["fused_attn"]):
                     ops.colsum_reduce(dqkv, d["cs_part"], self._qkv_view(pn, "bias"), M, 3 * E)
-                self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, M, slot=3)
+                self._wgrad(d, Op(dqkv, 3 * E), Op(d["h1"][n], E), self._qkv_view(pn, "weight"), 3 * E, E, Mp, slot=3)
             ops.gemm(Op(dqkv, 3 * E), self.W(pn + "self_attn.q_proj.weight", E), d["d_h"], M, E, 3 * E, b_t=True)
             # dx (= d x1) is the gradient of out_proj's output: out_proj.bias.grad rides on this LayerNorm backward
             # dres = d(x1): out_proj.bias.grad = colsum(dres x dropout1 mask); the bf16 output d(xin) feeds the fc2 gradients of the next
