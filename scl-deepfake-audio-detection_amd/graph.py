@@ -115,6 +115,21 @@ def _acquire(head, B, nS, nT, dev, hold):
 MAX_LIVE_PLANS = 16
 
 
+def _storages(*ts):
+    """What a plan keeps of the tensors its in-flight kernels read / write: the STORAGE (the memory stays allocated), never the tensor
+    object — an output tensor carries its grad_fn, and a plan that held it would keep its own autograd node (and through ctx.pl itself)
+    alive until the next forward of the shape, so a graph dropped without a backward could never hand its plan back."""
+    out = []
+    for t in ts:
+        if isinstance(t, (tuple, list)):
+            out.append(_storages(*t))
+        elif torch.is_tensor(t):
+            out.append(t.untyped_storage())
+        else:
+            out.append(t)
+    return tuple(out)
+
+
 def _release(pl, gen):
     if pl.gen == gen:
         pl.busy = False
@@ -362,7 +377,7 @@ def _forward(pl, head, e_S, e_T, training):
         fin.logits, fin.hidden = fin_out[0].data_ptr(), fin_out[1].data_ptr()
         a = pl.drop_entry[1]
         a[0], a[3], a[4], a[7] = e_S.data_ptr(), seeds["in_S"], e_T.data_ptr(), seeds["in_T"]
-        pl.live = (e_S, e_T, fin_out)
+        pl.live = _storages(e_S, e_T, fin_out)
         ops.replay(pl.fwd_calls)
         return fin_out
     st = _structs(pl, head, B, training, seeds)
@@ -394,7 +409,7 @@ def _forward(pl, head, e_S, e_T, training):
     fin = st["fin"]
     fin.logits, fin.hidden = fin_out[0].data_ptr(), fin_out[1].data_ptr()
     ops._call("scl_graph_final_fwd", ctypes.byref(fin), B, _S(), keep=fin)
-    pl.live = (e_S, e_T, fin_out)
+    pl.live = _storages(e_S, e_T, fin_out)
     if record:
         pl.fwd_calls = ops.stop_recording()
     return fin_out
@@ -438,7 +453,7 @@ def _backward(pl, head, d_logits, d_hidden, training):
     if pl.bwd_calls is not None and pl.sig == _signature(head, training):
         a = pl.dropb_entry[1]
         a[2], a[4], a[7], a[9] = deS.data_ptr(), sd["in_S"], deT.data_ptr(), sd["in_T"]
-        pl.live_b = (dl, dh, deS, deT)
+        pl.live_b = _storages(dl, dh, deS, deT)
         ops.replay(pl.bwd_calls)
         return deS, deT
     record = ops._rec() is None and pl.fwd_calls is not None
@@ -460,7 +475,7 @@ def _backward(pl, head, d_logits, d_hidden, training):
     pl.dropb_entry = ops._call("scl_graph_drop_bwd", lS["dxd_a"].data_ptr(), lS["dxd_b"].data_ptr(), deS.data_ptr(), deS.numel(), sd["in_S"],
                                lT["dxd_a"].data_ptr(), lT["dxd_b"].data_ptr(), deT.data_ptr(), deT.numel(), sd["in_T"], pl.p_in0, _S())
     _reduce(pl, head, B)
-    pl.live_b = (dl, dh, deS, deT)
+    pl.live_b = _storages(dl, dh, deS, deT)
     if record:
         pl.bwd_calls = ops.stop_recording()
     return deS, deT

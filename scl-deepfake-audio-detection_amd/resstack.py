@@ -133,6 +133,21 @@ def _acquire(B, H, W, chans, dev, hold):
 MAX_LIVE_PLANS = 16
 
 
+def _storages(*ts):
+    """What a plan keeps of the tensors its in-flight kernels read / write: the STORAGE (the memory stays allocated), never the tensor
+    object — an output tensor carries its grad_fn, and a plan that held it would keep its own autograd node (and through ctx.pl itself)
+    alive until the next forward of the shape, so a graph dropped without a backward could never hand its plan back."""
+    out = []
+    for t in ts:
+        if isinstance(t, (tuple, list)):
+            out.append(_storages(*t))
+        elif torch.is_tensor(t):
+            out.append(t.untyped_storage())
+        else:
+            out.append(t)
+    return tuple(out)
+
+
 def _release(pl, gen):
     if pl.gen == gen:
         pl.busy = False
@@ -229,7 +244,7 @@ def _forward(pl, x0, blocks, training, attn=None):
             pl.out_entry[1][1] = out.data_ptr()
         else:
             pl.pool_entry[1][3], pl.pool_entry[1][4] = out[0].data_ptr(), out[1].data_ptr()
-        pl.live = (x0, out)
+        pl.live = _storages(x0, out)
         ops.replay(pl.fwd_calls)
         return out
     pl.sig, pl.fwd_calls, pl.bwd_calls = sig, None, None
@@ -273,7 +288,7 @@ def _forward(pl, x0, blocks, training, attn=None):
         pl.out_entry = ops._call("scl_rs_copy", pl.p(pl.x[-1], c_last), out.data_ptr(), c_last, c_last, 1, ctypes.byref(pl.gx), S())
     else:
         _attn_forward(pl, attn, training, out)
-    pl.live = (x0, out)
+    pl.live = _storages(x0, out)
     if record:
         pl.fwd_calls = ops.stop_recording()
     return out
@@ -379,7 +394,7 @@ def _backward(pl, d_out, blocks, training, need_dx0, attn=None):
             pl.at["job"][0].src = d_out[0].data_ptr()
         if need_dx0:
             pl.dout_entry[1][1] = dx0.data_ptr()
-        pl.live_b = (d_out, dx0)
+        pl.live_b = _storages(d_out, dx0)
         ops.replay(pl.bwd_calls)
         return dx0
     record = ops._rec() is None and pl.fwd_calls is not None
@@ -416,7 +431,7 @@ def _backward(pl, d_out, blocks, training, need_dx0, attn=None):
         _conv(pl, dz, wv[(i, "c1T")], dprev, co, ci, neg(pl.s1), pl.gx, addend=addend)
     if need_dx0:
         pl.dout_entry = ops._call("scl_rs_copy", pl.p(pl.dx[0], pl.cps[0]), dx0.data_ptr(), pl.cps[0], 1, 1, ctypes.byref(pl.gx), S())
-    pl.live_b, pl.bwd_need = (d_out, dx0), need_dx0
+    pl.live_b, pl.bwd_need = _storages(d_out, dx0), need_dx0
     if record:
         pl.bwd_calls = ops.stop_recording()
     return dx0
