@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--model", choices=["wav2vec2_linear_nll", "wav2vec2_aasist", "wav2vec2_resnet_nll", "wav2vec2_btse"], default="wav2vec2_linear_nll",
                     help="model plugin; the headline (BASELINE.json) is wav2vec2_linear_nll, aasist / resnet / btse (configs[3], configs[4]) are extra workloads")
     ap.add_argument("--bio-tokens", type=int, default=199, help="wav2vec2_btse: synthetic bio tokens per utterance (the reference's tokeniser is absent)")
+    ap.add_argument("--eval", action="store_true", help="scoring throughput instead of the train step: main.py --eval / 03_eval.sh's forward (model.eval(), "
+                    "is_train False, no grad) on batches of 64600-sample clips (Dataset_for_eval's pad length); both scoring precisions are timed")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -157,6 +159,49 @@ def cpu_baseline(args):
                       "fp32 torch CPU oracle, %d threads; %.1f s), the first discarded" % (B, args.samples, args.rawboost, t_aug, torch.get_num_threads(), t_step)}
 
 
+def bench_eval(args, model, dev, world, rank):
+    """Scoring path (reference main.py:161-214: produce_evaluation_file over Dataset_for_eval's 64600-sample clips, batch_size from the CLI):
+    forward only, model.eval(), is_train False, torch.no_grad().  Times the default scoring precision (fp32 activations + fp32 master weights:
+    scores within 1e-3 of the fp32 reference) and the bf16-operand training kernels (SCL_SCORE_FP32=0: scores to ~1e-2), same weights, same
+    input, and reports how far the two sets of log-probs are apart."""
+    import torch
+    from scl_amd import model_linear
+    assert world == 1, "--eval is a single-GPU measurement (03_eval.sh shards the file list, every rank scores its own part)"
+    B, L = args.batch, (64600 if args.samples == 64000 else args.samples)
+    x = (0.1 * torch.randn(B, L, generator=torch.Generator().manual_seed(4321))).to(dev)
+    model.eval()
+    model.is_train = False
+    extra = ()
+    if args.model == "wav2vec2_btse":
+        extra = (torch.randint(0, 3, (B, args.bio_tokens), dtype=torch.int32).to(dev), torch.full((B,), args.bio_tokens, dtype=torch.int32, device=dev))
+    res, outs = {}, {}
+    for name, flag in (("fp32", True), ("bf16", False)):
+        model_linear.SCORE_FP32 = flag
+        with torch.no_grad():
+            for _ in range(max(1, args.warmup)):
+                out = model(x, *extra)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(x, *extra)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        res[name] = {"ms_per_batch": dt * 1e3, "utterances_per_s": B / dt}
+        outs[name] = out.float().cpu()
+    model_linear.SCORE_FP32 = True
+    d = (outs["bf16"] - outs["fp32"]).abs()
+    line = {"metric": "scoring utterances/sec (64600-sample clips)", "value": res["fp32"]["utterances_per_s"], "unit": "utterances/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["fp32"]["ms_per_batch"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s (XLS-R-300M shape, random init) scoring forward, batch %d x %d-sample clips, fp32 scoring path (the default of main.py --eval)" % (args.model, B, L),
+                       "per_gpu_batch": B, "samples": L, "tiny": bool(args.tiny)},
+            "fp32": res["fp32"], "bf16": res["bf16"],
+            "bf16_vs_fp32": {"max_abs_logprob_diff": float(d.max()), "max_rel_to_largest": float(d.max() / outs["fp32"].abs().max()),
+                             "argmax_agree": float((outs["bf16"].argmax(1) == outs["fp32"].argmax(1)).float().mean())},
+            "eval_set_hours": {k: 71933 / v["utterances_per_s"] / 3600 for k, v in res.items()}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -211,6 +256,8 @@ def main():
     model.grad_sync = sync
     opt = FusedAdamW(model, lr=1e-5, weight_decay=1e-4, grad_sync=sync)   # main.py:339 defaults (max_lr, weight_decay)
 
+    if args.eval:
+        return bench_eval(args, model, dev, world, rank)
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
     x = (0.1 * torch.randn(B, L, generator=g)).to(dev)       # resident in HBM before the timed region

@@ -93,6 +93,7 @@ typedef struct SclOperand {
 #define SCL_GEMM_NO_P8    0x00400000  /* do not pick the 256x256 ping-pong variant */
 #define SCL_GEMM_FORCE_P8 0x00800000  /* pick it whenever it is legal (testing / A-B comparison) */
 #define SCL_GEMM_NO_W8    0x01000000  /* never the wide-tile (<=208/256 x 256, runtime row pitch) ping-pong kernel of gemm_w8.hip */
+#define SCL_GEMM_F32X3    0x20000000  /* with SCL_GEMM_AB_F32: every f32 operand as a (hi, lo) bf16 pair, three bf16 MFMAs per product term (gemm_f32.hip): ~2e-5 relative per product, ~5x the matrix-core rate of the exact kernel */
 #define SCL_GEMM_FORCE_W8 0x02000000  /* pick it whenever it can address the operands (testing / A-B comparison) */
 #define SCL_GEMM_FORCE_X2 0x08000000  /* pick the two-blocks-per-CU 208 x 128 kernel of gemm_x2.hip whenever it can address the operands */
 #define SCL_GEMM_NO_X2    0x10000000  /* never that kernel (testing / A-B comparison) */

@@ -118,9 +118,27 @@ __device__ __forceinline__ void f32_frag(const float* img, int blk, int lane, fl
     }
 }
 
+// ---- "f32 x3": fp32 operands as bf16 pairs on the bf16 matrix cores ------------------------------------------------------------------
+// a = a_hi + a_lo + O(2^-17 |a|) with a_hi = bf16(a), a_lo = bf16(a - a_hi).  a b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-16 |a b|): three
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulation) replace the eight v_mfma_f32_16x16x4_f32 of a 32-deep step — 48 instead of 256 matrix-core
+// cycles per 16 x 16 block, i.e. the 2.5 PFLOP/s pipe at a third of its rate (~830 TFLOP/s) against the 157 TFLOP/s of the f32 pipe — for
+// products accurate to ~2e-5 relative (random signs: ~1e-6 of a long dot product) instead of 6e-8.  Same staging, same LDS images, same
+// fragments (a lane's eight k of one row ARE the bf16 instruction's operand layout), same epilogue; the split runs on the VALU per step.
+// Opt-in per launch (SCL_GEMM_F32X3): the back-end convolutions / linears and the scoring path ask for it, the exact kernel stays the
+// meaning of SCL_GEMM_AB_F32 alone.
+__device__ __forceinline__ void f32_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8 x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = v[j];
+    hi = __builtin_convertvector(x, bf16x8);
+    const f32x8 back = __builtin_convertvector(hi, f32x8);
+    lo = __builtin_convertvector(x - back, bf16x8);
+}
+
 // the 64x64 tile needs 60-90 VGPRs and 36 KiB of LDS: four blocks per CU hide its single-stage global prefetch (measured on the AASIST
 // convolution wgrads: 192 blocks at one per CU ran at the HBM latency, 1.6 us per 32-deep step)
-template <int TM, bool AT, bool BT>
+template <int TM, bool AT, bool BT, bool X3>
 __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(const GemmK d) {
     typedef F32Geom<TM> G;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -171,13 +189,27 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
             f32_frag<TM, AT>(tA, wr * G::NB + i, lane, fa[i]);
             f32_frag<TM, BT>(tB, wc * G::NB + i, lane, fb[i]);
         }
+        if constexpr (X3) {
+            bf16x8 ah[G::NB], al[G::NB], bh[G::NB], bl[G::NB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < G::NB; ++i) { f32_split8(fa[i], ah[i], al[i]); f32_split8(fb[i], bh[i], bl[i]); }
 #pragma unroll
             for (int i = 0; i < G::NB; ++i)
 #pragma unroll
-                for (int n = 0; n < G::NB; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0);
+                for (int n = 0; n < G::NB; ++n) {      // the two small terms first, the leading term last
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[n], ah[i], acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], al[i], acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], ah[i], acc[i][n], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                    for (int n = 0; n < G::NB; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0);
+        }
         if (more) {
             float* nA = smem + (cur ^ 1) * 2 * G::IMG;
             sa.store(nA, ra, tid); sb.store(nA + G::IMG, rb, tid);
@@ -201,22 +233,22 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
     }
 }
 
-template <int TM>
+template <int TM, bool X3>
 void f32_launch(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s) {
     const size_t lds = 4 * (size_t)F32Geom<TM>::IMG * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, false, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, false, true, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, false, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32_kernel<TM, true, true, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const dim3 block(256);
-    if (!at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, false>), grid, block, lds, s, k);
-    else if (!at && bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, true>), grid, block, lds, s, k);
-    else if (at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, false>), grid, block, lds, s, k);
-    else SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, true>), grid, block, lds, s, k);
+    if (!at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, false, X3>), grid, block, lds, s, k);
+    else if (!at && bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, false, true, X3>), grid, block, lds, s, k);
+    else if (at && !bt) SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, false, X3>), grid, block, lds, s, k);
+    else SCL_LAUNCH((scl_gemm_f32_kernel<TM, true, true, X3>), grid, block, lds, s, k);
 }
 
 }  // namespace
@@ -230,11 +262,14 @@ int scl_gemm_f32_launch(const SclGemmDesc& d, GemmK& k, hipStream_t s) {
     const long long zdim = (long long)d.nb1 * d.nb2 * d.splitk;
     // 128x128 tiles once they fill the chip twice over; otherwise 64x64 (4x the blocks: the back-ends' maps are small)
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
+    const bool x3 = d.flags & SCL_GEMM_F32X3;
     if (t128 >= 512 && d.M >= 128 && d.N >= 128) {
-        f32_launch<128>(k, at, bt, dim3((unsigned)(t128 / zdim), 1, (unsigned)zdim), s);
+        const dim3 grid((unsigned)(t128 / zdim), 1, (unsigned)zdim);
+        if (x3) f32_launch<128, true>(k, at, bt, grid, s); else f32_launch<128, false>(k, at, bt, grid, s);
     } else {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-        f32_launch<64>(k, at, bt, dim3((unsigned)t64, 1, (unsigned)zdim), s);
+        const dim3 grid((unsigned)t64, 1, (unsigned)zdim);
+        if (x3) f32_launch<64, true>(k, at, bt, grid, s); else f32_launch<64, false>(k, at, bt, grid, s);
     }
     return SCL_OK;
 }

@@ -88,6 +88,7 @@ GEMM_FORCE_W8 = 0x02000000
 GEMM_FORCE_X2 = 0x08000000
 GEMM_NO_X2 = 0x10000000
 GEMM_AB_F32 = 0x40000000
+GEMM_F32X3 = 0x20000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 ACT_GELU_DC2 = 5      # gelu whose second output is gelu'(pre-activation); the matching backward epilogue is rmode 2 with ract = RACT_STORED

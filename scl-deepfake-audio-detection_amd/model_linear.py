@@ -31,6 +31,7 @@ N_CLASS = 2
 SCORE_FP32 = os.environ.get("SCL_SCORE_FP32", "1") != "0"
 # the 128-wide frame-level head in f32 on the exact-fp32 GEMM (SCL_HEAD_F32=0: bf16 operands, the A/B switch of tests / probes)
 HEAD_F32 = os.environ.get("SCL_HEAD_F32", "1") != "0"
+X3_OFF = {"x3": False} if HEAD_F32 else {}      # the training head's f32 GEMMs stay on the exact kernel (its backward is checked at 4e-6)
 DROP_P = 0.5  # BackEnd(128, 128, 2, 0.5, False): torch.nn.Dropout(0.5) after each frame-level layer
 
 
@@ -238,7 +239,7 @@ class Model(nn.Module):
         for j, idx in enumerate((0, 3, 6)):
             dsc = ops.gemm(Op(prev, HEAD_DIM), Wf("backend.m_frame_level.%d.weight" % idx, HEAD_DIM), hb["h"][j], M, HEAD_DIM, HEAD_DIM,
                            bias=P.f32("backend.m_frame_level.%d.bias" % idx), act=ACT_LEAKY, c2=hb["pre"][j], drop_p=drop,
-                           drop_seed=seeds[j])
+                           drop_seed=seeds[j], x3=False)
             drop_descs.append(dsc)
             prev = hb["h"][j]
         ops.meanpool_fwd(prev, emb, B, T, HEAD_DIM)
@@ -287,14 +288,14 @@ class Model(nn.Module):
             inp = hb["h"][j - 1] if j > 0 else hb["r0"]
             ops.colsum_reduce(dpre, hb["cs"], P.g("backend.m_frame_level.%d.bias" % idx), M, HEAD_DIM)
             self.encoder._wgrad(sv["ectx"]["d"], Op(dpre, HEAD_DIM), Op(inp, HEAD_DIM), P.g("backend.m_frame_level.%d.weight" % idx),
-                                HEAD_DIM, HEAD_DIM, M)
+                                HEAD_DIM, HEAD_DIM, M, **X3_OFF)
             # fp32 master weights on the exact-fp32 GEMM (bf16 working copy when SCL_HEAD_F32=0)
             wj = Op(P.flat if HEAD_F32 else P.bf16, HEAD_DIM, offset=P.off("backend.m_frame_level.%d.weight" % idx))
             if j > 0:
                 drop_descs.append(ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dpre"][j - 1], M, HEAD_DIM, HEAD_DIM, b_t=True, R=hb["pre"][j - 1],
-                                           rmode=2, ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=seeds[j - 1]))
+                                           rmode=2, ract=ACT_LEAKY, drop_p=sv["drop"], drop_seed=seeds[j - 1], x3=False))
             else:
-                ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dfe"], M, HEAD_DIM, HEAD_DIM, b_t=True, R=sv["feats"], rmode=2, ract=ACT_RELU)
+                ops.gemm(Op(dpre, HEAD_DIM), wj, hb["dfe"], M, HEAD_DIM, HEAD_DIM, b_t=True, R=sv["feats"], rmode=2, ract=ACT_RELU, x3=False)
         # total gradient at feats = ReLU path + SupCon path
         ops.add_f32(hb["dfe"], st["d_feats"], hb["dfe"], hb["dfe_bf"], M * HEAD_DIM)
         ops.colsum_reduce(hb["dfe"], hb["cs"], P.g("LL.bias"), M, HEAD_DIM)

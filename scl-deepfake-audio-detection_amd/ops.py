@@ -97,6 +97,11 @@ class Op:
                             self.rpb, self.ld, self.cin, 0)
 
 
+# f32-operand GEMMs of the back-ends (AASIST / ResNet / BTSE / Conformer convolutions and linears) and of the scoring path as bf16 pairs
+# on the bf16 matrix cores (csrc/gemm_f32.hip "f32 x3": ~2e-5 relative per product at ~5x the matrix-core rate); SCL_F32X3=0: the exact
+# v_mfma_f32_16x16x4_f32 kernel everywhere.  The losses' Gram matrices and the linear plugin's frame-level head stay on the exact kernel.
+F32X3 = os.environ.get("SCL_F32X3", "1") != "0"
+
 _SPLITK_WS = {}      # per stream: f32 slabs of the automatic split-K path (old, smaller ones stay alive: recorded plans point into them)
 _AUTO_SPLITK = os.environ.get("SCL_GEMM_AUTO_SPLITK", "1") == "1"
 
@@ -116,13 +121,14 @@ def _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, f32):
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None):
-    """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h."""
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None, x3=None):
+    """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h.
+    x3 (f32 operands only): the bf16-pair form of the f32 kernel (SCL_GEMM_F32X3); None = the module default F32X3, False = the exact kernel."""
     d = _gemm_desc(A, B, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=act, c2=c2, R=R, rmode=rmode, ract=ract, alpha=alpha, nb1=nb1,
                    nb2=nb2, splitk=splitk, ldc=ldc, c_rpb=c_rpb, c_rbstride=c_rbstride, c_bs1=c_bs1, c_bs2=c_bs2, c_offset=c_offset,
                    bias_bs2=bias_bs2, bias_offset=bias_offset, drop_p=drop_p, drop_seed=drop_seed, c_split_stride=c_split_stride,
                    no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8,
-                   force_x2=force_x2, no_x2=no_x2, colsum_part=colsum_part)
+                   force_x2=force_x2, no_x2=no_x2, colsum_part=colsum_part, x3=x3)
     sk = _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, A.t.dtype == torch.float32)
     if sk > 1 and not (force_w8 or force_p8 or force_big or force_x2):
         key = (C.device.index, torch.cuda.current_stream(C.device).cuda_stream)
@@ -168,13 +174,15 @@ def gemm_wide_kind(A, B, C, M, N, K, **kw):
 def _gemm_desc(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
                alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
                c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False,
-               force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None):
+               force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None, x3=None):
     d = L.SclGemmDesc()
     d.A, d.B = A.c(), B.c()
     flags = 0
     assert A.t.dtype == B.t.dtype, "A and B must have the same element type"
     if A.t.dtype == torch.float32:
         flags |= L.GEMM_AB_F32
+        if F32X3 if x3 is None else x3:
+            flags |= L.GEMM_F32X3
     if a_t:
         flags |= L.GEMM_A_T
     if b_t:
