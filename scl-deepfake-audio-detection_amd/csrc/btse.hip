@@ -5,20 +5,28 @@
 //
 // The encoder is 40 752 parameters on a few hundred tokens: one WORKGROUP PER UTTERANCE runs all of it (embedding -> n_layers x
 // {QKV, relative-position attention, out-projection + residual + LayerNorm, FFN + residual + LayerNorm} -> scoring conv at the last
-// position) in ONE launch forward and ONE launch backward, fp32 throughout.  Per phase a thread owns one output channel and keeps that
-// channel's weight row in registers while it walks the rows; K and V of the layer sit in LDS at a 33-float pitch (lane j reads row j:
-// conflict-free) and one wave owns one query row, so the L x L scores, the soft-max and the relative-position skew (scores[i][j] +=
-// q_i . emb_rel_k[j - i + 4], out[i] += p[i][j] emb_rel_v[j - i + 4] for |j - i| <= 4: what the reference's pad / reshape tricks at
-// transformer.py:189-243 compute) live in registers.  The activations the backward needs go to a per-utterance scratch row in HBM
-// (L2-resident: 392 L floats per layer); the backward recomputes the probabilities from the saved row log-sum-exp, first per query row
-// (dq, delta, the relative-embedding gradients), then per key row (dk, dv) with Q and dA in LDS.  Parameter gradients leave as one slab
-// row per utterance; the host sums the rows in index order.
+// position) in ONE launch forward and ONE launch backward, fp32 throughout, and the work is laid out so that nothing waits on a chain of
+// dependent memory round trips:
+//   * every product with a 32- / 128-wide weight matrix is THREAD-PER-ROW: a thread holds its token's row in registers, the output
+//     channel is a uniform loop index, so the weights arrive through scalar loads and enter the FMAs as scalar operands; LayerNorm and
+//     the residual adds are in-thread, all L rows run in parallel and a whole layer needs three barriers;
+//   * the attention is THREAD-PER-(row, head): K and V of the layer sit in LDS and every lane reads the SAME key row (a broadcast), two
+//     passes over the keys (maximum; exponentials + P V), the relative-position skew (scores[i][j] += q_i . emb_rel_k[j - i + 4],
+//     out[i] += p[i][j] emb_rel_v[j - i + 4] for |j - i| <= 4: what the reference's pad / reshape tricks at transformer.py:189-243
+//     compute) as a band test — not one cross-lane operation;
+//   * the backward recomputes the probabilities from the saved row log-sum-exp, per query row (dq, delta, the band of dS / P the
+//     relative-embedding gradients need) and per key row (dk, dv, with Q and dA in LDS); parameter gradients are reductions over the
+//     rows: 64-row chunks of both operands staged in LDS, a thread owns 4 - 16 outputs in registers; they leave as one slab row per
+//     utterance and the host sums the rows in index order.
+// Round 5 first built the row loops as one-channel-per-thread with the activations re-read from the scratch row inside every loop trip:
+// 1.80 ms forward / 4.06 ms backward at 64 x 199 tokens, all of it memory latency; this form: see profiles/r5_btse_bio_probe.txt.
+// The activations the backward needs go to a per-utterance scratch row in HBM (L2-resident: 392 L floats per layer).
 // model.py:236 reads the LAST padded position times its mask: an utterance shorter than L scores exactly zero and contributes no
 // gradient — the backward writes a zero row for it and returns.
 #include "common.h"
 
 namespace {
-constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, KP = 33, MAXJ = 8, NT = 256, MAXL = 64 * MAXJ;
+constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, MAXL = 512, RC = 64;
 constexpr float QSCALE = 0.35355339059327373f;      // 1 / sqrt(k_channels = 8), transformer.py:155
 constexpr float EMB_SCALE = 5.656854249492381f;     // sqrt(bio_dim = 32), model.py:228
 constexpr float FILL = -1e4f, EPS = 1e-5f;          // transformer.py:168, modules.py:28
@@ -26,205 +34,210 @@ enum { I_WQ, I_BQ, I_WK, I_BK, I_WV, I_BV, I_WO, I_BO, I_EK, I_EV, I_G1, I_B1, I
 // per-utterance scratch, in units of L floats: layer l at l * O_LAYER, the encoder output at n_layers * O_LAYER, the backward's own
 // buffers behind it
 enum : int { O_XIN = 0, O_Q = 32, O_K = 64, O_V = 96, O_A = 128, O_S1 = 160, O_X1 = 192, O_S2 = 224, O_H = 256, O_ST = 384, O_LSE = 388, O_LAYER = 392 };
-enum : int { G_DX = 0, G_Q = 32, G_K = 64, G_V = 96, G_DA = 128, G_DS1 = 160, G_DS2 = 192, G_DH = 224, G_DELTA = 352, G_TOTAL = 356 };
+enum : int { G_DX = 0, G_Q = 32, G_K = 64, G_V = 96, G_DA = 128, G_DS1 = 160, G_DS2 = 192, G_DH = 224, G_DELTA = 352, G_BS = 356, G_BP = 392, G_TOTAL = 428 };
 
-__device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lanes that share a row (lanes 0-31 / 32-63 of the wave)
-    v = lanes16_sum(v);
-    return v + __shfl_xor(v, 16);
+// The parameters are read-only for the lifetime of a launch: addressed through the CONSTANT address space, a load with a uniform index is a
+// scalar load (s_load_dwordx8 / x16 into SGPRs, which feed the FMAs as scalar operands).  Through a plain pointer the compiler must assume
+// the kernel's own stores to the scratch row could alias the weights and issues one vector load per FMA instead (351 global loads in the
+// forward kernel, every one a memory round trip that all 64 lanes wait for: 1.03 ms instead of the time below).
+typedef const __attribute__((address_space(4))) float* cptr;
+__device__ __forceinline__ cptr as_const(const float* p) { return (cptr)(uintptr_t)p; }
+
+__device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&x)[BD]) {
+    const float4* p4 = (const float4*)p;
+#pragma unroll
+    for (int i = 0; i < BD / 4; ++i) { const float4 v = p4[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
 }
-__device__ __forceinline__ void wave_sync_lds() {      // same-wave LDS hand-over: LDS operations of a wave retire in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+__device__ __forceinline__ void store_row32(float* __restrict__ p, const float (&x)[BD]) {
+    float4* p4 = (float4*)p;
+#pragma unroll
+    for (int i = 0; i < BD / 4; ++i) p4[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
 }
-// sum of v over the 8 row groups of the (row group, channel) thread mapping, in index order; every thread gets its channel's total
-__device__ __forceinline__ float rg_total(float v, float* red, int rg, int c) {
-    red[rg * BD + c] = v;
-    __syncthreads();
+// y[c] = b[c] + sum_k x[k] W[c][k] for one row held in registers: the output channel is a uniform loop index, so the weight row
+// arrives through scalar loads and feeds the FMAs as scalar operands — no LDS, no per-lane weight traffic
+__device__ __forceinline__ void matvec32(const float (&x)[BD], cptr W, cptr b, float (&y)[BD]) {
+#pragma unroll 4
+    for (int c = 0; c < BD; ++c) {
+        float a = b[c];
+#pragma unroll
+        for (int k = 0; k < BD; ++k) a = fmaf(x[k], W[c * BD + k], a);
+        y[c] = a;
+    }
+}
+// y[k] += sum_c d[c] W[c][k]  (the data gradient of the same layer: rows of W again, the output index now the unrolled one)
+__device__ __forceinline__ void matvec32_t(const float (&d)[BD], cptr W, float (&y)[BD]) {
+#pragma unroll 4
+    for (int c = 0; c < BD; ++c) {
+        const float dc = d[c];
+#pragma unroll
+        for (int k = 0; k < BD; ++k) y[k] = fmaf(dc, W[c * BD + k], y[k]);
+    }
+}
+__device__ __forceinline__ void layernorm32(const float (&s)[BD], cptr g, cptr b, float (&y)[BD], float& mean, float& rs) {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < BD; ++c) m += s[c];
+    m *= 1.f / BD;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < BD; ++c) { const float d = s[c] - m; v = fmaf(d, d, v); }
+    rs = 1.f / sqrtf(v * (1.f / BD) + EPS);
+    mean = m;
+#pragma unroll
+    for (int c = 0; c < BD; ++c) y[c] = (s[c] - m) * rs * g[c] + b[c];
+}
+// ds = LayerNorm backward of one row (dy in, pre-norm row s, its mean / rstd)
+__device__ __forceinline__ void layernorm32_bwd(const float (&dy)[BD], const float (&s)[BD], float mean, float rs, cptr g, float (&ds)[BD]) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < BD; ++c) { const float xh = (s[c] - mean) * rs, dxh = dy[c] * g[c]; m1 += dxh; m2 = fmaf(dxh, xh, m2); }
+    m1 *= 1.f / BD; m2 *= 1.f / BD;
+#pragma unroll
+    for (int c = 0; c < BD; ++c) { const float xh = (s[c] - mean) * rs; ds[c] = rs * (dy[c] * g[c] - m1 - xh * m2); }
+}
+
+// One attention score of query row i (scaled q in registers) against key row j of head h: q . (k_j + emb_rel_k[j - i + 4]) inside the band
+__device__ __forceinline__ float score(const float (&qs)[BK], const float* __restrict__ kr, const float* __restrict__ Eks, int dj) {
+    const float4 k0 = ((const float4*)kr)[0], k1 = ((const float4*)kr)[1];
+    float s = qs[0] * k0.x;
+    s = fmaf(qs[1], k0.y, s); s = fmaf(qs[2], k0.z, s); s = fmaf(qs[3], k0.w, s);
+    s = fmaf(qs[4], k1.x, s); s = fmaf(qs[5], k1.y, s); s = fmaf(qs[6], k1.z, s); s = fmaf(qs[7], k1.w, s);
+    if ((unsigned)(dj + BW) <= 2u * BW) {
+        const float* e = Eks + (dj + BW) * BK;
+#pragma unroll
+        for (int d = 0; d < BK; ++d) s = fmaf(qs[d], e[d], s);
+    }
+    return s;
+}
+__device__ __forceinline__ float dot8(const float* __restrict__ a, const float (&b)[BK]) {
+    const float4 a0 = ((const float4*)a)[0], a1 = ((const float4*)a)[1];
+    float s = a0.x * b[0];
+    s = fmaf(a0.y, b[1], s); s = fmaf(a0.z, b[2], s); s = fmaf(a0.w, b[3], s);
+    s = fmaf(a1.x, b[4], s); s = fmaf(a1.y, b[5], s); s = fmaf(a1.z, b[6], s); s = fmaf(a1.w, b[7], s);
+    return s;
+}
+__device__ __forceinline__ float dot8_lds(const float* __restrict__ a, const float* __restrict__ e) {
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[g * BD + c];
-    __syncthreads();
+    for (int d = 0; d < BK; ++d) s = fmaf(a[d], e[d], s);
     return s;
 }
 
-// y[c] = bias + sum_k x[k] w[k] over a 32-float row read as 8 float4 (all 32 lanes of a row group read the same address)
-__device__ __forceinline__ float dot32(const float* __restrict__ row, const float (&w)[BD], float acc) {
-    const float4* r4 = (const float4*)row;
-#pragma unroll
-    for (int k4 = 0; k4 < BD / 4; ++k4) {
-        const float4 x = r4[k4];
-        acc = fmaf(x.x, w[4 * k4], acc); acc = fmaf(x.y, w[4 * k4 + 1], acc); acc = fmaf(x.z, w[4 * k4 + 2], acc); acc = fmaf(x.w, w[4 * k4 + 3], acc);
-    }
-    return acc;
-}
-
+// ---- forward ---------------------------------------------------------------------------------------------------------------------------
+// Thread-per-ROW for everything that is a product with a 32- / 128-wide weight matrix (QKV, out-projection + residual + LayerNorm, the
+// whole FFN + LayerNorm: a row's 12 k multiply-adds run out of registers against scalar-loaded weights, all L rows in parallel, no
+// barrier inside) and thread-per-(row, head) for the attention (K / V in LDS, every lane reads the SAME key row: a broadcast; two passes
+// over the keys — maximum, then exponentials + P V — and not one cross-lane operation).
 __global__ __launch_bounds__(NT) void btse_bio_fwd_kernel(const SclBtseBio p) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float Eks[NR * BK], Evs[NR * BK];
     const int b = blockIdx.x, t = threadIdx.x, L = p.L;
     const int len = min(max(p.lens[b], 0), L);            // commons.sequence_mask: arange(L) < length
     float* ws = p.ws + (int64_t)b * p.ws_stride;
     const int32_t* tok = p.bio + (int64_t)b * L;
     float* Ks = lds;
-    float* Vs = lds + L * KP;
-    const int c = t & 31, rg = t >> 5, lane = t & 63, w = t >> 6;
-    for (int idx = t; idx < L * BD; idx += NT) {          // model.py:228,232 + transformer.py:42
-        const int r = idx >> 5;
+    float* Vs = lds + L * BD;
+    for (int r = t; r < L; r += NT) {                     // model.py:228,232 + transformer.py:42
         const int tk = min(max(tok[r], 0), p.n_bios - 1);
-        ws[idx] = r < len ? p.emb[tk * BD + (idx & 31)] * EMB_SCALE : 0.f;
+        float x[BD];
+        load_row32(p.emb + tk * BD, x);
+#pragma unroll
+        for (int c = 0; c < BD; ++c) x[c] = r < len ? x[c] * EMB_SCALE : 0.f;
+        store_row32(ws + r * BD, x);
     }
-    __syncthreads();
     for (int l = 0; l < p.n_layers; ++l) {
         float* base = ws + (int64_t)l * O_LAYER * L;
         const float* const* W = p.lw[l];
-        const float* xin = base;
         if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
-        {   // q, k, v = conv_{q,k,v}(x)   (transformer.py:139-141)
-            float wq[BD], wk[BD], wv[BD];
-#pragma unroll
-            for (int k = 0; k < BD; ++k) { wq[k] = W[I_WQ][c * BD + k]; wk[k] = W[I_WK][c * BD + k]; wv[k] = W[I_WV][c * BD + k]; }
-            const float bq = W[I_BQ][c], bk = W[I_BK][c], bv = W[I_BV][c];
-            for (int r = rg; r < L; r += 8) {
-                const float* xr = xin + r * BD;
-                const float aq = dot32(xr, wq, bq), ak = dot32(xr, wk, bk), av = dot32(xr, wv, bv);
-                base[O_Q * L + r * BD + c] = aq; base[O_K * L + r * BD + c] = ak; base[O_V * L + r * BD + c] = av;
-                Ks[r * KP + c] = ak; Vs[r * KP + c] = av;
-            }
+        for (int r = t; r < L; r += NT) {                 // q, k, v = conv_{q,k,v}(x)   (transformer.py:139-141); a thread re-reads only rows it wrote
+            float x[BD], y[BD];
+            load_row32(base + r * BD, x);
+            matvec32(x, as_const(W[I_WQ]), as_const(W[I_BQ]), y); store_row32(base + O_Q * L + r * BD, y);
+            matvec32(x, as_const(W[I_WK]), as_const(W[I_BK]), y); store_row32(base + O_K * L + r * BD, y); store_row32(Ks + r * BD, y);
+            matvec32(x, as_const(W[I_WV]), as_const(W[I_BV]), y); store_row32(base + O_V * L + r * BD, y); store_row32(Vs + r * BD, y);
         }
         __syncthreads();
-        for (int i = w; i < L; i += 4) {      // one wave per query row (transformer.py:148-186)
+        for (int it = t; it < BH * L; it += NT) {          // transformer.py:148-186
+            const int i = it >> 2, h = it & 3;
             const bool mi = i < len;
+            float qs[BK];
+            {
+                const float4 q0 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[0], q1 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[1];
+                qs[0] = q0.x * QSCALE; qs[1] = q0.y * QSCALE; qs[2] = q0.z * QSCALE; qs[3] = q0.w * QSCALE;
+                qs[4] = q1.x * QSCALE; qs[5] = q1.y * QSCALE; qs[6] = q1.z * QSCALE; qs[7] = q1.w * QSCALE;
+            }
+            float mx = -INFINITY;
+            for (int j = 0; j < L; ++j) {
+                const float s = (mi && j < len) ? score(qs, Ks + j * BD + h * BK, Eks, j - i) : FILL;
+                mx = fmaxf(mx, s);
+            }
+            float sum = 0.f, o[BK];
+#pragma unroll
+            for (int d = 0; d < BK; ++d) o[d] = 0.f;
+            for (int j = 0; j < L; ++j) {
+                const int dj = j - i;
+                const float s = (mi && j < len) ? score(qs, Ks + j * BD + h * BK, Eks, dj) : FILL;
+                const float e = __expf(s - mx);
+                sum += e;
+                const float4 v0 = ((const float4*)(Vs + j * BD + h * BK))[0], v1 = ((const float4*)(Vs + j * BD + h * BK))[1];
+                o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
+                o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
+                if ((unsigned)(dj + BW) <= 2u * BW) {
+                    const float* ev = Evs + (dj + BW) * BK;
+#pragma unroll
+                    for (int d = 0; d < BK; ++d) o[d] = fmaf(e, ev[d], o[d]);
+                }
+            }
+            const float inv = 1.f / sum;
+            float4* ao = (float4*)(base + O_A * L + i * BD + h * BK);
+            ao[0] = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+            ao[1] = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+            base[O_LSE * L + h * L + i] = mx + logf(sum);
+        }
+        __syncthreads();
+        for (int r = t; r < L; r += NT) {                 // the rest of the layer, one row per thread
+            const bool valid = r < len;
+            float a[BD], x1[BD], s[BD];
+            load_row32(base + O_A * L + r * BD, a);
+            matvec32(a, as_const(W[I_WO]), as_const(W[I_BO]), s);              // conv_o (transformer.py:146)
+            load_row32(base + r * BD, a);
+#pragma unroll
+            for (int c = 0; c < BD; ++c) s[c] += a[c];      // x + y (transformer.py:46)
+            float mean, rs;
+            layernorm32(s, as_const(W[I_G1]), as_const(W[I_B1]), x1, mean, rs);
+            store_row32(base + O_S1 * L + r * BD, s);
+            store_row32(base + O_X1 * L + r * BD, x1);
+            base[O_ST * L + r * 4] = mean; base[O_ST * L + r * 4 + 1] = rs;
+            // FFN (transformer.py:283-291): 32 hidden units at a time — h = relu(conv_1(x * mask)), y += conv_2(h * mask)
+            float y[BD];
+#pragma unroll
+            for (int c = 0; c < BD; ++c) { y[c] = valid ? as_const(W[I_C2])[c] : 0.f; a[c] = valid ? x1[c] : 0.f; }
 #pragma unroll 1
-            for (int h = 0; h < BH; ++h) {
-                float qs[BK];
+            for (int f0 = 0; f0 < BF; f0 += BD) {
+                float hf[BD];
+                matvec32(a, as_const(W[I_W1]) + f0 * BD, as_const(W[I_C1]) + f0, hf);
 #pragma unroll
-                for (int d = 0; d < BK; ++d) qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE;
-                float s[MAXJ];
-                float mx = -INFINITY;
+                for (int j = 0; j < BD; ++j) hf[j] = fmaxf(hf[j], 0.f);
+                store_row32(base + O_H * L + r * BF + f0, hf);
+                if (valid) {
+#pragma unroll 4
+                    for (int c = 0; c < BD; ++c) {
+                        float acc = y[c];
+                        const cptr w2 = as_const(W[I_W2]) + c * BF + f0;
 #pragma unroll
-                for (int jt = 0; jt < MAXJ; ++jt) {
-                    s[jt] = -INFINITY;
-                    if (jt * 64 < L) {
-                        const int j = jt * 64 + lane;
-                        if (j < L) {
-                            const float* kr = Ks + j * KP + h * BK;
-                            float dot = 0.f;
-#pragma unroll
-                            for (int d = 0; d < BK; ++d) dot = fmaf(qs[d], kr[d], dot);
-                            const int dj = j - i;
-                            if (dj >= -BW && dj <= BW) {
-                                const float* er = Eks + (dj + BW) * BK;
-#pragma unroll
-                                for (int d = 0; d < BK; ++d) dot = fmaf(qs[d], er[d], dot);
-                            }
-                            s[jt] = (mi && j < len) ? dot : FILL;
-                        }
-                        mx = fmaxf(mx, s[jt]);
+                        for (int j = 0; j < BD; ++j) acc = fmaf(hf[j], w2[j], acc);
+                        y[c] = acc;
                     }
                 }
-                mx = wave_max(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int jt = 0; jt < MAXJ; ++jt)
-                    if (jt * 64 < L) { s[jt] = (jt * 64 + lane < L) ? expf(s[jt] - mx) : 0.f; sum += s[jt]; }
-                sum = wave_sum(sum);
-                const float inv = 1.f / sum;
-                float o[BK];
-#pragma unroll
-                for (int d = 0; d < BK; ++d) o[d] = 0.f;
-#pragma unroll
-                for (int jt = 0; jt < MAXJ; ++jt)
-                    if (jt * 64 < L) {
-                        const int j = jt * 64 + lane;
-                        if (j < L) {
-                            const float pj = s[jt] * inv;
-                            const float* vr = Vs + j * KP + h * BK;
-#pragma unroll
-                            for (int d = 0; d < BK; ++d) o[d] = fmaf(pj, vr[d], o[d]);
-                            const int dj = j - i;
-                            if (dj >= -BW && dj <= BW) {
-                                const float* er = Evs + (dj + BW) * BK;
-#pragma unroll
-                                for (int d = 0; d < BK; ++d) o[d] = fmaf(pj, er[d], o[d]);
-                            }
-                        }
-                    }
-#pragma unroll
-                for (int d = 0; d < BK; ++d) o[d] = wave_sum(o[d]);
-                if (lane == 0) {
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) base[O_A * L + i * BD + h * BK + d] = o[d];
-                    base[O_LSE * L + h * L + i] = mx + logf(sum);
-                }
             }
-        }
-        __syncthreads();
-        {   // x = LayerNorm(x + conv_o(attention))   (transformer.py:44-46)
-            float wo[BD];
 #pragma unroll
-            for (int k = 0; k < BD; ++k) wo[k] = W[I_WO][c * BD + k];
-            const float bo = W[I_BO][c], g1 = W[I_G1][c], b1 = W[I_B1][c];
-            for (int r0 = 0; r0 < L; r0 += 8) {
-                const int r = r0 + rg;
-                const bool ok = r < L;
-                const int rr = ok ? r : L - 1;
-                const float sv = xin[rr * BD + c] + dot32(base + O_A * L + rr * BD, wo, bo);
-                const float mean = half_sum(sv) * (1.f / BD);
-                const float dv = sv - mean;
-                const float rs = 1.f / sqrtf(half_sum(dv * dv) * (1.f / BD) + EPS);
-                if (ok) {
-                    base[O_S1 * L + r * BD + c] = sv;
-                    base[O_X1 * L + r * BD + c] = dv * rs * g1 + b1;
-                    if (c == 0) { base[O_ST * L + r * 4] = mean; base[O_ST * L + r * 4 + 1] = rs; }
-                }
-            }
+            for (int c = 0; c < BD; ++c) s[c] = x1[c] + y[c];      // y is already zero on padded rows (... * x_mask, transformer.py:291)
+            layernorm32(s, as_const(W[I_G2]), as_const(W[I_B2]), y, mean, rs);
+            store_row32(base + O_S2 * L + r * BD, s);
+            store_row32(base + (int64_t)O_LAYER * L + r * BD, y);
+            base[O_ST * L + r * 4 + 2] = mean; base[O_ST * L + r * 4 + 3] = rs;
         }
-        __syncthreads();
-        {   // h = relu(conv_1(x * mask))   (transformer.py:283-288)
-            const int f = t & 127;
-            float w1[BD];
-#pragma unroll
-            for (int k = 0; k < BD; ++k) w1[k] = W[I_W1][f * BD + k];
-            const float c1 = W[I_C1][f];
-            for (int r = t >> 7; r < L; r += 2) {
-                const float hv = r < len ? dot32(base + O_X1 * L + r * BD, w1, c1) : c1;
-                base[O_H * L + r * BF + f] = fmaxf(hv, 0.f);
-            }
-        }
-        __syncthreads();
-        {   // x = LayerNorm(x + conv_2(h * mask) * mask)   (transformer.py:290-291,48-50)
-            float w2[BF];
-#pragma unroll
-            for (int f = 0; f < BF; ++f) w2[f] = W[I_W2][c * BF + f];
-            const float c2 = W[I_C2][c], g2 = W[I_G2][c], b2 = W[I_B2][c];
-            float* xnext = base + (int64_t)O_LAYER * L;
-            for (int r0 = 0; r0 < L; r0 += 8) {
-                const int r = r0 + rg;
-                const bool ok = r < L;
-                const int rr = ok ? r : L - 1;
-                float y = 0.f;
-                if (rr < len) {
-                    const float4* h4 = (const float4*)(base + O_H * L + rr * BF);
-                    y = c2;
-#pragma unroll
-                    for (int f4 = 0; f4 < BF / 4; ++f4) {
-                        const float4 x = h4[f4];
-                        y = fmaf(x.x, w2[4 * f4], y); y = fmaf(x.y, w2[4 * f4 + 1], y); y = fmaf(x.z, w2[4 * f4 + 2], y); y = fmaf(x.w, w2[4 * f4 + 3], y);
-                    }
-                }
-                const float sv = base[O_X1 * L + rr * BD + c] + y;
-                const float mean = half_sum(sv) * (1.f / BD);
-                const float dv = sv - mean;
-                const float rs = 1.f / sqrtf(half_sum(dv * dv) * (1.f / BD) + EPS);
-                if (ok) {
-                    base[O_S2 * L + r * BD + c] = sv;
-                    xnext[r * BD + c] = dv * rs * g2 + b2;
-                    if (c == 0) { base[O_ST * L + r * 4 + 2] = mean; base[O_ST * L + r * 4 + 3] = rs; }
-                }
-            }
-        }
-        __syncthreads();
+        __syncthreads();      // LDS (K / V, the relative embeddings) is rewritten by the next layer
     }
     float* xfin = ws + (int64_t)p.n_layers * O_LAYER * L;
     for (int idx = len * BD + t; idx < L * BD; idx += NT) xfin[idx] = 0.f;          // transformer.py:51
@@ -241,28 +254,61 @@ __global__ __launch_bounds__(NT) void btse_bio_fwd_kernel(const SclBtseBio p) {
     }
 }
 
-// LayerNorm backward over the (row group, channel) mapping: dy rows in `gin`, pre-norm rows in `pre`, (mean, rstd) at st[4 r + so];
-// writes ds to `gout`, returns this thread's partial sums of dgamma / dbeta.
-__device__ __forceinline__ void ln_bwd_rows(const float* gin, const float* pre, const float* st, int so, float gamma, float* gout, int L, int rg, int c,
-                                            float& dg, float& db) {
-    dg = 0.f; db = 0.f;
-    for (int r0 = 0; r0 < L; r0 += 8) {
-        const int r = r0 + rg;
-        const bool ok = r < L;
-        const int rr = ok ? r : L - 1;
-        const float mu = st[rr * 4 + so], rs = st[rr * 4 + so + 1];
-        const float xh = (pre[rr * BD + c] - mu) * rs;
-        const float dy = ok ? gin[rr * BD + c] : 0.f;
-        dg = fmaf(dy, xh, dg); db += dy;
-        const float dxh = dy * gamma;
-        const float m1 = half_sum(dxh) * (1.f / BD), m2 = half_sum(dxh * xh) * (1.f / BD);
-        if (ok) gout[r * BD + c] = rs * (dxh - m1 - xh * m2);
+// ---- backward ---------------------------------------------------------------------------------------------------------------------------
+// dW[c][k] = sum_r dy[r][c] in[r][k] (and db[c] = sum_r dy[r][c]) for this utterance: 64-row chunks of both operands staged in LDS, a
+// thread owns output column kk and C K / 256 rows of dW in registers across the chunks.  Rows are summed in index order.
+template <int C, int K>
+__device__ __forceinline__ void wgrad_rows(const float* __restrict__ dy, const float* __restrict__ in, int L, float* __restrict__ dW, float* __restrict__ db,
+                                           float* stage, int t) {
+    constexpr int U = C * K / NT, G = NT / K;
+    const int kk = t % K, cg = t / K;
+    float acc[U], accb = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.f;
+    float* dyS = stage;
+    float* inS = stage + RC * C;
+    for (int r0 = 0; r0 < L; r0 += RC) {
+        const int nr = min(RC, L - r0);
+        __syncthreads();
+        for (int idx = t; idx < nr * C / 4; idx += NT) ((float4*)dyS)[idx] = ((const float4*)(dy + (int64_t)r0 * C))[idx];
+        for (int idx = t; idx < nr * K / 4; idx += NT) ((float4*)inS)[idx] = ((const float4*)(in + (int64_t)r0 * K))[idx];
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const float ik = inS[r * K + kk];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fmaf(dyS[r * C + cg + G * u], ik, acc[u]);
+            if (db && t < C) accb += dyS[r * C + t];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) dW[(cg + G * u) * K + kk] = acc[u];
+    if (db && t < C) db[t] = accb;
+}
+
+// dgamma[c] = sum_r dy[r][c] xhat[r][c], dbeta[c] = sum_r dy[r][c] over this utterance's rows (8 row groups x 32 channels, combined in order)
+__device__ __forceinline__ void ln_param_grads(const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ st, int so, int L,
+                                               float* __restrict__ dg, float* __restrict__ dbeta, float* red, int t) {
+    const int c = t & 31, rg = t >> 5;
+    float a = 0.f, bsum = 0.f;
+    for (int r = rg; r < L; r += 8) {
+        const float d = dy[r * BD + c];
+        a = fmaf(d, (pre[r * BD + c] - st[r * 4 + so]) * st[r * 4 + so + 1], a);
+        bsum += d;
+    }
+    __syncthreads();
+    red[rg * BD + c] = a; red[8 * BD + rg * BD + c] = bsum;
+    __syncthreads();
+    if (t < 2 * BD) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += red[(t >> 5) * 8 * BD + g * BD + (t & 31)];
+        (t < BD ? dg : dbeta)[t & 31] = s;
     }
 }
 
 __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
-    extern __shared__ float lds[];
-    __shared__ float Eks[NR * BK], Evs[NR * BK], red[8 * BD], red2[2 * BF], bandS[4][NR + 1], bandP[4][NR + 1], epart[4][2][NR * BK];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float Eks[NR * BK], Evs[NR * BK], red[16 * BD], epart[2][3][NR * BK];
     const int b = blockIdx.x, t = threadIdx.x, L = p.L;
     const int len = min(max(p.lens[b], 0), L);
     float* slab = p.slab + (int64_t)b * p.slab_ld;
@@ -273,9 +319,10 @@ __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
     float* ws = p.ws + (int64_t)b * p.ws_stride;
     const int32_t* tok = p.bio + (int64_t)b * L;
     const float* dsc = p.d_out + (int64_t)b * p.dout_ld;
-    float* A0 = lds;                 // K, then Q * scale
-    float* A1 = lds + L * KP;        // V, then dA
-    const int c = t & 31, rg = t >> 5, lane = t & 63, w = t >> 6;
+    float* A0 = lds;                 // K, then Q * scale     [L][32]
+    float* A1 = lds + L * BD;        // V, then dA            [L][32]
+    float* lseS = lds + 2 * L * BD;  // [4][L]
+    float* delS = lseS + BH * L;     // [4][L]
     float* G = ws + ((int64_t)p.n_layers * O_LAYER + BD) * L;
     float* gdx = G + G_DX * L;
     {   // scoring conv at the last position
@@ -294,260 +341,150 @@ __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
         float* base = ws + (int64_t)l * O_LAYER * L;
         const float* const* W = p.lw[l];
         const int32_t* go = p.go[l];
-        const float* xin = base;
         const float* st = base + O_ST * L;
         if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
-        {   // LayerNorm 2
-            float dg, db;
-            ln_bwd_rows(gdx, base + O_S2 * L, st, 2, W[I_G2][c], G + G_DS2 * L, L, rg, c, dg, db);
-            dg = rg_total(dg, red, rg, c); db = rg_total(db, red, rg, c);
-            if (rg == 0) { slab[go[I_G2] + c] = dg; slab[go[I_B2] + c] = db; }
-        }
-        const float* ds2 = G + G_DS2 * L;
-        {   // conv_2: bias, weight, input gradient (x ReLU')
-            float a = 0.f;
-            for (int r = rg; r < L; r += 8) a += ds2[r * BD + c];
-            a = rg_total(a, red, rg, c);
-            if (rg == 0) slab[go[I_C2] + c] = a;
-            const int f = t & 127, cg = t >> 7;
-            float acc[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-            for (int r = 0; r < L; ++r) {
-                const float hv = base[O_H * L + r * BF + f];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u] = fmaf(ds2[r * BD + cg + 2 * u], hv, acc[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) slab[go[I_W2] + (cg + 2 * u) * BF + f] = acc[u];
-            float w2c[BD];
-#pragma unroll
-            for (int k = 0; k < BD; ++k) w2c[k] = W[I_W2][k * BF + f];
-            float dc1 = 0.f;
-            for (int r = cg; r < L; r += 2) {
-                float v = dot32(ds2 + r * BD, w2c, 0.f);
-                v = base[O_H * L + r * BF + f] > 0.f ? v : 0.f;
-                G[G_DH * L + r * BF + f] = v;
-                dc1 += v;
-            }
-            red2[cg * BF + f] = dc1;
-            __syncthreads();
-            if (t < BF) slab[go[I_C1] + t] = red2[t] + red2[BF + t];
-        }
+        // (0) LayerNorm 2's parameter gradients need d x_out itself: before (1) re-uses the buffer
+        ln_param_grads(gdx, base + O_S2 * L, st, 2, L, slab + go[I_G2], slab + go[I_B2], red, t);
         __syncthreads();
-        const float* gdh = G + G_DH * L;
-        {   // conv_1: weight and input gradient; + the residual branch
-            const int fg = rg;
-            float acc[16];
+        // (1) one row per thread: LayerNorm 2, the FFN, LayerNorm 1, the out-projection — data gradients only
+        for (int r = t; r < L; r += NT) {
+            float dy[BD], s[BD], ds2[BD], dx1[BD];
+            load_row32(gdx + r * BD, dy);
+            load_row32(base + O_S2 * L + r * BD, s);
+            layernorm32_bwd(dy, s, st[r * 4 + 2], st[r * 4 + 3], as_const(W[I_G2]), ds2);
+            store_row32(G + G_DS2 * L + r * BD, ds2);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-            for (int r = 0; r < L; ++r) {
-                const float xk = base[O_X1 * L + r * BD + c];
+            for (int k = 0; k < BD; ++k) dx1[k] = ds2[k];      // the residual branch
+#pragma unroll 1
+            for (int f0 = 0; f0 < BF; f0 += BD) {
+                float dh[BD], hf[BD];
+                load_row32(base + O_H * L + r * BF + f0, hf);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u] = fmaf(gdh[r * BF + fg + 8 * u], xk, acc[u]);
-            }
+                for (int j = 0; j < BD; ++j) dh[j] = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < BD; ++c) {
+                    const float dc = ds2[c];
+                    const cptr w2 = as_const(W[I_W2]) + c * BF + f0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) slab[go[I_W1] + (fg + 8 * u) * BD + c] = acc[u];
-            float w1c[BF];
-#pragma unroll
-            for (int f = 0; f < BF; ++f) w1c[f] = W[I_W1][f * BD + c];
-            for (int r = rg; r < L; r += 8) {
-                const float4* g4 = (const float4*)(gdh + r * BF);
-                float a = ds2[r * BD + c];
-#pragma unroll
-                for (int f4 = 0; f4 < BF / 4; ++f4) {
-                    const float4 x = g4[f4];
-                    a = fmaf(x.x, w1c[4 * f4], a); a = fmaf(x.y, w1c[4 * f4 + 1], a); a = fmaf(x.z, w1c[4 * f4 + 2], a); a = fmaf(x.w, w1c[4 * f4 + 3], a);
+                    for (int j = 0; j < BD; ++j) dh[j] = fmaf(dc, w2[j], dh[j]);
                 }
-                gdx[r * BD + c] = a;
+#pragma unroll
+                for (int j = 0; j < BD; ++j) dh[j] = hf[j] > 0.f ? dh[j] : 0.f;
+                store_row32(G + G_DH * L + r * BF + f0, dh);
+                matvec32_t(dh, as_const(W[I_W1]) + f0 * BD, dx1);
             }
+            load_row32(base + O_S1 * L + r * BD, s);
+            layernorm32_bwd(dx1, s, st[r * 4], st[r * 4 + 1], as_const(W[I_G1]), dy);      // dy := d s1
+            store_row32(G + G_DS1 * L + r * BD, dy);
+            store_row32(gdx + r * BD, dx1);                                        // kept for LayerNorm 1's parameter gradients
+#pragma unroll
+            for (int k = 0; k < BD; ++k) s[k] = 0.f;
+            matvec32_t(dy, as_const(W[I_WO]), s);
+            store_row32(G + G_DA * L + r * BD, s);
         }
         __syncthreads();
-        {   // LayerNorm 1
-            float dg, db;
-            ln_bwd_rows(gdx, base + O_S1 * L, st, 0, W[I_G1][c], G + G_DS1 * L, L, rg, c, dg, db);
-            dg = rg_total(dg, red, rg, c); db = rg_total(db, red, rg, c);
-            if (rg == 0) { slab[go[I_G1] + c] = dg; slab[go[I_B1] + c] = db; }
-        }
+        const float* ds2 = G + G_DS2 * L;
         const float* ds1 = G + G_DS1 * L;
-        {   // conv_o
-            float a = 0.f;
-            for (int r = rg; r < L; r += 8) a += ds1[r * BD + c];
-            a = rg_total(a, red, rg, c);
-            if (rg == 0) slab[go[I_BO] + c] = a;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int r = 0; r < L; ++r) {
-                const float ak = base[O_A * L + r * BD + c];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = fmaf(ds1[r * BD + rg + 8 * u], ak, acc[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) slab[go[I_WO] + (rg + 8 * u) * BD + c] = acc[u];
-            float woc[BD];
-#pragma unroll
-            for (int k = 0; k < BD; ++k) woc[k] = W[I_WO][k * BD + c];
-            for (int r = rg; r < L; r += 8) G[G_DA * L + r * BD + c] = dot32(ds1 + r * BD, woc, 0.f);
-            for (int r = rg; r < L; r += 8) { A0[r * KP + c] = base[O_K * L + r * BD + c]; A1[r * KP + c] = base[O_V * L + r * BD + c]; }
-        }
+        // (2) parameter gradients of those layers
+        wgrad_rows<BD, BF>(ds2, base + O_H * L, L, slab + go[I_W2], slab + go[I_C2], lds, t);
+        wgrad_rows<BF, BD>(G + G_DH * L, base + O_X1 * L, L, slab + go[I_W1], slab + go[I_C1], lds, t);
+        wgrad_rows<BD, BD>(ds1, base + O_A * L, L, slab + go[I_WO], slab + go[I_BO], lds, t);
+        ln_param_grads(gdx, base + O_S1 * L, st, 0, L, slab + go[I_G1], slab + go[I_B1], red, t);
+        __syncthreads();
+        // (3) attention, pass 1: thread per (query row, head) -> dq, delta, the band of dS / P for the relative-embedding gradients
+        for (int idx = t; idx < L * BD / 4; idx += NT) { ((float4*)A0)[idx] = ((const float4*)(base + O_K * L))[idx]; ((float4*)A1)[idx] = ((const float4*)(base + O_V * L))[idx]; }
         __syncthreads();
         const float* gda = G + G_DA * L;
-        {   // attention, pass 1: one wave per query row -> dq, delta, the relative-embedding gradients
-            float aEk0 = 0.f, aEk1 = 0.f, aEv0 = 0.f, aEv1 = 0.f;
-            for (int i = w; i < L; i += 4) {
-#pragma unroll 1
-                for (int h = 0; h < BH; ++h) {
-                    float qs[BK], da[BK];
+        for (int it = t; it < BH * L; it += NT) {
+            const int i = it >> 2, h = it & 3;
+            float qs[BK], da[BK], dq[BK];
 #pragma unroll
-                    for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE; da[d] = gda[i * BD + h * BK + d]; }
-                    const float lse = base[O_LSE * L + h * L + i];
-                    float pv[MAXJ], dP[MAXJ];
-                    float part = 0.f;
+            for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE; da[d] = gda[i * BD + h * BK + d]; dq[d] = 0.f; }
+            const float lse = base[O_LSE * L + h * L + i];
+            float delta = 0.f;
+            for (int j = 0; j < L; ++j) {
+                const int dj = j - i;
+                const float pij = __expf(score(qs, A0 + j * BD + h * BK, Eks, dj) - lse);
+                delta = fmaf(pij, score(da, A1 + j * BD + h * BK, Evs, dj), delta);
+            }
+            float* bS = G + G_BS * L + (i * BH + h) * NR;
+            float* bP = G + G_BP * L + (i * BH + h) * NR;
 #pragma unroll
-                    for (int jt = 0; jt < MAXJ; ++jt) {
-                        pv[jt] = 0.f; dP[jt] = 0.f;
-                        if (jt * 64 < L) {
-                            const int j = jt * 64 + lane;
-                            if (j < L) {
-                                const float* kr = A0 + j * KP + h * BK;
-                                const float* vr = A1 + j * KP + h * BK;
-                                float dot = 0.f, g = 0.f;
+            for (int r = 0; r < NR; ++r) { bS[r] = 0.f; bP[r] = 0.f; }
+            for (int j = 0; j < L; ++j) {
+                const int dj = j - i;
+                const float* kr = A0 + j * BD + h * BK;
+                const float pij = __expf(score(qs, kr, Eks, dj) - lse);
+                const float dS = pij * (score(da, A1 + j * BD + h * BK, Evs, dj) - delta);
 #pragma unroll
-                                for (int d = 0; d < BK; ++d) { dot = fmaf(qs[d], kr[d], dot); g = fmaf(da[d], vr[d], g); }
-                                const int dj = j - i;
-                                if (dj >= -BW && dj <= BW) {
-                                    const float* ek = Eks + (dj + BW) * BK;
-                                    const float* ev = Evs + (dj + BW) * BK;
+                for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
+                if ((unsigned)(dj + BW) <= 2u * BW) {
+                    const float* ek = Eks + (dj + BW) * BK;
 #pragma unroll
-                                    for (int d = 0; d < BK; ++d) { dot = fmaf(qs[d], ek[d], dot); g = fmaf(da[d], ev[d], g); }
-                                }
-                                pv[jt] = expf(dot - lse);
-                                dP[jt] = g;
-                                part = fmaf(pv[jt], g, part);
-                            }
-                        }
-                    }
-                    const float delta = wave_sum(part);
-                    float dq[BK];
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) dq[d] = 0.f;
-                    if (lane <= NR) { bandS[w][lane] = 0.f; bandP[w][lane] = 0.f; }
-#pragma unroll
-                    for (int jt = 0; jt < MAXJ; ++jt)
-                        if (jt * 64 < L) {
-                            const int j = jt * 64 + lane;
-                            if (j < L) {
-                                const float dS = pv[jt] * (dP[jt] - delta);
-                                const float* kr = A0 + j * KP + h * BK;
-#pragma unroll
-                                for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
-                                const int dj = j - i;
-                                if (dj >= -BW && dj <= BW) {
-                                    const float* ek = Eks + (dj + BW) * BK;
-#pragma unroll
-                                    for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
-                                    bandS[w][dj + BW] = dS; bandP[w][dj + BW] = pv[jt];
-                                }
-                            }
-                        }
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) dq[d] = wave_sum(dq[d]);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int d = 0; d < BK; ++d) G[G_Q * L + i * BD + h * BK + d] = dq[d] * QSCALE;
-                        G[G_DELTA * L + h * L + i] = delta;
-                    }
-                    wave_sync_lds();
-                    {   // d emb_rel_k[r][d] += dS[i][i + r - 4] qs[d];  d emb_rel_v[r][d] += p[i][i + r - 4] da[d]   (lane = 8 r + d; r = 8 on lanes 0-7 again)
-                        const int d = lane & 7;
-                        const float qd = base[O_Q * L + i * BD + h * BK + d] * QSCALE, dd = gda[i * BD + h * BK + d];
-                        aEk0 = fmaf(bandS[w][lane >> 3], qd, aEk0); aEv0 = fmaf(bandP[w][lane >> 3], dd, aEv0);
-                        if (lane < BK) { aEk1 = fmaf(bandS[w][NR - 1], qd, aEk1); aEv1 = fmaf(bandP[w][NR - 1], dd, aEv1); }
-                    }
-                    wave_sync_lds();
+                    for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
+                    bS[dj + BW] = dS; bP[dj + BW] = pij;
                 }
             }
-            epart[w][0][lane] = aEk0; epart[w][1][lane] = aEv0;
-            if (lane < BK) { epart[w][0][64 + lane] = aEk1; epart[w][1][64 + lane] = aEv1; }
+#pragma unroll
+            for (int d = 0; d < BK; ++d) G[G_Q * L + i * BD + h * BK + d] = dq[d] * QSCALE;
+            lseS[h * L + i] = lse; delS[h * L + i] = delta;
         }
+        __syncthreads();
+        // (4) relative-embedding gradients: d emb_rel_k[r][d] = sum_(i,h) dS[i][i + r - 4] qs_i[d], d emb_rel_v[r][d] = sum P[i][i + r - 4] dA_i[d];
+        //     144 outputs x 3 row ranges, combined in order;  then Q * scale and dA replace K and V in LDS for pass 2
+        for (int wi = t; wi < 3 * 2 * NR * BK; wi += NT) {
+            const int part = wi / (2 * NR * BK), e = wi % (2 * NR * BK), which = e / (NR * BK), rd = e % (NR * BK), r = rd >> 3, d = rd & 7;
+            const int i0 = (L * part) / 3, i1 = (L * (part + 1)) / 3;
+            const float* bsrc = G + (which ? G_BP : G_BS) * L;
+            const float* vsrc = which ? gda : base + O_Q * L;
+            const float sc = which ? 1.f : QSCALE;
+            float a = 0.f;
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int h = 0; h < BH; ++h) a = fmaf(bsrc[(i * BH + h) * NR + r], vsrc[i * BD + h * BK + d] * sc, a);
+            epart[which][part][rd] = a;
+        }
+        for (int idx = t; idx < L * BD; idx += NT) { A0[idx] = base[O_Q * L + idx] * QSCALE; A1[idx] = gda[idx]; }
         __syncthreads();
         if (t < 2 * NR * BK) {
-            const int which = t / (NR * BK), e = t % (NR * BK);
-            slab[go[which ? I_EV : I_EK] + e] = epart[0][which][e] + epart[1][which][e] + epart[2][which][e] + epart[3][which][e];
+            const int which = t / (NR * BK), rd = t % (NR * BK);
+            slab[go[which ? I_EV : I_EK] + rd] = (epart[which][0][rd] + epart[which][1][rd]) + epart[which][2][rd];
         }
-        for (int r = rg; r < L; r += 8) { A0[r * KP + c] = base[O_Q * L + r * BD + c] * QSCALE; A1[r * KP + c] = gda[r * BD + c]; }
-        __syncthreads();
-        for (int j = w; j < L; j += 4) {      // attention, pass 2: one wave per key row -> dk, dv
-#pragma unroll 1
-            for (int h = 0; h < BH; ++h) {
-                float kj[BK], vj[BK], dk[BK], dv[BK];
+        // (5) attention, pass 2: thread per (key row, head) -> dk, dv
+        for (int it = t; it < BH * L; it += NT) {
+            const int j = it >> 2, h = it & 3;
+            float kj[BK], vj[BK], dk[BK], dv[BK];
 #pragma unroll
-                for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + j * BD + h * BK + d]; vj[d] = base[O_V * L + j * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
+            for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + j * BD + h * BK + d]; vj[d] = base[O_V * L + j * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
+            for (int i = 0; i < L; ++i) {
+                const int dj = j - i;
+                const float* qr = A0 + i * BD + h * BK;
+                const float* ar = A1 + i * BD + h * BK;
+                const bool band = (unsigned)(dj + BW) <= 2u * BW;
+                const float sij = dot8(qr, kj) + (band ? dot8_lds(qr, Eks + (dj + BW) * BK) : 0.f);      // q_i . (k_j + emb_rel_k[j - i + 4])
+                const float g = dot8(ar, vj) + (band ? dot8_lds(ar, Evs + (dj + BW) * BK) : 0.f);         // dA_i . (v_j + emb_rel_v[j - i + 4])
+                const float pij = __expf(sij - lseS[h * L + i]);
+                const float dS = pij * (g - delS[h * L + i]);
 #pragma unroll
-                for (int it = 0; it < MAXJ; ++it)
-                    if (it * 64 < L) {
-                        const int i = it * 64 + lane;
-                        if (i < L) {
-                            const float* qr = A0 + i * KP + h * BK;
-                            const float* ar = A1 + i * KP + h * BK;
-                            float dot = 0.f, g = 0.f;
-#pragma unroll
-                            for (int d = 0; d < BK; ++d) { dot = fmaf(qr[d], kj[d], dot); g = fmaf(ar[d], vj[d], g); }
-                            const int dj = j - i;
-                            if (dj >= -BW && dj <= BW) {
-                                const float* ek = Eks + (dj + BW) * BK;
-                                const float* ev = Evs + (dj + BW) * BK;
-#pragma unroll
-                                for (int d = 0; d < BK; ++d) { dot = fmaf(qr[d], ek[d], dot); g = fmaf(ar[d], ev[d], g); }
-                            }
-                            const float pij = expf(dot - base[O_LSE * L + h * L + i]);
-                            const float dS = pij * (g - G[G_DELTA * L + h * L + i]);
-#pragma unroll
-                            for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
-                        }
-                    }
-#pragma unroll
-                for (int d = 0; d < BK; ++d) { dk[d] = wave_sum(dk[d]); dv[d] = wave_sum(dv[d]); }
-                if (lane == 0) {
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) { G[G_K * L + j * BD + h * BK + d] = dk[d]; G[G_V * L + j * BD + h * BK + d] = dv[d]; }
-                }
+                for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
             }
+#pragma unroll
+            for (int d = 0; d < BK; ++d) { G[G_K * L + j * BD + h * BK + d] = dk[d]; G[G_V * L + j * BD + h * BK + d] = dv[d]; }
         }
         __syncthreads();
-        {   // conv_q / conv_k / conv_v: biases, weights, input gradient + the residual branch
-            const float* gq = G + G_Q * L;
-            const float* gk = G + G_K * L;
-            const float* gv = G + G_V * L;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            for (int r = rg; r < L; r += 8) { a0 += gq[r * BD + c]; a1 += gk[r * BD + c]; a2 += gv[r * BD + c]; }
-            a0 = rg_total(a0, red, rg, c); a1 = rg_total(a1, red, rg, c); a2 = rg_total(a2, red, rg, c);
-            if (rg == 0) { slab[go[I_BQ] + c] = a0; slab[go[I_BK] + c] = a1; slab[go[I_BV] + c] = a2; }
-            float acc[12];
-#pragma unroll
-            for (int u = 0; u < 12; ++u) acc[u] = 0.f;
-            for (int r = 0; r < L; ++r) {
-                const float xk = xin[r * BD + c];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[u] = fmaf(gq[r * BD + rg + 8 * u], xk, acc[u]);
-                    acc[4 + u] = fmaf(gk[r * BD + rg + 8 * u], xk, acc[4 + u]);
-                    acc[8 + u] = fmaf(gv[r * BD + rg + 8 * u], xk, acc[8 + u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                slab[go[I_WQ] + (rg + 8 * u) * BD + c] = acc[u];
-                slab[go[I_WK] + (rg + 8 * u) * BD + c] = acc[4 + u];
-                slab[go[I_WV] + (rg + 8 * u) * BD + c] = acc[8 + u];
-            }
-            float wqc[BD], wkc[BD], wvc[BD];
-#pragma unroll
-            for (int k = 0; k < BD; ++k) { wqc[k] = W[I_WQ][k * BD + c]; wkc[k] = W[I_WK][k * BD + c]; wvc[k] = W[I_WV][k * BD + c]; }
-            for (int r = rg; r < L; r += 8) {
-                float a = ds1[r * BD + c];
-                a = dot32(gq + r * BD, wqc, a); a = dot32(gk + r * BD, wkc, a); a = dot32(gv + r * BD, wvc, a);
-                gdx[r * BD + c] = a;
-            }
+        // (6) conv_q / conv_k / conv_v: parameter gradients, LayerNorm 2's parameter gradients of the layer BELOW are due there; input gradient
+        const float* xin = base;
+        wgrad_rows<BD, BD>(G + G_Q * L, xin, L, slab + go[I_WQ], slab + go[I_BQ], lds, t);
+        wgrad_rows<BD, BD>(G + G_K * L, xin, L, slab + go[I_WK], slab + go[I_BK], lds, t);
+        wgrad_rows<BD, BD>(G + G_V * L, xin, L, slab + go[I_WV], slab + go[I_BV], lds, t);
+        __syncthreads();
+        for (int r = t; r < L; r += NT) {
+            float d[BD], y[BD];
+            load_row32(ds1 + r * BD, y);                       // the residual branch
+            load_row32(G + G_Q * L + r * BD, d); matvec32_t(d, as_const(W[I_WQ]), y);
+            load_row32(G + G_K * L + r * BD, d); matvec32_t(d, as_const(W[I_WK]), y);
+            load_row32(G + G_V * L + r * BD, d); matvec32_t(d, as_const(W[I_WV]), y);
+            store_row32(gdx + r * BD, y);
         }
         __syncthreads();
     }
@@ -632,7 +569,7 @@ extern "C" int64_t scl_btse_bio_ws_floats(int n_layers, int L) { return ((int64_
 extern "C" int scl_btse_bio_fwd(const SclBtseBio* p, void* stream) {
     const int rc = bio_check(p, "btse_bio_fwd", false);
     if (rc != SCL_OK) return rc;
-    const size_t lds = (size_t)2 * p->L * KP * sizeof(float);
+    const size_t lds = (size_t)2 * p->L * BD * sizeof(float);
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)btse_bio_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(btse_bio_fwd_kernel, dim3(p->B), dim3(NT), lds, (hipStream_t)stream, *p);
     return scl_check_launch("scl_btse_bio_fwd");
@@ -640,7 +577,9 @@ extern "C" int scl_btse_bio_fwd(const SclBtseBio* p, void* stream) {
 extern "C" int scl_btse_bio_bwd(const SclBtseBio* p, void* stream) {
     const int rc = bio_check(p, "btse_bio_bwd", true);
     if (rc != SCL_OK) return rc;
-    const size_t lds = (size_t)2 * p->L * KP * sizeof(float);
+    size_t lds = (size_t)(2 * p->L * BD + 2 * BH * p->L) * sizeof(float);      // K / V (then Q / dA) + the rows' log-sum-exp and delta
+    const size_t stage = (size_t)RC * (BD + BF) * sizeof(float);                 // the widest weight-gradient staging chunk
+    if (lds < stage) lds = stage;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)btse_bio_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(btse_bio_bwd_kernel, dim3(p->B), dim3(NT), lds, (hipStream_t)stream, *p);
     return scl_check_launch("scl_btse_bio_bwd");
