@@ -326,10 +326,10 @@ def main():
     flop_per_utt = FLOP_PER_UTT_STEP_64000 if (L == 64000 and not args.tiny) else None
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # HBM traffic per GEMM launch cannot be read live (PMC needs rocprofv3): take it from the committed counter pass of this
-    # same command (profiles/r4_pmc_hbm_traffic.json, or the previous round's; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
+    # same command (profiles/r5_pmc_hbm_traffic.json, or a previous round's; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
     # while the GEMM sources are the ones that pass was taken with (its "gemm_src_sha"), else null
     traffic = None
-    for tag in ("r4", "r3"):
+    for tag in ("r5", "r4", "r3"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)) as f:
                 pmc = json.load(f)

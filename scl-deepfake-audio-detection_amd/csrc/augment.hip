@@ -276,7 +276,7 @@ extern "C" int scl_fir_multi_f32(const float* x, int64_t ldx, int Lin, const flo
     SCL_REQUIRE(nclip >= 1 && nclip <= 65535 && nf >= 1 && Lin >= 1 && Lout >= 1, "fir: bad dims");
     dim3 grid(scl_fir_nblocks(Lout), nclip), block(256);
     SclProfScope prof(SCL_KID_AUG, (hipStream_t)stream, 0.0);
-    static const int mode = [] { const char* e = getenv("SCL_FIR_MODE"); return e ? atoi(e) : 0; }();
+    const int mode = 0;      // the three instruction forms measured equal (fir_kernel); the switch is gone
     if (mode == 2) hipLaunchKernelGGL(fir_kernel<2>, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
     else hipLaunchKernelGGL(fir_kernel<0>, grid, block, 0, (hipStream_t)stream, x, ldx, Lin, taps, tap_off, tap_len, tap_h, nf, use_pow, y, ldy, Lout, part);
     return scl_check_launch("scl_fir_multi_f32");

@@ -697,7 +697,7 @@ namespace {
 // wide tiles with a runtime row pitch (gemm_w8.hip): whole rounds of the 256 CUs at M = 64 x 199 rows; picked when the problem fills at
 // least half a round of them and the operands advance linearly along K
 bool gemm_pick_w8(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, W8Plan* plan) {
-    static const int w8_env = [] { const char* e = getenv("SCL_GEMM_W8"); return e ? atoi(e) : 1; }();
+    const int w8_env = 1;
     if (d.flags & (SCL_GEMM_NO_W8 | SCL_GEMM_FORCE_P8 | SCL_GEMM_FORCE_BIG | SCL_GEMM_NO_DMA)) return false;
     const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0);
     const bool b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
@@ -780,7 +780,7 @@ static int gemm_fill_k(const SclGemmDesc& d, GemmK& k) {
     k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
     k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
-    static const int group_m_env = [] { const char* e = getenv("SCL_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();
+    const int group_m_env = 8;      // 2 .. 62 swept in round 3: 8 and 16 equal, the extremes slower
     static const bool epi_generic = [] { const char* e = getenv("SCL_W8_EPI_GENERIC"); return e && atoi(e) != 0; }();
     k.group_m = group_m_env; k.tile_m = 0; k.debug = epi_generic ? 16 : 0;      // bit 4: generic epilogue loops (A/B); the wide launch sets its own bits
     // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias

@@ -890,7 +890,6 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
     // The ping-pong loop stays for utterance-batched K rows (below) and as SCL_W8_MODE=0.
     const char* me = getenv("SCL_W8_MODE");
     int mode = (me && *me) ? atoi(me) : 1;
-    if (at && bt) { const char* mt = getenv("SCL_W8_MODE_TT"); if (mt && *mt) mode = atoi(mt); }      // A/B of the weight-gradient loop alone
     if (at && bt) {      // utterance-batched K rows (see scl_gemm_w8_plan): only the ping-pong loop computes per-step offsets
         if ((long long)k.A.rpb < (long long)k.K) { k.debug |= 4; mode = 0; }
         if ((long long)k.B.rpb < (long long)k.K) { k.debug |= 8; mode = 0; }

@@ -456,7 +456,7 @@ extern "C" int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, c
                 "layernorm_fwd: need 8 <= C <= 2048, C, ldx, ldy multiples of 8 (C=%d)", C);
     dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
-    static const int nr_env = [] { const char* e = getenv("SCL_LN_ROWS"); return e ? atoi(e) : 2; }();
+    const int nr_env = 2;
     const int nr = (nr_env == 2 && C <= 1024 && M >= 4096) ? 2 : 1;
     dim3 grid((M + 4 * nr - 1) / (4 * nr));
 #define LN_FWD(XF, NR) hipLaunchKernelGGL((ln_fwd_kernel<XF, NR>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, C, ldx, ldy, eps, act)

@@ -20,18 +20,18 @@ from . import ops
 from .lib import ACT_GELU, ACT_GELU_DC2, FLAT, RACT_STORED
 from .ops import Op
 
-# fc1.bias.grad summed by the epilogue of the GEMM that writes its input (SCL_FUSED_BIAS_GRAD=0: a separate pass over the 104 MB tensor)
-FUSED_BIAS_GRAD = os.environ.get("SCL_FUSED_BIAS_GRAD", "1") != "0"
+# fc1.bias.grad summed by the epilogue of the GEMM that writes its input
+FUSED_BIAS_GRAD = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 # 12-31-tile weight gradients (out-proj: 16 tiles of 256 x 256) in up to 16 split-K slabs on the wide kernel.  Round-3 re-measurement in one
 # call, three pairs: 47.78 / 47.59 / 47.66 ms per step off, 47.76 / 47.29 / 47.26 on (launch + slab reduction: 61.4 -> 53.8 us) — the earlier
 # "slower" verdict (53.7 vs 51.9 on different boxes) was box-to-box noise.
-WGRAD_SMALL_SPLIT = os.environ.get("SCL_WGRAD_SMALL_SPLIT", "1") != "0"
-# the (up to) four small column reductions that close a layer's backward in ONE launch (SCL_BATCH_REDUCE=0: one launch each)
-BATCH_REDUCE = os.environ.get("SCL_BATCH_REDUCE", "1") != "0"
+WGRAD_SMALL_SPLIT = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
+# the (up to) four small column reductions that close a layer's backward in ONE launch
+BATCH_REDUCE = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 # the split-K slabs of a layer's four weight gradients are combined by ONE launch at the end of the layer's backward (each gradient keeps
 # its own slab buffer until then) instead of one launch behind every weight-gradient GEMM: 72 kernel boundaries per step less
-# (SCL_BATCH_SLABS=0: as before; bit-identical either way)
-BATCH_SLABS = os.environ.get("SCL_BATCH_SLABS", "1") != "0"
+#
+BATCH_SLABS = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 # the four weight gradients of a transformer layer as ONE grouped launch at the end of the layer's backward (ops.gemm_group: 16 + 48 + 64 + 64
 # tiles of 256 x 256, every block walks the whole reduction, finished tiles go straight into the flat gradient buffer): no split-K slabs, no
 # slab reduction, 5 launches -> 1.  SCL_WGRAD_GROUP=0: one split-K launch per gradient + the layer's slab combine, as rounds 2-4 ran.
@@ -39,14 +39,14 @@ BATCH_SLABS = os.environ.get("SCL_BATCH_SLABS", "1") != "0"
 WGRAD_GROUP = os.environ.get("SCL_WGRAD_GROUP", "1") != "0"
 WGRAD_GROUP_MIN_KSTEPS = 16      # from 1024 rows on (measured: 11 x 199 rows 16.2 -> 14.2 ms per step, 16 x 199 20.8 -> 17.6, 32 x 199 29.1 -> 26.1, 64 x 199 44.1 -> 42.5)
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
-POSCONV_MFMA = os.environ.get("SCL_POSCONV_MFMA", "1") != "0"
+POSCONV_MFMA = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 # fc1's forward epilogue stores gelu'(pre-activation) (one erf / exp evaluation serves gelu and its derivative) and fc2's data-gradient
 # epilogue multiplies by the stored number; 0 = store the pre-activation and re-evaluate gelu' in the backward epilogue (rounds 1-2)
-GELU_DC2 = os.environ.get("SCL_GELU_DC2", "1") != "0"
+GELU_DC2 = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 # BASELINE.json configs[4] names fp8 attention: csrc/attention_fp8.hip (e4m3 operands, fp32 accumulation) for the no-grad bf16 forward.  Opt-in:
 # the reference is fp32 and the fused forward is bound by its soft-max VALU work, not by the matrix pipe (profiles/r4_attn_fp8_probe.txt).
 ATTN_FP8 = os.environ.get("SCL_ATTN_FP8", "0") == "1"
-CONV_WGRAD_WIDE = os.environ.get("SCL_CONV_WGRAD_WIDE", "1") != "0"
+CONV_WGRAD_WIDE = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 
 
 class W2VConfig:
@@ -319,7 +319,7 @@ class Encoder:
         # wide tiles (gemm_w8.hip: 256 x 256 output tiles, one 8-wave block per CU): size the split for one round of the 256 CUs
         t256 = ((Mo + 255) // 256) * ((No + 255) // 256) * kw.get("nb2", 1)
         # 12-31 tiles with a very long reduction (conv-stack weight gradients: 12 tiles, 800-6400 K steps, utterance-batched K rows): 16 slabs
-        # of >= 50 steps each on the wide ping-pong kernel instead of the 128 x 128 one (SCL_CONV_WGRAD_WIDE=0: as before)
+        # of >= 50 steps each on the wide ping-pong kernel instead of the 128 x 128 one
         if t256 >= 32 or ((WGRAD_SMALL_SPLIT or (CONV_WGRAD_WIDE and ksteps >= 700)) and t256 >= 12):
             # 12-31 tiles (out-proj: 16): up to 16 slabs fill the 256 CUs once; the 128 x 128 sizing below left 160 blocks of 25 K steps
             # slabs: one round of the 256 CUs; at most 8 (>= 32 tiles) / 16 (12-31 tiles) / 21 (12 tiles and >= 700 K steps: the conv layers;

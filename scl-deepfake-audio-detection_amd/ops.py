@@ -103,7 +103,7 @@ class Op:
 F32X3 = os.environ.get("SCL_F32X3", "1") != "0"
 
 _SPLITK_WS = {}      # per stream: f32 slabs of the automatic split-K path (old, smaller ones stay alive: recorded plans point into them)
-_AUTO_SPLITK = os.environ.get("SCL_GEMM_AUTO_SPLITK", "1") == "1"
+_AUTO_SPLITK = True
 
 
 def _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, f32):

@@ -1,5 +1,5 @@
 """LayerNorm forward / backward alone at the encoder's shapes: us per launch and effective HBM rate (algorithmic bytes / time).
-Run once per setting of SCL_LN_ROWS (read once per process)."""
+The rows-per-wave choice is fixed (2) since round 4."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,4 +20,4 @@ for M, C in ((12736, 1024), (64 * 3199, 512), (6368, 1024)):
     for i in range(60): fwd(i)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / 60
-    print("SCL_LN_ROWS=%s ln_fwd f32->bf16 M=%d C=%d: %.1f us  %.2f TB/s" % (os.environ.get("SCL_LN_ROWS", "default"), M, C, us, M * C * 6 / us / 1e6))
+    print("SCL_LN_ROWS=%s ln_fwd f32->bf16 M=%d C=%d: %.1f us  %.2f TB/s" % ("2", M, C, us, M * C * 6 / us / 1e6))
