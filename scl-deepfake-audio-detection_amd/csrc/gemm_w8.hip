@@ -817,7 +817,7 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
         // the K loop of either tile is bound by the per-CU L2 -> LDS feed (stamps + ablation, profiles/r2_gemm_*): a round costs
         // ~ (tile rows + 256 columns) x K bytes per CU, not the MFMA count
         const int bm = v == 0 ? 208 : 256;
-        const long long ntm = (d.M + bm - 1) / bm;
+        const long long ntm = (d.M + bm - 1) / bm;      // (round 5: 64 tiles of 199 rows instead of 62 of 206 at M = 12736 — a full last round, 3.4 % fewer rows per tile — measured 113.7 vs 112.5 us per launch: no gain, not kept)
         const long long rounds = (ntm * tiles_n * zdim + ncu - 1) / ncu;
         const long long cost = rounds * (bm + W8_BN);
         if (best < 0 || cost < best) {
