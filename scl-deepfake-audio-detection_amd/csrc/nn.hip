@@ -68,7 +68,52 @@ __device__ __forceinline__ void slab_reduce(int N, int C, double* part, int slab
     }
 }
 
+// The same reduction with 16-byte loads (C a power of two in 4 .. 512): a thread owns 4 consecutive channels, the block covers 1024 elements
+// (1024 / C rows) per trip, four trips in flight.  Round 5: the scalar form read three maps with 4-byte loads and ran the ResNet back-end's
+// BatchNorm backward statistics at 2.5 TB/s (19 launches x 82 us per step at batch 32).
+template <class F>
+__device__ __forceinline__ void slab_reduce4(int N, int C, double* part, int slab_rows, F f) {
+    __shared__ double red4[2][4][256];
+    const int slab = blockIdx.x, t = threadIdx.x;
+    const long long e0 = (long long)slab * slab_rows * C, e1 = min((long long)(slab + 1) * slab_rows, (long long)N) * C;
+    const int ch = (4 * t) & (C - 1);
+    const long long step = 1024;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    long long e = e0 + 4 * t;
+    for (; e + 3 * step < e1; e += 4 * step) {
+        float4 u0, v0, u1, v1, u2, v2, u3, v3;
+        f(e, ch, u0, v0); f(e + step, ch, u1, v1); f(e + 2 * step, ch, u2, v2); f(e + 3 * step, ch, u3, v3);
+        s0[0] += ((double)u0.x + (double)u1.x) + ((double)u2.x + (double)u3.x); s1[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s0[1] += ((double)u0.y + (double)u1.y) + ((double)u2.y + (double)u3.y); s1[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        s0[2] += ((double)u0.z + (double)u1.z) + ((double)u2.z + (double)u3.z); s1[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+        s0[3] += ((double)u0.w + (double)u1.w) + ((double)u2.w + (double)u3.w); s1[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+    }
+    for (; e < e1; e += step) {
+        float4 u, v;
+        f(e, ch, u, v);
+        s0[0] += u.x; s0[1] += u.y; s0[2] += u.z; s0[3] += u.w; s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red4[0][j][t] = s0[j]; red4[1][j][t] = s1[j]; }
+    __syncthreads();
+    const int groups = C / 4;                     // threads t, t + groups, ... share their 4 channels
+    for (int o = t; o < C; o += 256) {
+        const int g = o >> 2, j = o & 3;
+        double r0 = 0.0, r1 = 0.0;
+        for (int k = g; k < 256; k += groups) { r0 += red4[0][j][k]; r1 += red4[1][j][k]; }
+        part[((long long)slab * 2 + 0) * C + o] = r0;
+        part[((long long)slab * 2 + 1) * C + o] = r1;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, double* __restrict__ part, int slab_rows) {
+    if (C >= 4) {
+        slab_reduce4(N, C, part, slab_rows, [&](long long e, int, float4& u, float4& v) {
+            u = *reinterpret_cast<const float4*>(x + e);
+            v = make_float4(u.x * u.x, u.y * u.y, u.z * u.z, u.w * u.w);
+        });
+        return;
+    }
     slab_reduce(N, C, part, slab_rows, [&](long long e, int, float& u, float& v) { const float a = x[e]; u = a; v = a * a; });
 }
 
@@ -150,6 +195,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C, int act,
                                                            double* __restrict__ part, int slab_rows) {
+    if (C >= 4) {
+        slab_reduce4(N, C, part, slab_rows, [&](long long e, int c, float4& u, float4& v) {
+            float4 dz = *reinterpret_cast<const float4*>(dy + e);
+            if (act) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + e);
+                dz.x *= nn_act_grad_from_y(act, yv.x); dz.y *= nn_act_grad_from_y(act, yv.y); dz.z *= nn_act_grad_from_y(act, yv.z); dz.w *= nn_act_grad_from_y(act, yv.w);
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(x + e), mv = *reinterpret_cast<const float4*>(mean + c), rv = *reinterpret_cast<const float4*>(rstd + c);
+            u = dz;
+            v = make_float4(dz.x * (xv.x - mv.x) * rv.x, dz.y * (xv.y - mv.y) * rv.y, dz.z * (xv.z - mv.z) * rv.z, dz.w * (xv.w - mv.w) * rv.w);
+        });
+        return;
+    }
     slab_reduce(N, C, part, slab_rows, [&](long long e, int c, float& u, float& v) {
         const float dz = dy[e] * (act ? nn_act_grad_from_y(act, y[e]) : 1.f);
         u = dz; v = dz * (x[e] - mean[c]) * rstd[c];
