@@ -135,7 +135,7 @@ typedef struct SclGemmDesc {
  * (model/xlsr.py:41), nn.Linear in model/wav2vec2_linear_nll.py:107,49-67 and their autograd
  * backward (main.py:79).                                                                       */
 int scl_gemm_bf16(const SclGemmDesc* desc, void* stream);
-/* Up to 4 independent weight-gradient contractions in ONE launch: every member is C = A^T B (SCL_GEMM_A_T | SCL_GEMM_B_T, plain f32 output,
+/* Up to 8 independent weight-gradient contractions in ONE launch: every member is C = A^T B (SCL_GEMM_A_T | SCL_GEMM_B_T, plain f32 output,
  * flat K rows, K % 64 == 0 and >= 192, no batching, no split-K, M and N multiples of 8, 16-byte aligned C).  One 8-wave block per 256 x 256
  * output tile walks the WHOLE reduction and stores the finished tile: the four weight gradients of a transformer layer (autograd backward of
  * fairseq's TransformerSentenceEncoderLayer reached from model/xlsr.py:41; 16 + 48 + 64 + 64 tiles at E = 1024, F = 4096) need neither
@@ -143,6 +143,13 @@ int scl_gemm_bf16(const SclGemmDesc* desc, void* stream);
  * SCL_EUNSUPPORTED for a list that does not. */
 int scl_gemm_bf16_group_ok(const SclGemmDesc* descs, int n);
 int scl_gemm_bf16_group(const SclGemmDesc* descs, int n, void* stream);
+/* The same with every member restricted to a RANGE of its problem's 256 x 256 output tiles: member i computes tiles [tile0[i], tile0[i] +
+ * ntile[i]) of the scl_gemm_bf16_group_tiles(&descs[i]) tiles of its problem (ids in the kernel's own tile order; any partition of [0, tiles)
+ * over several launches covers every output element exactly once).  Lets a caller carry tiles over so that each launch is a whole round of
+ * the 256 CUs: the encoder backward issues 3 launches of 256 tiles per 4 layers instead of 4 of 192 (scl_amd/encoder.py).
+ * scl_gemm_bf16_group_tiles: 0 if the descriptor does not qualify as a member. */
+int scl_gemm_bf16_group_tiles(const SclGemmDesc* desc);
+int scl_gemm_bf16_group_part(const SclGemmDesc* descs, const int32_t* tile0, const int32_t* ntile, int n, void* stream);
 
 /* 0 when scl_gemm_bf16 would run this descriptor on the 128x128 tiles, 1 / 2 for the wide (<= 208 / 256 rows x 256 columns) tiles of
  * gemm_w8.hip — lets the caller size split-K for the tile that will actually be used (pointers are not dereferenced). */

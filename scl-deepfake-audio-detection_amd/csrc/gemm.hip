@@ -811,18 +811,37 @@ extern "C" int scl_gemm_bf16_group_ok(const SclGemmDesc* descs, int n) {
     GemmK ks[W8_GROUP_MAX];
     return gemm_group_prepare(descs, n, ks) == SCL_OK ? 1 : 0;
 }
-extern "C" int scl_gemm_bf16_group(const SclGemmDesc* descs, int n, void* stream) {
+static int gemm_group_run(const SclGemmDesc* descs, const int32_t* tile0, const int32_t* ntile, int n, void* stream, const char* what) {
     GemmK ks[W8_GROUP_MAX];
     const int rc = gemm_group_prepare(descs, n, ks);
-    if (rc == SCL_EUNSUPPORTED) scl_set_error("gemm group: 1..%d members, each A^T B with flat K rows, K %% 64 == 0, no batch / split-K, plain f32 output", W8_GROUP_MAX);
+    if (rc == SCL_EUNSUPPORTED) scl_set_error("%s: 1..%d members, each A^T B with flat K rows, K %% 64 == 0, no batch / split-K, plain f32 output", what, W8_GROUP_MAX);
     if (rc != SCL_OK) return rc;
     double flops = 0.0;
-    for (int i = 0; i < n; ++i) flops += 2.0 * descs[i].M * descs[i].N * (double)descs[i].K;
+    for (int i = 0; i < n; ++i) {
+        const int all = scl_gemm_w8_group_tiles(ks[i]);
+        if (tile0 || ntile) {
+            SCL_REQUIRE(tile0 && ntile && tile0[i] >= 0 && ntile[i] >= 1 && tile0[i] + ntile[i] <= all, "%s: member %d covers tiles [%d, %d) of %d", what, i,
+                        tile0 ? tile0[i] : 0, (tile0 ? tile0[i] : 0) + (ntile ? ntile[i] : 0), all);
+        }
+        flops += 2.0 * descs[i].M * descs[i].N * (double)descs[i].K * (ntile ? (double)ntile[i] / all : 1.0);
+    }
     {
         SclProfScope prof(SCL_KID_GEMM, (hipStream_t)stream, flops, true);
-        scl_gemm_w8_group_launch(ks, n, (hipStream_t)stream);
+        scl_gemm_w8_group_launch(ks, n, tile0, ntile, (hipStream_t)stream);
     }
-    return scl_check_launch("scl_gemm_bf16_group");
+    return scl_check_launch(what);
+}
+extern "C" int scl_gemm_bf16_group(const SclGemmDesc* descs, int n, void* stream) {
+    return gemm_group_run(descs, nullptr, nullptr, n, stream, "scl_gemm_bf16_group");
+}
+extern "C" int scl_gemm_bf16_group_tiles(const SclGemmDesc* desc) {
+    GemmK k;
+    if (gemm_group_prepare(desc, 1, &k) != SCL_OK) return 0;
+    return scl_gemm_w8_group_tiles(k);
+}
+extern "C" int scl_gemm_bf16_group_part(const SclGemmDesc* descs, const int32_t* tile0, const int32_t* ntile, int n, void* stream) {
+    SCL_REQUIRE(tile0 && ntile, "gemm group part: tile ranges missing");
+    return gemm_group_run(descs, tile0, ntile, n, stream, "scl_gemm_bf16_group_part");
 }
 
 extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {

@@ -296,9 +296,10 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
 int scl_gemm_read_stamps(unsigned long long* out, int nblocks);
 long long scl_gemm_w8p_launches();
 int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long zdim, hipStream_t s);
-constexpr int W8_GROUP_MAX = 4;      // members of a grouped launch (scl_gemm_bf16_group)
+constexpr int W8_GROUP_MAX = 8;      // members of a grouped launch (scl_gemm_bf16_group / _part)
 bool scl_gemm_w8_group_member_ok(const GemmK& k, bool at, bool bt, const SclGemmDesc& d);
-int scl_gemm_w8_group_launch(GemmK* ks, int n, hipStream_t s);
+int scl_gemm_w8_group_tiles(const GemmK& k);
+int scl_gemm_w8_group_launch(GemmK* ks, int n, const int* tile0, const int* ntile, hipStream_t s);
 
 // gemm_x2.hip (host side): 208 x 128 tiles, two 4-wave workgroups per CU (plan->variant = 2)
 bool scl_gemm_x2_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, long long zdim, int ncu, W8Plan* plan);

@@ -561,7 +561,9 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_kernel(const GemmK d) {
 // kernel-argument segment with scalar loads (uniform index): nothing of the descriptor is copied, nothing goes to scratch.
 struct GemmGroupK {
     GemmK k[W8_GROUP_MAX];
-    int first[W8_GROUP_MAX + 1];
+    int first[W8_GROUP_MAX + 1];      // launch-wide block index of each member's first block
+    int tile0[W8_GROUP_MAX];          // the member's first tile inside ITS problem (a member may be a RANGE of a problem's tiles: carry-over)
+    int ntiles[W8_GROUP_MAX];         // tiles of the whole problem (tile_coords needs the full count)
     int n;
 };
 typedef const __attribute__((address_space(4))) GemmGroupK* W8GArg;
@@ -573,8 +575,7 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_group_kernel(const GemmGr
 #pragma unroll
     for (int i = 1; i < W8_GROUP_MAX; ++i) mem += (i < g.n && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
     mem = __builtin_amdgcn_readfirstlane(mem);
-    const int lo = gp->first[mem], hi = gp->first[mem + 1];
-    w8s_tile<AT, BT, RB0, RB1>(*(const GemmK*)&gp->k[mem], smem, (int)blockIdx.x - lo, hi - lo, 0);
+    w8s_tile<AT, BT, RB0, RB1>(*(const GemmK*)&gp->k[mem], smem, (int)blockIdx.x - gp->first[mem] + gp->tile0[mem], gp->ntiles[mem], 0);
 }
 
 #ifdef SCL_EXPERIMENTS      // opt-in experiment, not part of the shipped library (see gemm.hip)
@@ -839,11 +840,15 @@ bool scl_gemm_w8_group_member_ok(const GemmK& k, bool at, bool bt, const SclGemm
     return (d.flags & ~(SCL_GEMM_NO_DMA | SCL_GEMM_NO_W8)) == plain && !d.colsum_part;
 }
 
-int scl_gemm_w8_group_launch(GemmK* ks, int n, hipStream_t s) {
+int scl_gemm_w8_group_tiles(const GemmK& k) { return ((k.M + 255) / 256) * ((k.N + W8_BN - 1) / W8_BN); }
+
+// tile0 / ntile (optional): member i covers tiles [tile0[i], tile0[i] + ntile[i]) of its problem — the caller carries the rest over into a
+// later launch, so that every launch is a full round of the 256 CUs (the encoder's backward: 3 launches of 256 tiles per 4 layers instead of
+// 4 of 192; the launch time barely depends on the tile count: 336 us at 192 tiles, 348 at 256, tools/group_fill_probe.py).
+int scl_gemm_w8_group_launch(GemmK* ks, int n, const int* tile0, const int* ntile, hipStream_t s) {
     // 256-row tiles.  Measured against 240 tiles of 205 rows for a layer's four weight gradients (94 % instead of 75 % of the CUs busy, the
     // choice scl_gemm_w8_plan's cost model would make): 365 vs 275 us per launch, the step 45.1 vs 42.5 ms (round 5, three interleaved
-    // pairs) — the loop is bound by the L2 -> LDS feed, and 192 blocks with the larger tile move fewer operand bytes per MFMA and share the
-    // fabric among fewer CUs.
+    // pairs): the smaller tile moves more operand bytes per MFMA through the L2 -> LDS path that paces the loop.
     GemmGroupK g = GemmGroupK();
     int total = 0;
     for (int i = 0; i < n; ++i) {
@@ -853,7 +858,9 @@ int scl_gemm_w8_group_launch(GemmK* ks, int n, hipStream_t s) {
         k.debug = 0;
         g.k[i] = k;
         g.first[i] = total;
-        total += ntm * ((k.N + W8_BN - 1) / W8_BN);
+        g.ntiles[i] = scl_gemm_w8_group_tiles(k);
+        g.tile0[i] = tile0 ? tile0[i] : 0;
+        total += ntile ? ntile[i] : g.ntiles[i];
     }
     for (int i = n; i <= W8_GROUP_MAX; ++i) g.first[i] = total;
     g.n = n;

@@ -37,6 +37,7 @@ BATCH_SLABS = True      # decided by the A/Bs of rounds 2-4 (DESIGN.md section 3
 # slab reduction, 5 launches -> 1.  SCL_WGRAD_GROUP=0: one split-K launch per gradient + the layer's slab combine, as rounds 2-4 ran.
 # Engaged when the group covers at least 3/8 of the CUs and the reduction has at least WGRAD_GROUP_MIN_KSTEPS steps of 64 rows.
 WGRAD_GROUP = os.environ.get("SCL_WGRAD_GROUP", "1") != "0"
+WGRAD_CARRY = os.environ.get("SCL_WGRAD_CARRY", "1") != "0"      # carry a layer's tile remainder into the next layer's launch (whole rounds of 256 tiles)
 WGRAD_GROUP_MIN_KSTEPS = 16      # from 1024 rows on (measured: 11 x 199 rows 16.2 -> 14.2 ms per step, 16 x 199 20.8 -> 17.6, 32 x 199 29.1 -> 26.1, 64 x 199 44.1 -> 42.5)
 # positional conv forward / data gradient on the LDS-resident-slab kernel (csrc/posconv.hip) instead of the grouped GEMM; 0 = the GEMM (A/B)
 POSCONV_MFMA = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
@@ -220,12 +221,13 @@ class Encoder:
         d["a"] = [bfz(Mp, Fd) for _ in range(cfg.layers)]
         d["out"], d["omean"], d["orstd"] = bf(M * E), f32(M), f32(M)
         # backward scratch (shared by all layers)
-        d["dx_a"], d["dx_b"], d["dx_c"] = f32(M * E), f32(M * E), f32(M * E)
-        d["dxbf_a"], d["dxbf_b"], d["dxbf_c"] = bfz(Mp, E, slack), bfz(Mp, E, slack), bfz(Mp, E, slack)
-        d["d_f"] = bfz(Mp, Fd, slack)
+        # residual-gradient pairs (f32, bf16) rotate over FIVE buffers and d_f / dqkv alternate between TWO: the weight gradients of a layer may
+        # be carried over into the grouped launch at the end of the NEXT layer (see _flush_slabs), so their operands outlive their layer by one
+        d["dx_rot"] = [(f32(M * E), bfz(Mp, E, slack)) for _ in range(5)]
+        d["d_f"] = [bfz(Mp, Fd, slack), bfz(Mp, Fd, slack)]
         d["d_h"] = bf(M * E + slack)
         d["d_ctx"] = bf(M * E + slack)
-        d["dqkv"] = bfz(Mp, 3 * E, slack)
+        d["dqkv"] = [bfz(Mp, 3 * E, slack), bfz(Mp, 3 * E, slack)]
         d["dS"] = None if d["fused_attn"] else bf(B * H * T * Tp + 1024)
         d["dcpad"] = bf(B * (T + K) * E + slack)
         d["dz"] = [bf(B * t * C + slack) for t in Ts]
@@ -345,16 +347,23 @@ class Encoder:
         ops.gemm(A, B_, d["slab"], Mo, No, Kr, a_t=True, b_t=True, splitk=sk, c_split_stride=n, **kw)
         ops.reduce_slabs(d["slab"], out, n, sk, n)
 
-    def _flush_slabs(self, d):
-        """The queued weight gradients of this layer as one grouped launch (or, if the list does not qualify, one by one on the split-K
-        path), then the queued split-K combines, one launch (on the stream the weight gradients ran on)."""
+    def _flush_slabs(self, d, final=True):
+        """End of a layer's backward: its queued weight gradients join the pending tile work and whole rounds of 256 tiles are launched
+        (ops.gemm_group_part: a launch takes tile RANGES of up to 8 problems, oldest first).  A layer's 192 tiles do not fill the 256 CUs and a
+        grouped launch takes about as long with 192 tiles as with 256 (336 vs 348 us, tools/group_fill_probe.py), so the remainder is carried
+        into the NEXT layer's launch: 3 launches per 4 layers.  Everything of the previous layer is flushed here (its operands are re-used
+        by the layer after this one); `final` flushes all.  SCL_WGRAD_CARRY=0: one launch of a layer's own tiles per layer.  If the list
+        does not qualify the gradients run one by one on the split-K path.  Then the queued split-K combines, one launch."""
         group = d.get("wgrad_group")
+        pend = d.setdefault("wgrad_pending", [])      # [problem, tiles, next tile, age in layers]
+        for it in pend:
+            it[3] += 1
         if group:
             d["wgrad_group"] = []
-            tiles = sum(((Mo + 255) // 256) * ((No + 255) // 256) for _, _, _, Mo, No, _, _ in group)
-            with self._side():
-                done = tiles >= 96 and ops.gemm_group([g[:6] for g in group])
-            if not done:
+            counts = [ops.gemm_group_tiles(*g[:6]) for g in group]
+            if min(counts) > 0 and sum(counts) >= 96:
+                pend.extend([g[:6], c, 0, 0] for g, c in zip(group, counts))
+            else:
                 global WGRAD_GROUP
                 saved, WGRAD_GROUP = WGRAD_GROUP, False
                 try:
@@ -363,6 +372,25 @@ class Encoder:
                             self._wgrad(d, A, B_, out, Mo, No, Kr, slot=slot)
                 finally:
                     WGRAD_GROUP = saved
+        while pend:
+            total = sum(it[1] - it[2] for it in pend)
+            if total >= 256 and WGRAD_CARRY:
+                take = 256
+            elif final or not WGRAD_CARRY or any(it[3] >= 1 for it in pend):
+                take = total
+            else:
+                break
+            parts = []
+            while take > 0 and pend and len(parts) < 8:
+                it = pend[0]
+                c = min(take, it[1] - it[2])
+                parts.append((it[0], it[2], c))
+                it[2] += c
+                take -= c
+                if it[2] == it[1]:
+                    pend.pop(0)
+            with self._side():
+                ops.gemm_group_part(parts)
         jobs = d.get("slab_jobs")
         if jobs:
             with self._side():
@@ -576,7 +604,8 @@ class Encoder:
         # final LayerNorm
         # residual-gradient buffers rotate over three (f32, bf16) pairs: a LayerNorm backward never writes the pair a weight-gradient
         # GEMM of the same layer may still be reading on the second stream
-        rot = [(d["dx_a"], d["dxbf_a"]), (d["dx_b"], d["dxbf_b"]), (d["dx_c"], d["dxbf_c"])]
+        rot = d["dx_rot"]
+        NR = len(rot)
         cur = 0
         dx, dxb = rot[cur]
         dout, lyr = mask3_of(active)
@@ -585,7 +614,9 @@ class Encoder:
         if lyr is not None:
             self._slot(slots, e, ops.LN_BWD_DOUT_SEED, lyr, self.SITE_3)
         self._ln_grads(d, nlnM, E, "encoder.layer_norm.weight", "encoder.layer_norm.bias")
-        other, otherb = rot[(cur + 1) % 3]
+        other, otherb = rot[(cur + 1) % NR]
+        li, prev_off = 0, None
+        d["wgrad_group"], d["wgrad_pending"] = [], []      # nothing is carried across backward passes (an interrupted one may have left work)
         for n in reversed(range(cfg.layers)):
             pn = "encoder.layers.%d." % n
             if n in ctx["skipped"]:
@@ -596,15 +627,16 @@ class Encoder:
                     P.g(self.n(pn + nm)).zero_()
                 continue
             xin = d["xin"][n]
+            d_f, li = d["d_f"][li & 1], li + 1      # li: layers processed so far (the parity picks this layer's d_f / dqkv)
             # ---- FFN:  xout = x1 + gelu(h2 W1^T + b1) W2^T + b2
             with self._side():
                 self._wgrad(d, Op(dxb, E), Op(d["a"][n], Fd), P.g(self.n(pn + "fc2.weight")), E, Fd, Mp, slot=0)
             # fc1.bias.grad = colsum(d_f): summed per tile by the GEMM that writes d_f (wide tiles), else by a pass over d_f
             fc2_dgrad = dict(b_t=True, R=d["f"][n], rmode=2, ract=RACT_STORED if GELU_DC2 else ACT_GELU, drop_p=p_act, drop_seed=sseed(n, self.SITE_2))
-            nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
+            nrows = ops.gemm_colsum_rows(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d_f, M, Fd, E, **fc2_dgrad) if FUSED_BIAS_GRAD else 0
             if nrows * Fd > d["cs_fused"].numel():
                 nrows = 0
-            dsc = ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d["d_f"], M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
+            dsc = ops.gemm(Op(dxb, E), self.W(pn + "fc2.weight", Fd), d_f, M, Fd, E, colsum_part=d["cs_fused"] if nrows else None, **fc2_dgrad)
             if p_act > 0 and recording:
                 self._slot(slots, dsc, None, n, self.SITE_2)
             jobs = []      # this layer's closing reductions (BATCH_REDUCE: one launch at the end of the layer)
@@ -615,9 +647,9 @@ class Encoder:
                     ops.colreduce(d["cs_fused"], P.g(self.n(pn + "fc1.bias")), nrows, Fd)
             with self._side():
                 if not nrows:
-                    self._bias_grad(d, d["d_f"], M, Fd, pn + "fc1.bias")
-                self._wgrad(d, Op(d["d_f"], Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, Mp, slot=1)
-            ops.gemm(Op(d["d_f"], Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
+                    self._bias_grad(d, d_f, M, Fd, pn + "fc1.bias")
+                self._wgrad(d, Op(d_f, Fd), Op(d["h2"][n], E), P.g(self.n(pn + "fc1.weight")), Fd, E, Mp, slot=1)
+            ops.gemm(Op(d_f, Fd), self.W(pn + "fc1.weight", E), d["d_h"], M, E, Fd, b_t=True)
             # dx (= d xout) is the gradient of fc2's output: its column sum (fc2.bias.grad) rides on this LayerNorm backward
             # dres = d(xout): fc2.bias.grad = colsum(dres x dropout3 mask); the bf16 output d(x1) feeds out_proj's gradients: dropout1 mask
             e = ops.layernorm_bwd(d["d_h"], d["x1"][n], d["m2"][n], d["r2"][n], self.b(pn + "final_layer_norm.weight"), None, dx,
@@ -630,13 +662,13 @@ class Encoder:
                 jobs.append(self._ln_job(d["ln_part"], nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias"))
             else:
                 self._ln_grads(d, nlnM, E, pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", resid_bias=pn + "fc2.bias")
-            cur = (cur + 1) % 3
-            (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d x1
+            cur = (cur + 1) % NR
+            (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % NR]      # dx = d x1
             # ---- attention:  x1 = xin + ctx Wo^T + bo
             with self._side():
                 self._wgrad(d, Op(dxb, E), Op(d["ctx"][n], E), P.g(self.n(pn + "self_attn.out_proj.weight")), E, E, Mp, slot=2)
             ops.gemm(Op(dxb, E), self.W(pn + "self_attn.out_proj.weight", E), d["d_ctx"], M, E, E, b_t=True)
-            qkv, dqkv = d["qkv"][n], d["dqkv"]
+            qkv, dqkv = d["qkv"][n], d["dqkv"][li & 1]
             if d["fused_attn"]:
                 e = ops.attn_bwd(qkv, d["ctx"][n], d["d_ctx"], d["lse"][n], dqkv, B, T, H, D, D ** -0.5,
                                  bias_part=d["qkv_bias_part"] if FUSED_BIAS_GRAD else None, drop_p=p_attn, drop_seed=sseed(n, self.SITE_ATTN))
@@ -692,12 +724,17 @@ class Encoder:
             else:
                 self._ln_grads(d, nlnM, E, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias",
                                resid_bias=pn + "self_attn.out_proj.bias")
-            cur = (cur + 1) % 3
-            (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % 3]      # dx = d xin
-            self._flush_slabs(d)
-            self._join_side()          # d_f / dqkv / the bf16 residual gradients of this layer are free again; its gradients are final
-            if self.on_grads_ready is not None:
-                ops.host_callback(self.on_grads_ready, P.off(self.n(pn + "self_attn_layer_norm.weight")))
+            cur = (cur + 1) % NR
+            (dx, dxb), (other, otherb) = rot[cur], rot[(cur + 1) % NR]      # dx = d xin
+            self._flush_slabs(d, final=(n == active[0]))
+            self._join_side()
+            # gradients that are final now: this layer's if nothing of it is still pending in the carried-over tile work, else the previous
+            # processed layer's (everything older than one layer has been flushed)
+            this_off = P.off(self.n(pn + "self_attn_layer_norm.weight"))
+            ready_off = this_off if not d.get("wgrad_pending") else prev_off
+            prev_off = this_off
+            if self.on_grads_ready is not None and ready_off is not None:
+                ops.host_callback(self.on_grads_ready, ready_off)
         # ---- positional conv:  xin0 = x0 + gelu(conv(x0) + b)
         pb = K // 2 - 1
         if p_res > 0:      # backward of F.dropout(x0 + pos_conv(x0)): dx = d(xin[0]) x mask, in place (nothing reads the unmasked value again)

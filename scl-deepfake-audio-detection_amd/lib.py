@@ -115,6 +115,8 @@ def _protos():
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_gemm_bf16_group_ok": ([P(SclGemmDesc), _i32], _i32),
         "scl_gemm_bf16_group": ([P(SclGemmDesc), _i32, _vp], _i32),
+        "scl_gemm_bf16_group_tiles": ([P(SclGemmDesc)], _i32),
+        "scl_gemm_bf16_group_part": ([P(SclGemmDesc), P(_i32), P(_i32), _i32, _vp], _i32),
         "scl_reduce_slabs_f32": ([_vp, _vp, _i64, _i32, _i64, _vp], _i32),
         "scl_posconv_supported": ([_i32, _i32, _i32, _i32], _i32),
         "scl_posconv_wgrad_supported": ([_i32, _i32, _i32, _i32], _i32),

@@ -152,10 +152,28 @@ def gemm_group(problems):
     for i, (A, B, C, M, N, K) in enumerate(problems):
         d = _gemm_desc(A, B, C, M, N, K, a_t=True, b_t=True)
         ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(d), ctypes.sizeof(L.SclGemmDesc))
-    if len(problems) > 4 or not L.load().scl_gemm_bf16_group_ok(arr, len(problems)):
+    if len(problems) > 8 or not L.load().scl_gemm_bf16_group_ok(arr, len(problems)):
         return False
     _call("scl_gemm_bf16_group", arr, len(problems), _stream(), keep=arr)
     return True
+
+
+def gemm_group_tiles(A, B, C, M, N, K):
+    """256 x 256 output tiles of one weight-gradient problem as a group member; 0 if it does not qualify."""
+    d = _gemm_desc(A, B, C, M, N, K, a_t=True, b_t=True)
+    return L.load().scl_gemm_bf16_group_tiles(ctypes.byref(d))
+
+
+def gemm_group_part(parts):
+    """parts: list of ((A, B, C, M, N, K), first_tile, n_tiles) — one launch over tile RANGES of up to 8 weight-gradient problems."""
+    n = len(parts)
+    arr = (L.SclGemmDesc * n)()
+    t0, nt = (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)()
+    for i, ((A, B, C, M, N, K), first, count) in enumerate(parts):
+        d = _gemm_desc(A, B, C, M, N, K, a_t=True, b_t=True)
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(d), ctypes.sizeof(L.SclGemmDesc))
+        t0[i], nt[i] = first, count
+    _call("scl_gemm_bf16_group_part", arr, t0, nt, n, _stream(), keep=(arr, t0, nt))
 
 
 def gemm_colsum_rows(A, B, C, M, N, K, **kw):

@@ -789,14 +789,52 @@ def test_grouped_weight_gradient_launch_equals_the_single_launches(dev, Kr):
     for (A, B, C, Mo, No, _), ref, S in zip(probs, refs, singles):
         _close(C, ref, 2e-5 * math.sqrt(Kr), "group vs fp32 (%d x %d)" % (Mo, No))
         assert torch.equal(C, S), "group member [%d, %d] differs from its single launch" % (Mo, No)
-    # one member alone, and the refusals: K not a multiple of 64, fewer than 3 K steps, five members, a bias
+    # one member alone, and the refusals: K not a multiple of 64, fewer than 3 K steps, nine members, a bias
     C1 = torch.empty_like(probs[2][2])
     assert ops.gemm_group([probs[2][:2] + (C1,) + probs[2][3:]]) and torch.equal(C1, probs[2][2])
     A, B, C, Mo, No, _ = probs[0]
     assert ops.gemm_group([(A, B, C, Mo, No, Kr - 32)]) is False
     assert ops.gemm_group([(A, B, C, Mo, No, 128)]) is False
-    assert ops.gemm_group(probs + [probs[0]]) is False
+    assert ops.gemm_group(probs + probs + [probs[0]]) is False
     import ctypes
     d = ops._gemm_desc(A, B, C, Mo, No, Kr, a_t=True, b_t=True, bias=torch.zeros(No, device=dev))
     assert ops.L.load().scl_gemm_bf16_group_ok(ctypes.byref(d), 1) == 0
     assert ops.L.load().scl_gemm_bf16_group(ctypes.byref(d), 1, None) == -3
+
+
+def test_grouped_launch_over_tile_ranges_covers_every_tile_once(dev):
+    """scl_gemm_bf16_group_part: members are RANGES of their problems' tiles (the encoder carries a layer's remainder into the next
+    layer's launch so that every launch is a whole round of 256 tiles).  Any partition of a problem's tiles over several launches must
+    reproduce the single launch bit for bit; ranges outside a problem are refused."""
+    import ctypes
+    Kr, E, Fd = 448, 256, 512
+    shapes = [(E, Fd), (Fd, E), (E, E), (3 * E, E), (Fd, Fd)]
+    probs, singles = [], []
+    for i, (Mo, No) in enumerate(shapes):
+        A = _rand((Kr, Mo), dev, 30 + i, 0.5)
+        B = _rand((Kr, No), dev, 40 + i, 0.5)
+        probs.append((ops.Op(A, Mo), ops.Op(B, No), torch.full((Mo, No), float("nan"), device=dev), Mo, No, Kr))
+        S = torch.empty(Mo, No, device=dev)
+        ops.gemm(ops.Op(A, Mo), ops.Op(B, No), S, Mo, No, Kr, a_t=True, b_t=True, force_w8=True)
+        singles.append(S)
+    tiles = [ops.gemm_group_tiles(*p) for p in probs]
+    assert tiles == [2, 2, 1, 3, 4]
+    # three launches of 4 tiles each, oldest first, a problem split across launches where the cut falls
+    queue = [[p, t, 0] for p, t in zip(probs, tiles)]
+    launches = 0
+    while queue:
+        take, parts = 4, []
+        while take and queue:
+            it = queue[0]
+            c = min(take, it[1] - it[2])
+            parts.append((it[0], it[2], c)); it[2] += c; take -= c
+            if it[2] == it[1]:
+                queue.pop(0)
+        ops.gemm_group_part(parts)
+        launches += 1
+    torch.cuda.synchronize()
+    assert launches == 3
+    for p, S in zip(probs, singles):
+        assert torch.equal(p[2], S)
+    with pytest.raises(ops.L.SclError, match="covers tiles"):
+        ops.gemm_group_part([(probs[0], 1, 2)])
