@@ -26,22 +26,15 @@ from .ops import Op
 
 ACT_NONE, ACT_RELU, ACT_SELU = 0, 1, 2
 
-# FORWARD products of the ResNet back-end (and of the per-layer AASIST composition) run on the EXACT f32 matrix-core kernel: with the
-# bf16-pair form (ops.F32X3, csrc/gemm_f32.hip, 1.3 - 1.8 x faster per launch) the reference goldens' outputs still hold 2e-4, but a 5e-6
-# perturbation of the pre-activations flips ReLU / SELU masks and the earliest layers' gradients drift to 4e-3 (eval) / 1.5e-2 (train) of
-# their scale through 18 layers (bound: 2e-3).  The BACKWARD products (data and weight gradients: two thirds of the work) are linear
-# maps GIVEN the forward's masks, so they take the pair form: the masks stay the reference's, the gradients move by ~1e-5.
-# SCL_HIPNN_X3=1: pair form in the forward too; =0: exact everywhere.
-_MODE = os.environ.get("SCL_HIPNN_X3", "bwd")
-X3_FWD, X3_BWD = _MODE == "1", _MODE != "0"
-
-
+# Everything here runs on the EXACT f32 matrix-core kernel unless a caller asks otherwise.  With the bf16-pair form (ops.F32X3,
+# csrc/gemm_f32.hip, 1.3 - 1.8 x faster per launch) in the FORWARD the reference goldens' outputs still hold 2e-4, but a 5e-6 perturbation of
+# the pre-activations flips ReLU / SELU masks and the ResNet's earliest gradients drift to 4e-3 (eval) / 1.5e-2 (train) of their scale
+# through 18 layers (bound 2e-3).  The BACKWARD products of a convolution (data and weight gradient: two thirds of the work) are linear maps
+# GIVEN the forward's masks: conv2d(..., x3_bwd=True) runs them in the pair form — the masks stay the reference's, the gradients move by
+# ~1e-5 (the ResNet back-end asks for it; the per-layer AASIST composition, whose small bias gradients sit at 8e-4 with it, does not).
 def _gemm(*a, **kw):
-    return ops.gemm(*a, x3=X3_FWD, **kw)
+    return ops.gemm(*a, x3=False, **kw)
 
-
-def _gemm_bwd(*a, **kw):
-    return ops.gemm(*a, x3=X3_BWD, **kw)
 
 # Re-laid-out copies of the convolution weights ([Co][kh][kw][Cp] for the forward / wgrad, flipped [Ci][kh][kw][Cop] for the dgrad) are
 # pure functions of the weights: they are rebuilt once per optimizer step (the model bumps the epoch), not once per call.
@@ -108,7 +101,7 @@ def _colsum(x2d, M, N):
 # ---- convolution ---------------------------------------------------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dtype):
+    def forward(ctx, x, weight, bias, stride, padding, dtype, x3_bwd=False):
         """x [B, H, W, Ci] f32; weight [Co, Ci, kh, kw] (torch layout); bias [Co] or None -> y [B, OH, OW, Co] f32."""
         B, H, W, Ci = x.shape
         Co, _, kh, kw = weight.shape
@@ -137,12 +130,14 @@ class _Conv2dFn(torch.autograd.Function):
                  nb1=B, c_bs1=OH * OW * Co, bias=None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(xp, weight)
         ctx.geom = (B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, bias is not None)
+        ctx.x3_bwd = bool(x3_bwd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xp, weight = ctx.saved_tensors
         B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, has_bias = ctx.geom
+        x3_bwd = ctx.x3_bwd
         dev = dy.device
         dy = dy.contiguous().float()
         vec = 8 if dtype == torch.bfloat16 else 4
@@ -166,8 +161,8 @@ class _Conv2dFn(torch.autograd.Function):
             tiles = ((Co + tile - 1) // tile) * ((K + tile - 1) // tile) * B
             sk = max(1, min(8, 1024 // max(tiles, 1), (OH * OW) // 256))          # enough blocks to hide the single-stage prefetch
             slabs = torch.empty(B * sk, Co, K, dtype=torch.float32, device=dev)
-            _gemm_bwd(Op(dyc, Cop, bs1=OH * OW * Cop), Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp),
-                     slabs, Co, K, OH * OW, a_t=True, b_t=True, nb1=B, c_bs1=sk * Co * K, splitk=sk, c_split_stride=Co * K if sk > 1 else 0)
+            ops.gemm(Op(dyc, Cop, bs1=OH * OW * Cop), Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp),
+                     slabs, Co, K, OH * OW, a_t=True, b_t=True, nb1=B, c_bs1=sk * Co * K, splitk=sk, c_split_stride=Co * K if sk > 1 else 0, x3=x3_bwd)
             dwk = torch.empty(Co, K, dtype=torch.float32, device=dev)
             ops.reduce_slabs(slabs, dwk, Co * K, B * sk, Co * K)
             dw = dwk.view(Co, kh, kw, Cp)[..., :Ci].permute(0, 3, 1, 2)
@@ -188,16 +183,16 @@ class _Conv2dFn(torch.autograd.Function):
                 return w.reshape(Ci, Kd).to(dtype)
             wd = _packed(weight, "bwd", dtype, pack_bwd)
             dx = torch.empty(B, H, W, Ci, dtype=torch.float32, device=dev)
-            _gemm_bwd(Op(dyp, Cop, rpb=W, rbstride=Wd * Cop, cin=kw * Cop, cout=Wd * Cop, bs1=Hd * Wd * Cop), Op(wd, Kd), dx, H * W, Ci, Kd,
-                     nb1=B, c_bs1=H * W * Ci)
+            ops.gemm(Op(dyp, Cop, rpb=W, rbstride=Wd * Cop, cin=kw * Cop, cout=Wd * Cop, bs1=Hd * Wd * Cop), Op(wd, Kd), dx, H * W, Ci, Kd,
+                     nb1=B, c_bs1=H * W * Ci, x3=x3_bwd)
             _zeros_release(ent_p)
         _zeros_release(ctx.xp_ent)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dtype=torch.float32):
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dtype=torch.float32, x3_bwd=False):
     """Channels-last 2-D convolution (cross-correlation, as nn.Conv2d): x [B, H, W, Ci] -> [B, OH, OW, Co]."""
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), dtype)
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), dtype, x3_bwd)
 
 
 # ---- BatchNorm (+ activation) --------------------------------------------------------------------------------------------------------
@@ -265,7 +260,7 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dev)
-            _gemm_bwd(Op(dyc, N), Op(wc, K), dx, M, K, N, b_t=True)
+            _gemm(Op(dyc, N), Op(wc, K), dx, M, K, N, b_t=True)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.empty(N, K, device=dev)
@@ -275,10 +270,10 @@ class _LinearFn(torch.autograd.Function):
             sk = max(1, min(32, 256 // tiles, M // 128))
             if sk > 1:
                 slabs = torch.empty(sk, N, K, device=dev)
-                _gemm_bwd(Op(dyc, N), Op(xc, K), slabs, N, K, M, a_t=True, b_t=True, splitk=sk, c_split_stride=N * K)
+                _gemm(Op(dyc, N), Op(xc, K), slabs, N, K, M, a_t=True, b_t=True, splitk=sk, c_split_stride=N * K)
                 ops.reduce_slabs(slabs, dw, N * K, sk, N * K)
             else:
-                _gemm_bwd(Op(dyc, N), Op(xc, K), dw, N, K, M, a_t=True, b_t=True)
+                _gemm(Op(dyc, N), Op(xc, K), dw, N, K, M, a_t=True, b_t=True)
         if has_b and ctx.needs_input_grad[2]:
             db = _colsum(dyc, M, N)
         return dx, dw, db
@@ -321,10 +316,10 @@ class _BmmFn(torch.autograd.Function):
         da = db = None
         if ctx.needs_input_grad[0]:          # dA[m][k] = sum_n dC[m][n] B[k][n]
             da = torch.empty(B, M, K, device=dc.device)
-            _gemm_bwd(Op(dcc, N, bs1=M * N), Op(bc, N, bs1=K * N), da, M, K, N, nb1=B, c_bs1=M * K)
+            _gemm(Op(dcc, N, bs1=M * N), Op(bc, N, bs1=K * N), da, M, K, N, nb1=B, c_bs1=M * K)
         if ctx.needs_input_grad[1]:          # dB[k][n] = sum_m A[m][k] dC[m][n]
             db = torch.empty(B, K, N, device=dc.device)
-            _gemm_bwd(Op(ac, K, bs1=M * K), Op(dcc, N, bs1=M * N), db, K, N, M, a_t=True, b_t=True, nb1=B, c_bs1=K * N)
+            _gemm(Op(ac, K, bs1=M * K), Op(dcc, N, bs1=M * N), db, K, N, M, a_t=True, b_t=True, nb1=B, c_bs1=K * N)
         return da, db
 
 
