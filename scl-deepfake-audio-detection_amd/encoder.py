@@ -115,6 +115,34 @@ def param_specs(cfg, prefix="ssl_model.model."):
     return sp
 
 
+def plan_group_launches(pend, final, carry=True, round_tiles=256, max_members=8):
+    """Pending tile work -> launches.  pend: list of [problem, tiles, next tile, age in layers] (oldest first; consumed in place).
+    Returns a list of launches, each a list of (problem, first tile, count).  Rules: while at least `round_tiles` tiles are pending, launch
+    exactly that many (a whole round of the CUs), oldest first, splitting a problem where the cut falls; then, if anything older than the
+    current layer is left (its operands are about to be re-used), or `final`, or carrying is off, launch the rest; otherwise keep it for
+    the next call.  Every tile of every problem is launched exactly once."""
+    launches = []
+    while pend:
+        total = sum(it[1] - it[2] for it in pend)
+        if total >= round_tiles and carry:
+            take = round_tiles
+        elif final or not carry or any(it[3] >= 1 for it in pend):
+            take = total
+        else:
+            break
+        parts = []
+        while take > 0 and pend and len(parts) < max_members:
+            it = pend[0]
+            c = min(take, it[1] - it[2])
+            parts.append((it[0], it[2], c))
+            it[2] += c
+            take -= c
+            if it[2] == it[1]:
+                pend.pop(0)
+        launches.append(parts)
+    return launches
+
+
 def _splitk(tiles, ksteps, target=512, cap=32):
     s = max(1, min(cap, target // max(tiles, 1), ksteps))
     return s
@@ -372,23 +400,7 @@ class Encoder:
                             self._wgrad(d, A, B_, out, Mo, No, Kr, slot=slot)
                 finally:
                     WGRAD_GROUP = saved
-        while pend:
-            total = sum(it[1] - it[2] for it in pend)
-            if total >= 256 and WGRAD_CARRY:
-                take = 256
-            elif final or not WGRAD_CARRY or any(it[3] >= 1 for it in pend):
-                take = total
-            else:
-                break
-            parts = []
-            while take > 0 and pend and len(parts) < 8:
-                it = pend[0]
-                c = min(take, it[1] - it[2])
-                parts.append((it[0], it[2], c))
-                it[2] += c
-                take -= c
-                if it[2] == it[1]:
-                    pend.pop(0)
+        for parts in plan_group_launches(pend, final, WGRAD_CARRY):
             with self._side():
                 ops.gemm_group_part(parts)
         jobs = d.get("slab_jobs")

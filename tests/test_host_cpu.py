@@ -195,3 +195,37 @@ def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
     pack.set_audio_loader(lambda p, sr: np.zeros(10, np.float32))
     pack.require_decoder_for(["music-fma-0001.mp3"], "list")               # a registered loader decodes anything
     pack.set_audio_loader(None)
+
+
+@pytest.mark.parametrize("per_layer", [[64, 64, 16, 48], [16, 16, 4, 12], [100, 100, 30, 90], [300, 7]])
+@pytest.mark.parametrize("carry", [True, False])
+def test_carried_over_group_launches_cover_every_tile_once_and_never_hold_work_for_two_layers(per_layer, carry):
+    """Host logic of the grouped weight-gradient launches (scl_amd/encoder.py::plan_group_launches): a backward over 24 layers, each
+    contributing `per_layer` tile counts.  Every tile of every problem is launched exactly once, in order; no problem is still pending
+    when the layer AFTER the next one starts (its operands live one extra layer); with carrying on, every launch but the last of a
+    flush is a whole round of 256 tiles — 18 launches instead of 24 for the encoder's 64 + 64 + 16 + 48."""
+    from scl_amd.encoder import plan_group_launches
+    pend, seen, launches = [], {}, []
+    for layer in range(24):
+        for it in pend:
+            it[3] += 1
+        pend.extend(["L%d.%d" % (layer, j), c, 0, 0] for j, c in enumerate(per_layer))
+        out = plan_group_launches(pend, final=(layer == 23), carry=carry)
+        assert all(it[3] == 0 for it in pend), "work older than the current layer was held back"
+        for parts in out:
+            assert 1 <= len(parts) <= 8
+            for name, first, count in parts:
+                assert count >= 1 and seen.get(name, 0) == first, (name, first, seen.get(name))
+                seen[name] = first + count
+        launches += out
+    assert not pend
+    for layer in range(24):
+        for j, c in enumerate(per_layer):
+            assert seen["L%d.%d" % (layer, j)] == c
+    sizes = [sum(c for _, _, c in parts) for parts in launches]
+    if carry:
+        assert all(s <= 256 for s in sizes)
+        if per_layer == [64, 64, 16, 48]:
+            assert sizes == [256] * 18
+    elif sum(per_layer) <= 256 and len(per_layer) <= 8:
+        assert sizes == [sum(per_layer)] * 24
