@@ -118,3 +118,17 @@ def test_bench_gpus_2_self_launched_on_one_device(dev):
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert line["rccl"]["rccl_ranks"] == 2 and line["rccl"]["backend"] == "gloo" and line["rccl"]["grad_bytes_per_step"] > 0
     assert "cpu_baseline" not in line            # N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_eval_mode_times_both_scoring_precisions(dev):
+    """`python bench.py --eval`: the scoring forward of 03_eval.sh (model.eval(), is_train False, no grad) on the fp32 scoring path and on
+    the bf16 training kernels, same weights and input; the JSON line carries both rates and how far the two sets of log-probs are apart."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--eval", "--tiny", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--samples", "16000"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"].startswith("scoring utterances/sec") and line["dtype"] == "f32" and line["config"]["samples"] == 16000
+    assert line["fp32"]["utterances_per_s"] > 0 and line["bf16"]["utterances_per_s"] > 0 and line["value"] == line["fp32"]["utterances_per_s"]
+    assert line["bf16_vs_fp32"]["max_rel_to_largest"] < 5e-2 and 0.0 <= line["bf16_vs_fp32"]["argmax_agree"] <= 1.0
