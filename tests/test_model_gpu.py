@@ -491,3 +491,53 @@ def test_fp32_scoring_path_matches_oracle_to_1e3_at_xlsr_shape(dev):
           (mx(out, ro), mx(emb, re), mx(feats, rf), mx(ob, ro), mx(eb, re), mx(fb, rf)))
     assert mx(out, ro) < 1e-3 and mx(emb, re) < 1e-3 and mx(feats, rf) < 1e-3
     assert (out.argmax(1).cpu() == ro.argmax(1)).all()
+
+
+@pytest.mark.parametrize("layerdrop", [0.0, 0.35])
+def test_carried_over_weight_gradient_launches_equal_the_split_k_path(dev, layerdrop):
+    """The grouped weight-gradient launches with carry-over (scl_amd/encoder.py::_flush_slabs: tile ranges of several layers' problems
+    in one launch, operands alive one layer longer) against one split-K launch per gradient, on the SAME forward: XLS-R-300M shape,
+    6 x 64000 samples (M = 1194 rows: zero rows up to 1216 behind the reduction operands), with and without LayerDrop (skipped layers
+    contribute no tiles; the flush rule counts processed layers).  Every encoder weight gradient must agree to fp32 summation round-off
+    (the two paths add the same products in different orders) — a clobbered operand would show as O(1)."""
+    from scl_amd import encoder as E
+    from scl_amd.encoder import W2VConfig
+    torch.manual_seed(11)
+    m = Model(ARGS, dev, w2v_cfg=W2VConfig(encoder_layerdrop=layerdrop))
+    m.train()
+    x = (0.1 * torch.randn(6, 64000, generator=torch.Generator().manual_seed(5))).to(dev)
+    y = torch.tensor([1, 1, 1, 0, 0, 0], device=dev)
+    grads = {}
+    saved = (E.WGRAD_GROUP, E.WGRAD_CARRY)
+    try:
+        for mode, (grp, carry) in (("split-k", (False, False)), ("group", (True, False)), ("carry", (True, True))):
+            E.WGRAD_GROUP, E.WGRAD_CARRY = grp, carry
+            for st in m._states.values():
+                st["plans"].clear()                   # a recorded launch plan would replay the first mode's launches
+            torch.manual_seed(123)                    # the same layers are dropped in every mode
+            m._step_seed = 777                        # ... and the same head-dropout masks drawn
+            out, feats, emb = m(x)
+            losses = m.loss(out, feats, emb, y, CONF)
+            m.P.grad.zero_()
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            grads[mode] = m.P.grad.clone()
+    finally:
+        E.WGRAD_GROUP, E.WGRAD_CARRY = saved
+    ref = grads["split-k"]
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+    for mode in ("group", "carry"):
+        for name in ("encoder.layers.23.fc2.weight", "encoder.layers.23.self_attn.q_proj.weight", "encoder.layers.12.fc1.weight",
+                     "encoder.layers.11.self_attn.out_proj.weight", "encoder.layers.0.fc2.weight", "encoder.layers.0.self_attn.v_proj.weight"):
+            o, n_, shape, _ = m.P.index["ssl_model.model." + name]
+            a, b = grads[mode][o:o + n_], ref[o:o + n_]
+            scale = float(b.abs().max())
+            if scale == 0:                            # a dropped layer: zero on both sides
+                assert float(a.abs().max()) == 0, (mode, name)
+                continue
+            assert float((a - b).abs().max()) < 2e-5 * scale, (mode, name, float((a - b).abs().max()) / scale)
+        whole = float((grads[mode] - ref).norm() / ref.norm())
+        assert whole < 1e-5, (mode, whole)
+    if layerdrop > 0:
+        zero_layers = sum(1 for n in range(24) if float(ref[m.P.index["ssl_model.model.encoder.layers.%d.fc1.weight" % n][0]:][:1024].abs().max()) == 0)
+        assert 1 <= zero_layers <= 20, zero_layers
