@@ -24,6 +24,20 @@ constexpr int FBK = 32;
 constexpr int LDK = 36;      // words per row of a K-contiguous image ([rows][32 k] + 4 pad: 16-byte aligned rows, spread banks)
 constexpr int LDT = 132;     // words per k-row of a transposed image ([32 k][128 contiguous] + 4 pad), 68 for the 64-wide tile
 
+constexpr int PK = 40;       // bf16 per row of a pair-form image ([rows][32 k] + 8 pad: 80-byte rows, the 16 rows of a fragment read hit 16 distinct bank quads)
+
+// four f32 -> four (hi, lo) bf16 pairs: hi = bf16(a) (round to nearest even), lo = bf16(a - hi)
+__device__ __forceinline__ void f32_split4(const u32x4& raw, uint2& hi, uint2& lo) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const f4 x = __builtin_bit_cast(f4, raw);
+    const b4 h = __builtin_convertvector(x, b4);
+    const f4 back = __builtin_convertvector(h, f4);
+    const b4 l = __builtin_convertvector(x - back, b4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
 template <int TM> struct F32Geom {
     static constexpr int ROWS = TM;                       // tile rows (= columns)
     static constexpr int WT = TM / 2;                     // per-wave rows
@@ -66,6 +80,18 @@ template <int TM> struct F32Stage<TM, false> {      // K-contiguous: TM rows x 3
         const int c = tid & 7;                       // logical k chunk (4 k); lane group q = c>>1 owns k 8q..8q+7
 #pragma unroll
         for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4*>(img + ((tid >> 3) + 32 * i) * LDK + 4 * c) = r[i];
+    }
+    // pair form: the element as hi = bf16(a) and lo = bf16(a - hi), each into its own [row][32 k] bf16 image (pitch PK)
+    __device__ __forceinline__ void store_pair(char* hi_img, char* lo_img, const u32x4 (&r)[NV], int tid) const {
+        const int c = tid & 7;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            uint2 h, l;
+            f32_split4(r[i], h, l);
+            const int off = ((tid >> 3) + 32 * i) * (PK * 2) + 8 * c;
+            *reinterpret_cast<uint2*>(hi_img + off) = h;
+            *reinterpret_cast<uint2*>(lo_img + off) = l;
+        }
     }
     __device__ __forceinline__ void advance() { kcur += FBK; }
 };
@@ -233,6 +259,102 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
     }
 }
 
+// ---- pair form with the split at STAGING time (round 5, second step) ---------------------------------------------------------------------
+// The X3 path above converts every fragment in every wave (each element twice, ~190 VALU instructions per 32-deep step and wave) and reads
+// f32 from LDS.  Here a thread converts the float4 it just fetched ONCE and stores hi and lo into two bf16 images; a fragment is one
+// ds_read_b128 per image and the loop body is 3 NB^2 MFMAs + 4 NB reads.  Same tiles, same global staging, same epilogue.
+template <int TM>
+__global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32p_kernel(const GemmK d) {
+    constexpr bool AT = false, BT = false;
+    typedef F32Geom<TM> G;
+    constexpr int IMGB = TM * PK * 2;      // bytes per image; a buffer = A hi, A lo, B hi, B lo
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + TM - 1) / TM;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + TM - 1) / TM, tiles_n, tm, tn, d.group_m);
+    const int m0 = tm * TM, n0 = tn * TM;
+    int z = blockIdx.z;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + FBK - 1) / FBK;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
+    const int kbegin = ksplit * nk_per * FBK;
+    int kend = kbegin + nk_per * FBK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + FBK - 1) / FBK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+    F32Stage<TM, AT> sa;
+    F32Stage<TM, BT> sb;
+    sa.init(d.A, Ab, m0, d.M, kbegin, kend, tid);
+    sb.init(d.B, Bb, n0, d.N, kbegin, kend, tid);
+    f32x4 acc[G::NB][G::NB];
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 ra[F32Stage<TM, AT>::NV], rb[F32Stage<TM, BT>::NV];
+    if (nk > 0) {
+        sa.load(d.A, ra); sb.load(d.B, rb);
+        sa.store_pair(psm, psm + IMGB, ra, tid); sb.store_pair(psm + 2 * IMGB, psm + 3 * IMGB, rb, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    const int frow = (lane & 15) * (PK * 2) + (lane >> 4) * 16;      // a lane's row and its 8 consecutive k inside a 16-row block
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) { sa.advance(); sb.advance(); sa.load(d.A, ra); sb.load(d.B, rb); }
+        const char* t0 = psm + cur * 4 * IMGB;
+        bf16x8 ah[G::NB], al[G::NB], bh[G::NB], bl[G::NB];
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i) {
+            const int ao = (wr * G::NB + i) * 16 * (PK * 2) + frow, bo = (wc * G::NB + i) * 16 * (PK * 2) + frow;
+            ah[i] = *reinterpret_cast<const bf16x8*>(t0 + ao);
+            al[i] = *reinterpret_cast<const bf16x8*>(t0 + IMGB + ao);
+            bh[i] = *reinterpret_cast<const bf16x8*>(t0 + 2 * IMGB + bo);
+            bl[i] = *reinterpret_cast<const bf16x8*>(t0 + 3 * IMGB + bo);
+        }
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+            for (int n = 0; n < G::NB; ++n) {
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[n], ah[i], acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], al[i], acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], ah[i], acc[i][n], 0, 0, 0);
+            }
+        if (more) {
+            char* nb = psm + (cur ^ 1) * 4 * IMGB;
+            sa.store_pair(nb, nb + IMGB, ra, tid); sb.store_pair(nb + 2 * IMGB, nb + 3 * IMGB, rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if constexpr (G::NB == 4) {
+        f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0][0]);
+        gemm_epilogue_blk<4>(d, a4, m0 + wr * 64, n0 + wc * 64, d.M, 4, z1, z2, ksplit, lane);
+    } else {
+        f32x4 a24[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a24[i][0] = acc[i][0]; a24[i][1] = acc[i][1]; a24[i][2] = f32x4{0.f, 0.f, 0.f, 0.f}; a24[i][3] = a24[i][2]; }
+        GemmK dd = d;
+        const int nlim = n0 + wc * 32 + 32;
+        dd.N = nlim < d.N ? nlim : d.N;
+        gemm_epilogue_blk<2>(dd, a24, m0 + wr * 32, n0 + wc * 32, d.M, 2, z1, z2, ksplit, lane);
+    }
+}
+
+template <int TM>
+void f32p_launch(const GemmK& k, dim3 grid, hipStream_t s) {
+    const size_t lds = (size_t)2 * 4 * TM * PK * 2;
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        (void)hipFuncSetAttribute((const void*)scl_gemm_f32p_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    SCL_LAUNCH((scl_gemm_f32p_kernel<TM>), grid, dim3(256), lds, s, k);
+}
+
 template <int TM, bool X3>
 void f32_launch(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s) {
     const size_t lds = 4 * (size_t)F32Geom<TM>::IMG * sizeof(float);
@@ -263,13 +385,20 @@ int scl_gemm_f32_launch(const SclGemmDesc& d, GemmK& k, hipStream_t s) {
     // 128x128 tiles once they fill the chip twice over; otherwise 64x64 (4x the blocks: the back-ends' maps are small)
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * zdim;
     const bool x3 = d.flags & SCL_GEMM_F32X3;
+    // K-contiguous operands take the staging-split kernel; a transposed operand would need 2-byte scatter stores into the images
+    // (measured 95.8 vs 68.2 us on the ResNet TT weight gradient) and keeps the fragment-split form
+    const bool frag_form = at || bt;
     if (t128 >= 512 && d.M >= 128 && d.N >= 128) {
         const dim3 grid((unsigned)(t128 / zdim), 1, (unsigned)zdim);
-        if (x3) f32_launch<128, true>(k, at, bt, grid, s); else f32_launch<128, false>(k, at, bt, grid, s);
+        if (x3 && !frag_form) f32p_launch<128>(k, grid, s);
+        else if (x3) f32_launch<128, true>(k, at, bt, grid, s);
+        else f32_launch<128, false>(k, at, bt, grid, s);
     } else {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64);
         const dim3 grid((unsigned)t64, 1, (unsigned)zdim);
-        if (x3) f32_launch<64, true>(k, at, bt, grid, s); else f32_launch<64, false>(k, at, bt, grid, s);
+        if (x3 && !frag_form) f32p_launch<64>(k, grid, s);
+        else if (x3) f32_launch<64, true>(k, at, bt, grid, s);
+        else f32_launch<64, false>(k, at, bt, grid, s);
     }
     return SCL_OK;
 }

@@ -1,10 +1,12 @@
-"""HIP front end (XLS-R encoder + LL projection, losses) with a torch-composed back-end: the shared machinery of the
-`wav2vec2_aasist` and `wav2vec2_resnet_nll` plugins.
+"""HIP front end (XLS-R encoder + LL projection, losses) in front of a back-end module: the shared machinery of the
+`wav2vec2_aasist`, `wav2vec2_resnet_nll` and `wav2vec2_btse` plugins.
 
 What runs where: the encoder, the LL projection and the three loss terms are the HIP kernels of the wav2vec2_linear_nll
 path (one autograd boundary around encoder + LL, launch plans recorded per (B, L)).  The back-end on the [bz, T, 128]
-features is a torch module whose parameters are views into the same flat fp32 buffer, so the fused AdamW kernel and the
-data-parallel gradient buckets cover them too; in training it is replayed as two captured hipGraphs per feature shape.
+features is an nn.Module (a parameter container whose forward is hand-written HIP behind its own autograd Function: resstack.py +
+graph.py, resnet_head.py, btse_head.py) whose parameters are views into the same flat fp32 buffer, so the fused AdamW kernel and the
+data-parallel gradient buckets cover them too.  SCL_HEAD_GRAPH=1 replays a back-end as two captured hipGraphs per feature shape (off by
+default: the HIP back-ends are a few dozen launches).
 Sub-classes supply `_build_head(args)` (an nn.Module whose children / parameters are grafted at the root under the
 reference's state-dict names) and `_head_forward(mod, feats) -> (output, emb)`.
 """

@@ -85,8 +85,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         # gradients live in one flat buffer that every backward overwrites in full; nothing to clear,
-        # and the .grad views must stay attached.  A model with torch-composed parts (wav2vec2_aasist's head) clears the
-        # slice autograd accumulates into.
+        # and the .grad views must stay attached.  A model whose back-end accumulates through autograd's .grad views clears
+        # that slice (model_front.zero_torch_grads).
         if hasattr(self.model, "zero_torch_grads"):
             self.model.zero_torch_grads()
         return None

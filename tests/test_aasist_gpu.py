@@ -1,5 +1,5 @@
-"""`wav2vec2_aasist` plugin on the GPU: HIP encoder + LL behind one autograd boundary, torch-composed AASIST back-end on
-flat-buffer parameter views.  Reference = oracle wav2vec2 restatement (fp32, CPU) -> LL -> the same AasistHead class that
+"""`wav2vec2_aasist` plugin on the GPU: HIP encoder + LL behind one autograd boundary, the hand-written HIP AASIST back-end
+(scl_amd/resstack.py + graph.py) on flat-buffer parameter views.  Reference = oracle wav2vec2 restatement (fp32, CPU) -> LL -> the same AasistHead class that
 tests/test_aasist_cpu.py pins to the reference's own Model.  Tolerance: the bf16 bar of BASELINE.json (rel-L2 < 1e-2 on the
 encoder-side tensors); the back-end's top-k graph pooling is discontinuous, so tensors after it get 5e-2."""
 import os
