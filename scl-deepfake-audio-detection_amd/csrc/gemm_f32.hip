@@ -263,6 +263,17 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
 // The X3 path above converts every fragment in every wave (each element twice, ~190 VALU instructions per 32-deep step and wave) and reads
 // f32 from LDS.  Here a thread converts the float4 it just fetched ONCE and stores hi and lo into two bf16 images; a fragment is one
 // ds_read_b128 per image and the loop body is 3 NB^2 MFMAs + 4 NB reads.  Same tiles, same global staging, same epilogue.
+// Measured (tools/f32x3_probe.py, MI355X): scoring GEMMs 449-605 -> 355-500 us (216-235 TFLOP/s of f32-equivalent work), ResNet data-gradient
+// convolutions 171-226 -> 150-172 us.  A transposed operand would need 2-byte scatter stores into the images (95.8 vs 68.2 us on the
+// ResNet TT weight gradient) and keeps the fragment-split form.
+// Tried and dropped in the same round (QKV-shaped scoring GEMM 12864 x 3072 x 1024 / ResNet 64->64 conv at 32 utterances):
+//  * a THREE-part form (a = p0 + p1 + p2 carries all 24 mantissa bits; the six terms of weight >= 2^-16) as a replacement for the exact
+//    v_mfma_f32_16x16x4_f32 kernel: same error against fp64 (1.0e-6 vs 1.3e-6) at 96 instead of 256 matrix-core cycles per 16x16x32
+//    block, but 745 vs 759 us / 286 vs 254 us — three images per operand are 120 KB of LDS (one block per CU) and 1.5x the LDS traffic;
+//  * a second register set (fetch distance 2): no change (354 vs 355 us) at +42 VGPRs.
+//  Ablations on the QKV shape: full 354 us; without the global fetches 257; without the MFMAs 237; without the split + image stores 297 —
+//  no single resource bounds it: fetch issue, fragment reads, MFMAs and image stores run back to back inside a wave and two blocks
+//  per CU overlap them only partly (LDS traffic ~= MFMA time at this tile shape).
 template <int TM>
 __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32p_kernel(const GemmK d) {
     constexpr bool AT = false, BT = false;
