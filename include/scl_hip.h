@@ -216,12 +216,19 @@ int scl_bn_fwd(const float* x, int N, int C, const float* gamma, const float* be
                float* rstd, float* y, void* y2, int y2_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs, int64_t m_cs,
                int64_t m_base, void* stream);
 /* backward of the above: dz = dy * act'(y); dgamma = sum dz * xhat, dbeta = sum dz (either may be NULL); dx = gamma * rstd *
- * (dz - [training] (sum dz + xhat * sum dz*xhat) / N).  part: as above; sums: f32 [2*C] scratch. */
+ * (dz - [training] (sum dz + xhat * sum dz*xhat) / N).  part: as above; sums: f32 [2*C] scratch.  accumulate != 0: dgamma / dbeta are ADDED to
+ * (autograd's accumulation into an attached .grad buffer, done by the finishing kernel). */
 int scl_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int N, int C,
-               int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, void* stream);
+               int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, int accumulate, void* stream);
 /* src [rows, C] contiguous f32 -> mapped (padded / dilated) destination, f32 or bf16 (row mapping as scl_bn_fwd's y2) */
 int scl_pad_nhwc_f32(const float* src, int64_t rows, int C, void* dst, int dst_bf16, int m_W, int m_HW, int64_t m_bs, int64_t m_rs,
                      int64_t m_cs, int64_t m_base, void* stream);
+/* Both re-laid-out copies of a Conv2d weight [Co][Ci][kh][kw] (torch layout, model/wav2vec2_resnet_nll.py's nn.Conv2d parameters) for the
+ * implicit-GEMM convolution: fwd [Co][kh][kw][Cp] (zero channels Ci..Cp) and bwd [Ci][kh][kw][Cop] with flipped taps (zero channels Co..Cop). */
+int scl_conv_pack_weights(const float* w, float* fwd, float* bwd, int Co, int Ci, int kh, int kw, int Cp, int Cop, void* stream);
+/* grad [Co][Ci][kh][kw] (+)= sum over nslab slabs [Co][kh][kw][Cp] in slab order (the conv weight gradient's split-K / per-utterance partials,
+ * what torch's conv backward + AccumulateGrad produce); accumulate = 0 overwrites. */
+int scl_conv_wgrad_finish(const float* slabs, float* grad, int nslab, int Co, int Ci, int kh, int kw, int Cp, int accumulate, void* stream);
 /* F.max_pool2d(x, (3, 3)) of a single-channel map given by strides (elements): y [B, H/3, W/3], idx = flat argmax inside x[b]
  * (model/wav2vec2_aasist.py:517); the backward scatters dy into a zeroed dx. */
 int scl_maxpool3_fwd(const float* x, int64_t xs_h, int64_t xs_w, int64_t xs_b, int H, int W, int B, float* y, int* idx, void* stream);

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     });
 }
 __global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const double* __restrict__ part, int nslab, int C, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ sums) {
+                                                            float* __restrict__ dbeta, float* __restrict__ sums, int accumulate) {
     __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const double* __res
     if (lane4 != 0 || c >= C) return;
     s = 0.0; q = 0.0;
     for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
-    if (dbeta) dbeta[c] = (float)s;
-    if (dgamma) dgamma[c] = (float)q;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
     sums[c] = (float)s; sums[C + c] = (float)q;
 }
 // pass 2: dx = gamma * rstd * (dz - [training] (sum dz + xhat * sum dz*xhat) / N)
@@ -351,13 +351,13 @@ extern "C" int scl_bn_fwd(const float* x, int N, int C, const float* gamma, cons
 }
 
 extern "C" int scl_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int N, int C,
-                          int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, void* stream) {
+                          int act, int training, float* part, float* sums, float* dgamma, float* dbeta, float* dx, int accumulate, void* stream) {
     SCL_REQUIRE(dy && x && mean && rstd && part && sums && dx && N >= 1 && bn_channels_ok(C), "bn_bwd: bad args");
     SCL_REQUIRE(act == 0 || y, "bn_bwd: the activation gradient needs the forward output y");
     hipStream_t s = (hipStream_t)stream;
     const int nslab = scl_bn_nslabs(N);
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nslab), dim3(256), 0, s, dy, y, x, mean, rstd, N, C, act, (double*)part, bn_slab_rows(N));
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const double*)part, nslab, C, dgamma, dbeta, sums, accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, s, dy, y, x, mean, rstd, gamma, sums, (long long)N * C, N, C,
                        act, training, dx);
     return scl_check_launch("scl_bn_bwd");
@@ -369,6 +369,62 @@ extern "C" int scl_pad_nhwc_f32(const float* src, int64_t rows, int C, void* dst
     const RowMap map = {m_W, m_HW, m_bs, m_rs, m_cs, m_base};
     hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, src, rows * C, C, dst, dst_bf16, map);
     return scl_check_launch("scl_pad_nhwc_f32");
+}
+
+// Re-layout of one convolution's weights for the implicit-GEMM kernels, both copies in one launch (hipnn.py's _packed cache):
+//   fwd [Co][kh][kw][Cp]  = w[co][c][r][s]            (forward and weight-gradient operand; channels c >= Ci are zero)
+//   bwd [Ci][kh][kw][Cop] = w[co][c][kh-1-r][kw-1-s]  (data-gradient operand: flipped taps, in/out swapped; channels co >= Co are zero)
+// Replaces five torch kernels per convolution and step (two fills, flip, two strided copies: 0.75 ms of the ResNet step at batch 32).
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ bwd, int Co, int Ci, int kh, int kw,
+                                                        int Cp, int Cop) {
+    const long long nf = (long long)Co * kh * kw * Cp, nb = (long long)Ci * kh * kw * Cop;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nf + nb; i += gridDim.x * 256ll) {
+        if (i < nf) {
+            const int c = (int)(i % Cp); long long t = i / Cp;
+            const int s_ = (int)(t % kw); t /= kw;
+            const int r = (int)(t % kh); const int co = (int)(t / kh);
+            fwd[i] = c < Ci ? w[(((long long)co * Ci + c) * kh + r) * kw + s_] : 0.f;
+        } else {
+            const long long j = i - nf;
+            const int co = (int)(j % Cop); long long t = j / Cop;
+            const int s_ = (int)(t % kw); t /= kw;
+            const int r = (int)(t % kh); const int c = (int)(t / kh);
+            bwd[j] = co < Co ? w[(((long long)co * Ci + c) * kh + (kh - 1 - r)) * kw + (kw - 1 - s_)] : 0.f;
+        }
+    }
+}
+
+extern "C" int scl_conv_pack_weights(const float* w, float* fwd, float* bwd, int Co, int Ci, int kh, int kw, int Cp, int Cop, void* stream) {
+    SCL_REQUIRE(w && fwd && bwd && Co >= 1 && Ci >= 1 && kh >= 1 && kw >= 1 && Cp >= Ci && Cop >= Co, "conv_pack_weights: bad args");
+    const long long n = (long long)Co * kh * kw * Cp + (long long)Ci * kh * kw * Cop;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, fwd, bwd, Co, Ci, kh, kw, Cp, Cop);
+    return scl_check_launch("scl_conv_pack_weights");
+}
+
+// Weight gradient of a convolution out of its per-utterance slabs: grad[co][c][r][s] += sum_z slabs[z][co][(r*kw+s)*Cp + c] — the fixed-order
+// slab sum, the [Co][kh][kw][Cp] -> torch-layout permute and autograd's accumulation into the parameter's .grad in one pass.
+__global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ grad, int nslab, int Co, int Ci, int kh, int kw,
+                                                                int Cp, int accumulate) {
+    // threads run over the SLAB layout (channel fastest): the nslab reads are coalesced, the one write per element is the strided one
+    const long long slab = (long long)Co * kh * kw * Cp;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < slab; i += gridDim.x * 256ll) {
+        const int c = (int)(i % Cp);
+        if (c >= Ci) continue;
+        long long t = i / Cp;
+        const int s_ = (int)(t % kw); t /= kw;
+        const int r = (int)(t % kh); const int co = (int)(t / kh);
+        float acc = 0.f;
+        for (int z = 0; z < nslab; ++z) acc += slabs[z * slab + i];
+        float* g = grad + (((long long)co * Ci + c) * kh + r) * kw + s_;
+        *g = accumulate ? *g + acc : acc;
+    }
+}
+
+extern "C" int scl_conv_wgrad_finish(const float* slabs, float* grad, int nslab, int Co, int Ci, int kh, int kw, int Cp, int accumulate, void* stream) {
+    SCL_REQUIRE(slabs && grad && nslab >= 1 && Co >= 1 && Ci >= 1 && kh >= 1 && kw >= 1 && Cp >= Ci, "conv_wgrad_finish: bad args");
+    hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3(grid_for((long long)Co * kh * kw * Cp)), dim3(256), 0, (hipStream_t)stream, slabs, grad, nslab, Co, Ci, kh, kw,
+                       Cp, accumulate);
+    return scl_check_launch("scl_conv_wgrad_finish");
 }
 
 extern "C" int scl_maxpool3_fwd(const float* x, int64_t xs_h, int64_t xs_w, int64_t xs_b, int H, int W, int B, float* y, int* idx, void* stream) {

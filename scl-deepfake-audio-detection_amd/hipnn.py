@@ -59,6 +59,20 @@ def _packed(weight, kind, dtype, build):
     return hit[1]
 
 
+def _packed_conv(weight, dtype, Co, Ci, kh, kw, Cp, Cop):
+    """(forward / weight-gradient operand [Co, kh*kw*Cp], data-gradient operand [Ci, kh*kw*Cop]) of a Conv2d weight: one HIP launch per
+    convolution and optimizer step (scl_conv_pack_weights) instead of two fills, a flip and two strided copies."""
+    def build():
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        fwd = torch.empty(Co, kh * kw * Cp, dtype=torch.float32, device=w.device)
+        bwd = torch.empty(Ci, kh * kw * Cop, dtype=torch.float32, device=w.device)
+        ops.conv_pack_weights(w, fwd, bwd, Co, Ci, kh, kw, Cp, Cop)
+        return fwd.to(dtype), bwd.to(dtype)
+    return _packed(weight, "conv", dtype, build)
+
+
 # Zero-bordered / zero-dilated staging maps are written in their interior only (pad_nhwc), so a buffer that was zero-filled ONCE can serve
 # every later call with the same geometry: 93 torch fills per ResNet step (0.6 ms at batch 32) disappear.  A forward's padded input lives
 # until its backward (busy flag, released there or when the node dies); the backward's own maps are free again as soon as their GEMMs
@@ -101,8 +115,8 @@ def _colsum(x2d, M, N):
 # ---- convolution ---------------------------------------------------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dtype, x3_bwd=False):
-        """x [B, H, W, Ci] f32; weight [Co, Ci, kh, kw] (torch layout); bias [Co] or None -> y [B, OH, OW, Co] f32."""
+    def forward(ctx, x, weight, bias, stride, padding, dtype, x3_bwd=False, grad_in_place=False, residual=None):
+        """x [B, H, W, Ci] f32; weight [Co, Ci, kh, kw] (torch layout); bias [Co] or None -> y [B, OH, OW, Co] f32 (+ residual, same shape)."""
         B, H, W, Ci = x.shape
         Co, _, kh, kw = weight.shape
         sh, sw = stride
@@ -119,18 +133,16 @@ class _Conv2dFn(torch.autograd.Function):
         ops.pad_nhwc(xc, B * H * W, Ci, xp, rowmap)
         ctx.xp_ent = ent
         weakref.finalize(ctx, _zeros_release, ent)
-        def pack_fwd():
-            w = torch.zeros(Co, kh, kw, Cp, dtype=torch.float32, device=dev)
-            w[..., :Ci] = weight.detach().permute(0, 2, 3, 1)
-            return w.reshape(Co, kh * kw * Cp).to(dtype)
-        wk = _packed(weight, "fwd", dtype, pack_fwd)
+        wk = _packed_conv(weight, dtype, Co, Ci, kh, kw, Cp, _ceil(Co, vec))[0]
         K = kh * kw * Cp
         y = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
         _gemm(Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp), Op(wk, K), y, OH * OW, Co, K,
-                 nb1=B, c_bs1=OH * OW * Co, bias=None if bias is None else bias.detach().float().contiguous())
+                 nb1=B, c_bs1=OH * OW * Co, bias=None if bias is None else bias.detach().float().contiguous(),
+                 **({} if residual is None else dict(R=residual.detach().contiguous().float(), rmode=1)))       # the block's skip connection in the epilogue
         ctx.save_for_backward(xp, weight)
         ctx.geom = (B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, bias is not None)
         ctx.x3_bwd = bool(x3_bwd)
+        ctx.grad_in_place = weight if grad_in_place else None      # the Parameter itself: saved_tensors hands back a fresh tensor object without .grad
         return y
 
     @staticmethod
@@ -163,9 +175,14 @@ class _Conv2dFn(torch.autograd.Function):
             slabs = torch.empty(B * sk, Co, K, dtype=torch.float32, device=dev)
             ops.gemm(Op(dyc, Cop, bs1=OH * OW * Cop), Op(xp, sw * Cp, rpb=OW, rbstride=sh * Wp * Cp, cin=kw * Cp, cout=Wp * Cp, bs1=Hp * Wp * Cp),
                      slabs, Co, K, OH * OW, a_t=True, b_t=True, nb1=B, c_bs1=sk * Co * K, splitk=sk, c_split_stride=Co * K if sk > 1 else 0, x3=x3_bwd)
-            dwk = torch.empty(Co, K, dtype=torch.float32, device=dev)
-            ops.reduce_slabs(slabs, dwk, Co * K, B * sk, Co * K)
-            dw = dwk.view(Co, kh, kw, Cp)[..., :Ci].permute(0, 3, 1, 2)
+            # slab sum (fixed order) + [Co][kh][kw][Cp] -> torch layout in one kernel; with grad_in_place (parameters whose .grad is an
+            # attached flat-buffer view: the model plugins) also autograd's accumulation, and no gradient is handed back to the engine
+            g = ctx.grad_in_place.grad if ctx.grad_in_place is not None else None
+            if g is not None and g.dtype == torch.float32 and g.is_contiguous() and not torch.cuda.is_current_stream_capturing():
+                ops.conv_wgrad_finish(slabs, g, B * sk, Co, Ci, kh, kw, Cp, accumulate=True)
+            else:
+                dw = torch.empty(Co, Ci, kh, kw, dtype=torch.float32, device=dev)
+                ops.conv_wgrad_finish(slabs, dw, B * sk, Co, Ci, kh, kw, Cp, accumulate=False)
             if ent_c is not None:
                 _zeros_release(ent_c)
         if ctx.needs_input_grad[0]:
@@ -176,29 +193,28 @@ class _Conv2dFn(torch.autograd.Function):
             dyp = ent_p[0]
             ops.pad_nhwc(dy, B * OH * OW, Co, dyp, rm)
             Kd = kh * kw * Cop
-
-            def pack_bwd():
-                w = torch.zeros(Ci, kh, kw, Cop, dtype=torch.float32, device=dev)
-                w[..., :Co] = weight.detach().flip(2, 3).permute(1, 2, 3, 0)
-                return w.reshape(Ci, Kd).to(dtype)
-            wd = _packed(weight, "bwd", dtype, pack_bwd)
+            wd = _packed_conv(weight, dtype, Co, Ci, kh, kw, Cp, Cop)[1]
             dx = torch.empty(B, H, W, Ci, dtype=torch.float32, device=dev)
             ops.gemm(Op(dyp, Cop, rpb=W, rbstride=Wd * Cop, cin=kw * Cop, cout=Wd * Cop, bs1=Hd * Wd * Cop), Op(wd, Kd), dx, H * W, Ci, Kd,
                      nb1=B, c_bs1=H * W * Ci, x3=x3_bwd)
             _zeros_release(ent_p)
         _zeros_release(ctx.xp_ent)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, (dy if ctx.needs_input_grad[8] else None)
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dtype=torch.float32, x3_bwd=False):
-    """Channels-last 2-D convolution (cross-correlation, as nn.Conv2d): x [B, H, W, Ci] -> [B, OH, OW, Co]."""
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), dtype, x3_bwd)
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dtype=torch.float32, x3_bwd=False, grad_in_place=False, residual=None):
+    """Channels-last 2-D convolution (cross-correlation, as nn.Conv2d): x [B, H, W, Ci] -> [B, OH, OW, Co] (+ residual [B, OH, OW, Co], added in
+    the GEMM epilogue; its gradient is the output gradient).  grad_in_place: the weight
+    gradient is ADDED into `weight.grad` by the finishing kernel (when that tensor exists) instead of being returned to autograd — for
+    `.backward()` callers whose parameters carry attached .grad views (the plugins' flat gradient buffer); torch.autograd.grad callers
+    leave it off."""
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), dtype, x3_bwd, grad_in_place, residual)
 
 
 # ---- BatchNorm (+ activation) --------------------------------------------------------------------------------------------------------
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act, grad_in_place=False):
         C = x.shape[-1]
         xc = x.contiguous().float()
         N = xc.numel() // C
@@ -209,6 +225,7 @@ class _BatchNormFn(torch.autograd.Function):
         ops.bn_fwd(xc, N, C, weight, bias, running_mean, running_var, nbt, training, momentum, eps, act, part, mean, rstd, y)
         ctx.save_for_backward(xc, y, mean, rstd, weight)
         ctx.cfg = (N, C, act, training, weight is not None, bias is not None)
+        ctx.in_place = (weight, bias) if grad_in_place else None
         return y
 
     @staticmethod
@@ -219,20 +236,27 @@ class _BatchNormFn(torch.autograd.Function):
         dyc = dy.contiguous().float()
         part = torch.empty(ops.bn_nslabs(N) * 2 * C, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * C, device=dev)
+        dx = torch.empty_like(xc)
+        if ctx.in_place is not None and has_w and has_b and not torch.cuda.is_current_stream_capturing():
+            # both parameters carry an attached, contiguous f32 .grad (the plugins' flat gradient buffer): the finishing kernel adds into
+            # them (what AccumulateGrad would do with two more launches) and autograd gets no parameter gradient back
+            gw, gb = ctx.in_place[0].grad, ctx.in_place[1].grad
+            if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for g in (gw, gb)):
+                ops.bn_bwd(dyc, y, xc, mean, rstd, weight, N, C, act, training, part, sums, gw, gb, dx, accumulate=True)
+                return dx, None, None, None, None, None, None, None, None, None, None
         dg = torch.empty(C, device=dev) if has_w else None
         db = torch.empty(C, device=dev) if has_b else None
-        dx = torch.empty_like(xc)
         ops.bn_bwd(dyc, y, xc, mean, rstd, weight, N, C, act, training, part, sums, dg, db, dx)
-        return dx, dg, db, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, bn, act=ACT_NONE):
+def batch_norm(x, bn, act=ACT_NONE, grad_in_place=False):
     """nn.BatchNorm1d / 2d semantics over the LAST dimension of x (channels-last), fused with `act`; `bn` supplies weight, bias, the
-    running statistics and the training flag (its forward is never called)."""
+    running statistics and the training flag (its forward is never called).  grad_in_place: as conv2d's."""
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, training,
-                              momentum, bn.eps, act)
+                              momentum, bn.eps, act, grad_in_place)
 
 
 # ---- Linear / bmm ----------------------------------------------------------------------------------------------------------------------

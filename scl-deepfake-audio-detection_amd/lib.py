@@ -130,8 +130,10 @@ def _protos():
         "scl_bn_nslabs": ([_i32], _i32),
         "scl_bn_fwd": ([_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64,
                         _i64, _i64, _vp], _i32),
-        "scl_bn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+        "scl_bn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
         "scl_pad_nhwc_f32": ([_vp, _i64, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp], _i32),
+        "scl_conv_pack_weights": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+        "scl_conv_wgrad_finish": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_maxpool3_fwd": ([_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
         "scl_maxpool3_bwd": ([_vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp], _i32),
         "scl_avgpool_fwd": ([_vp, _i32, _i32, _i32, _vp, _vp], _i32),

@@ -614,14 +614,22 @@ def bn_fwd(x, N, C, gamma, beta, running_mean, running_var, nbt, training, momen
           _p(part), _p(mean), _p(rstd), _p(y), _p(y2), 1 if (y2 is not None and y2.dtype == torch.bfloat16) else 0, W_, HW, bs, rs, cs, base, _stream())
 
 
-def bn_bwd(dy, y, x, mean, rstd, gamma, N, C, act, training, part, sums, dgamma, dbeta, dx):
+def bn_bwd(dy, y, x, mean, rstd, gamma, N, C, act, training, part, sums, dgamma, dbeta, dx, accumulate=False):
     _call("scl_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), N, C, act, 1 if training else 0, _p(part), _p(sums), _p(dgamma),
-          _p(dbeta), _p(dx), _stream())
+          _p(dbeta), _p(dx), 1 if accumulate else 0, _stream())
 
 
 def pad_nhwc(src, rows, C, dst, rowmap):
     W_, HW, bs, rs, cs, base = rowmap
     _call("scl_pad_nhwc_f32", _p(src), rows, C, _p(dst), 1 if dst.dtype == torch.bfloat16 else 0, W_, HW, bs, rs, cs, base, _stream())
+
+
+def conv_pack_weights(w, fwd, bwd, Co, Ci, kh, kw, Cp, Cop):
+    _call("scl_conv_pack_weights", _p(w), _p(fwd), _p(bwd), Co, Ci, kh, kw, Cp, Cop, _stream())
+
+
+def conv_wgrad_finish(slabs, grad, nslab, Co, Ci, kh, kw, Cp, accumulate=True):
+    _call("scl_conv_wgrad_finish", _p(slabs), _p(grad), nslab, Co, Ci, kh, kw, Cp, 1 if accumulate else 0, _stream())
 
 
 def maxpool3_fwd(x, xs_h, xs_w, xs_b, H, W_, B, y, idx):

@@ -53,9 +53,9 @@ class ConvWeight(nn.Module):
         else:
             self.bias = None
 
-    def conv(self, x, dtype):
-        """x [B, H, W, Ci] channels-last -> [B, OH, OW, Co]."""
-        return hipnn.conv2d(x, self.weight, self.bias, self.stride, self.padding, dtype, x3_bwd=X3_BWD)
+    def conv(self, x, dtype, residual=None):
+        """x [B, H, W, Ci] channels-last -> [B, OH, OW, Co] (+ residual, the block's skip connection, in the GEMM epilogue)."""
+        return hipnn.conv2d(x, self.weight, self.bias, self.stride, self.padding, dtype, x3_bwd=X3_BWD, grad_in_place=True, residual=residual)
 
 
 class _Shortcut(nn.Module):
@@ -80,10 +80,10 @@ class PreActBlock(nn.Module):
             self.shortcut = _Shortcut(cin, planes, stride)
 
     def run(self, x, dt):
-        a = hipnn.batch_norm(x, self.bn1, hipnn.ACT_RELU)
+        a = hipnn.batch_norm(x, self.bn1, hipnn.ACT_RELU, grad_in_place=True)
         skip = getattr(self.shortcut, "0").conv(a, dt) if hasattr(self, "shortcut") else x
-        h = hipnn.batch_norm(self.conv1.conv(a, dt), self.bn2, hipnn.ACT_RELU)
-        return self.conv2.conv(h, dt) + skip
+        h = hipnn.batch_norm(self.conv1.conv(a, dt), self.bn2, hipnn.ACT_RELU, grad_in_place=True)
+        return self.conv2.conv(h, dt, residual=skip)
 
 
 class PreActBottleneck(nn.Module):
@@ -102,11 +102,11 @@ class PreActBottleneck(nn.Module):
             self.shortcut = _Shortcut(cin, 4 * planes, stride)
 
     def run(self, x, dt):
-        a = hipnn.batch_norm(x, self.bn1, hipnn.ACT_RELU)
+        a = hipnn.batch_norm(x, self.bn1, hipnn.ACT_RELU, grad_in_place=True)
         skip = getattr(self.shortcut, "0").conv(a, dt) if hasattr(self, "shortcut") else x
-        h = hipnn.batch_norm(self.conv1.conv(a, dt), self.bn2, hipnn.ACT_RELU)
-        h = hipnn.batch_norm(self.conv2.conv(h, dt), self.bn3, hipnn.ACT_RELU)
-        return self.conv3.conv(h, dt) + skip
+        h = hipnn.batch_norm(self.conv1.conv(a, dt), self.bn2, hipnn.ACT_RELU, grad_in_place=True)
+        h = hipnn.batch_norm(self.conv2.conv(h, dt), self.bn3, hipnn.ACT_RELU, grad_in_place=True)
+        return self.conv3.conv(h, dt, residual=skip)
 
 
 class _Stage(nn.Module):
@@ -136,11 +136,11 @@ class ResNet(nn.Module):
 
     def run(self, x, dt):
         """x [bz, T, 128, 1] -> (logits [bz, nclasses], emb [bz, 256])."""
-        x = hipnn.batch_norm(self.conv1.conv(x, dt), self.bn1, hipnn.ACT_RELU)
+        x = hipnn.batch_norm(self.conv1.conv(x, dt), self.bn1, hipnn.ACT_RELU, grad_in_place=True)
         for s in (1, 2, 3, 4):
             for blk in getattr(self, "layer%d" % s).children():
                 x = blk.run(x, dt)
-        x = hipnn.batch_norm(self.conv5.conv(x, dt), self.bn5, hipnn.ACT_RELU)          # [bz, H', W', 256]
+        x = hipnn.batch_norm(self.conv5.conv(x, dt), self.bn5, hipnn.ACT_RELU, grad_in_place=True)          # [bz, H', W', 256]
         emb = hipnn.avg_pool_rows(x.reshape(x.shape[0], -1, x.shape[-1]))
         return hipnn.linear(emb, self.fc.weight, self.fc.bias), emb
 
@@ -155,5 +155,5 @@ class ResNetHead(nn.Module):
         self.resnet = ResNet(**(cfg or DEFAULT_RESNET))
 
     def forward(self, feats):
-        x = hipnn.batch_norm(feats.unsqueeze(-1), self.first_bn, hipnn.ACT_SELU)       # the [bz, 1, T, 128] map, channels last
+        x = hipnn.batch_norm(feats.unsqueeze(-1), self.first_bn, hipnn.ACT_SELU, grad_in_place=True)       # the [bz, 1, T, 128] map, channels last
         return self.resnet.run(x, _conv_dtype())
