@@ -21,6 +21,8 @@ GEOMS = [  # B, H, W, Ci, Co, k, stride, pad
     (2, 17, 12, 16, 32, 3, (2, 2), (1, 1)),       # strided block entry
     (2, 9, 10, 32, 6, 1, (2, 2), (0, 0)),         # 1x1 shortcut, Co not a multiple of 4
     (2, 8, 8, 64, 64, 3, (1, 1), (1, 1)),
+    (2, 9, 10, 32, 8, 1, (1, 1), (0, 0)),         # 1x1, stride 1: the flat whole-batch weight gradient with a single tap
+    (5, 30, 34, 8, 16, 3, (1, 1), (1, 1)),        # enough positions for several split-K slabs of the flat weight gradient
 ]
 
 
