@@ -1,32 +1,35 @@
-// btse.hip — the "bio" branch of the reference's wav2vec2_btse plugin (BASELINE.json configs[4]) as two kernels, and the join in front
-// of fc2.  Reference: model/wav2vec2_btse/model.py:210-238 (bioEncoderTransformersmall), :321-343 (Model.forward);
+// btse.hip — the "bio" branch of the reference's wav2vec2_btse plugin (BASELINE.json configs[4]): row kernels and per-head attention
+// kernels behind two entry points (scl_btse_bio_fwd / _bwd), and the join in front of fc2.  Reference: model/wav2vec2_btse/model.py:210-238 (bioEncoderTransformersmall), :321-343 (Model.forward);
 // model/wav2vec2_btse/transformer.py:17-52 (Encoder), :105-260 (MultiHeadAttention, window_size = 4 relative keys and values shared by
 // the heads), :261-306 (FFN); model/wav2vec2_btse/modules.py:27-39 (LayerNorm over channels).
 //
-// The encoder is 40 752 parameters on a few hundred tokens: one WORKGROUP PER UTTERANCE runs all of it (embedding -> n_layers x
-// {QKV, relative-position attention, out-projection + residual + LayerNorm, FFN + residual + LayerNorm} -> scoring conv at the last
-// position) in ONE launch forward and ONE launch backward, fp32 throughout, and the work is laid out so that nothing waits on a chain of
-// dependent memory round trips:
-//   * every product with a 32- / 128-wide weight matrix is THREAD-PER-ROW: a thread holds its token's row in registers, the output
-//     channel is a uniform loop index, so the weights arrive through scalar loads and enter the FMAs as scalar operands; LayerNorm and
-//     the residual adds are in-thread, all L rows run in parallel and a whole layer needs three barriers;
-//   * the attention is THREAD-PER-(row, head): K and V of the layer sit in LDS and every lane reads the SAME key row (a broadcast), two
-//     passes over the keys (maximum; exponentials + P V), the relative-position skew (scores[i][j] += q_i . emb_rel_k[j - i + 4],
-//     out[i] += p[i][j] emb_rel_v[j - i + 4] for |j - i| <= 4: what the reference's pad / reshape tricks at transformer.py:189-243
-//     compute) as a band test — not one cross-lane operation;
+// The encoder is 40 752 parameters on a few hundred tokens (embedding -> n_layers x {QKV, relative-position attention, out-projection +
+// residual + LayerNorm, FFN + residual + LayerNorm} -> scoring conv at the last position), fp32 throughout, laid out so that nothing waits on
+// a chain of dependent memory round trips:
+//   * every product with a 32- / 128-wide weight matrix is THREAD-PER-ROW (one workgroup per utterance): a thread holds its token's row in
+//     registers, the output channel is a uniform loop index, so the weights arrive through scalar loads and enter the FMAs as scalar
+//     operands; LayerNorm and the residual adds are in-thread, all L rows run in parallel;
+//   * the attention is one workgroup per (utterance, HEAD), thread per row: the head's K and V slices sit in LDS and every lane reads the
+//     SAME key row (a broadcast), two passes over the keys (maximum; exponentials + P V), the relative-position skew (scores[i][j] +=
+//     q_i . emb_rel_k[j - i + 4], out[i] += p[i][j] emb_rel_v[j - i + 4] for |j - i| <= 4: what the reference's pad / reshape tricks at
+//     transformer.py:189-243 compute) as a band test — not one cross-lane operation;
 //   * the backward recomputes the probabilities from the saved row log-sum-exp, per query row (dq, delta, the band of dS / P the
 //     relative-embedding gradients need) and per key row (dk, dv, with Q and dA in LDS); parameter gradients are reductions over the
 //     rows: 64-row chunks of both operands staged in LDS, a thread owns 4 - 16 outputs in registers; they leave as one slab row per
 //     utterance and the host sums the rows in index order.
-// Round 5 first built the row loops as one-channel-per-thread with the activations re-read from the scratch row inside every loop trip:
-// 1.80 ms forward / 4.06 ms backward at 64 x 199 tokens, all of it memory latency; this form: see profiles/r5_btse_bio_probe.txt.
+// History (profiles/r5_btse_bio_probe*.txt, batch 128 x 199 tokens, forward / backward): one-channel-per-thread row loops re-reading the
+// scratch row in every trip 1.80 / 4.06 ms (at batch 64); thread-per-row with scalar weights, one workgroup per utterance for the whole encoder
+// 1.00 / 2.05 ms (half the CUs idle, one wave per SIMD on the rest, 796 (row, head) items behind 256 threads); 512 threads per utterance
+// 0.74 / 1.71 ms; the attention as its own launch per layer with a workgroup per (utterance, head) 0.59 / 1.20 ms (2 n_layers + 1 launches
+// forward, 3 n_layers + 1 backward; 512 tokens: 3.9 / 8.0 -> 1.46 / 3.43 ms).  What is left is the row launches: ~1500 scalar weight loads
+// per row phase behind a single wave per SIMD.
 // The activations the backward needs go to a per-utterance scratch row in HBM (L2-resident: 392 L floats per layer).
 // model.py:236 reads the LAST padded position times its mask: an utterance shorter than L scores exactly zero and contributes no
 // gradient — the backward writes a zero row for it and returns.
 #include "common.h"
 
 namespace {
-constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, MAXL = 512, RC = 64;
+constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, NG = NT / 32, NTA = 256, MAXL = 512, RC = 64;
 constexpr float QSCALE = 0.35355339059327373f;      // 1 / sqrt(k_channels = 8), transformer.py:155
 constexpr float EMB_SCALE = 5.656854249492381f;     // sqrt(bio_dim = 32), model.py:228
 constexpr float FILL = -1e4f, EPS = 1e-5f;          // transformer.py:168, modules.py:28
@@ -128,74 +131,32 @@ __device__ __forceinline__ float dot8_lds(const float* __restrict__ a, const flo
 // whole FFN + LayerNorm: a row's 12 k multiply-adds run out of registers against scalar-loaded weights, all L rows in parallel, no
 // barrier inside) and thread-per-(row, head) for the attention (K / V in LDS, every lane reads the SAME key row: a broadcast; two passes
 // over the keys — maximum, then exponentials + P V — and not one cross-lane operation).
-__global__ __launch_bounds__(NT) void btse_bio_fwd_kernel(const SclBtseBio p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float Eks[NR * BK], Evs[NR * BK];
+//
+// Launch structure (round 5, third form).  One workgroup per utterance for the WHOLE encoder left 128 of 256 CUs idle at batch 128 and
+// one or two waves per SIMD on the others, with 796 (row, head) attention items queueing behind 256 - 512 threads: 0.74 - 1.0 ms forward,
+// 1.7 - 2.0 ms backward, three quarters of it the attention loops.  The attention is now its own launch per layer with one workgroup
+// per (utterance, HEAD): 4 x the workgroups, the head's K / V slices (16 L floats each) in LDS, every lane on the same key row.  The
+// row phases between two attentions (the rest of layer l - 1, then Q / K / V of layer l out of the same registers) are one launch per
+// utterance as before.  n_layers + 1 row launches and n_layers attention launches forward; the activations were in the per-utterance
+// scratch row already, so the split adds no traffic.
+
+// rows kernel `l` (0 .. n_layers): [embedding | the post-attention half of layer l - 1] -> x;  [Q, K, V of layer l | the read-out]
+__global__ __launch_bounds__(NT) void btse_rows_fwd_kernel(const SclBtseBio p, const int l) {
     const int b = blockIdx.x, t = threadIdx.x, L = p.L;
     const int len = min(max(p.lens[b], 0), L);            // commons.sequence_mask: arange(L) < length
     float* ws = p.ws + (int64_t)b * p.ws_stride;
     const int32_t* tok = p.bio + (int64_t)b * L;
-    float* Ks = lds;
-    float* Vs = lds + L * BD;
-    for (int r = t; r < L; r += NT) {                     // model.py:228,232 + transformer.py:42
-        const int tk = min(max(tok[r], 0), p.n_bios - 1);
+    float* cur = ws + (int64_t)l * O_LAYER * L;           // layer l's block: its input rows first
+    for (int r = t; r < L; r += NT) {
         float x[BD];
-        load_row32(p.emb + tk * BD, x);
+        if (l == 0) {                                     // model.py:228,232 + transformer.py:42
+            const int tk = min(max(tok[r], 0), p.n_bios - 1);
+            load_row32(p.emb + tk * BD, x);
 #pragma unroll
-        for (int c = 0; c < BD; ++c) x[c] = r < len ? x[c] * EMB_SCALE : 0.f;
-        store_row32(ws + r * BD, x);
-    }
-    for (int l = 0; l < p.n_layers; ++l) {
-        float* base = ws + (int64_t)l * O_LAYER * L;
-        const float* const* W = p.lw[l];
-        if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
-        for (int r = t; r < L; r += NT) {                 // q, k, v = conv_{q,k,v}(x)   (transformer.py:139-141); a thread re-reads only rows it wrote
-            float x[BD], y[BD];
-            load_row32(base + r * BD, x);
-            matvec32(x, as_const(W[I_WQ]), as_const(W[I_BQ]), y); store_row32(base + O_Q * L + r * BD, y);
-            matvec32(x, as_const(W[I_WK]), as_const(W[I_BK]), y); store_row32(base + O_K * L + r * BD, y); store_row32(Ks + r * BD, y);
-            matvec32(x, as_const(W[I_WV]), as_const(W[I_BV]), y); store_row32(base + O_V * L + r * BD, y); store_row32(Vs + r * BD, y);
-        }
-        __syncthreads();
-        for (int it = t; it < BH * L; it += NT) {          // transformer.py:148-186
-            const int i = it >> 2, h = it & 3;
-            const bool mi = i < len;
-            float qs[BK];
-            {
-                const float4 q0 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[0], q1 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[1];
-                qs[0] = q0.x * QSCALE; qs[1] = q0.y * QSCALE; qs[2] = q0.z * QSCALE; qs[3] = q0.w * QSCALE;
-                qs[4] = q1.x * QSCALE; qs[5] = q1.y * QSCALE; qs[6] = q1.z * QSCALE; qs[7] = q1.w * QSCALE;
-            }
-            float mx = -INFINITY;
-            for (int j = 0; j < L; ++j) {
-                const float s = (mi && j < len) ? score(qs, Ks + j * BD + h * BK, Eks, j - i) : FILL;
-                mx = fmaxf(mx, s);
-            }
-            float sum = 0.f, o[BK];
-#pragma unroll
-            for (int d = 0; d < BK; ++d) o[d] = 0.f;
-            for (int j = 0; j < L; ++j) {
-                const int dj = j - i;
-                const float s = (mi && j < len) ? score(qs, Ks + j * BD + h * BK, Eks, dj) : FILL;
-                const float e = __expf(s - mx);
-                sum += e;
-                const float4 v0 = ((const float4*)(Vs + j * BD + h * BK))[0], v1 = ((const float4*)(Vs + j * BD + h * BK))[1];
-                o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
-                o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
-                if ((unsigned)(dj + BW) <= 2u * BW) {
-                    const float* ev = Evs + (dj + BW) * BK;
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) o[d] = fmaf(e, ev[d], o[d]);
-                }
-            }
-            const float inv = 1.f / sum;
-            float4* ao = (float4*)(base + O_A * L + i * BD + h * BK);
-            ao[0] = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-            ao[1] = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
-            base[O_LSE * L + h * L + i] = mx + logf(sum);
-        }
-        __syncthreads();
-        for (int r = t; r < L; r += NT) {                 // the rest of the layer, one row per thread
+            for (int c = 0; c < BD; ++c) x[c] = r < len ? x[c] * EMB_SCALE : 0.f;
+        } else {                                          // the rest of layer l - 1, one row per thread
+            float* base = ws + (int64_t)(l - 1) * O_LAYER * L;
+            const float* const* W = p.lw[l - 1];
             const bool valid = r < len;
             float a[BD], x1[BD], s[BD];
             load_row32(base + O_A * L + r * BD, a);
@@ -232,25 +193,91 @@ __global__ __launch_bounds__(NT) void btse_bio_fwd_kernel(const SclBtseBio p) {
             }
 #pragma unroll
             for (int c = 0; c < BD; ++c) s[c] = x1[c] + y[c];      // y is already zero on padded rows (... * x_mask, transformer.py:291)
-            layernorm32(s, as_const(W[I_G2]), as_const(W[I_B2]), y, mean, rs);
+            layernorm32(s, as_const(W[I_G2]), as_const(W[I_B2]), x, mean, rs);
             store_row32(base + O_S2 * L + r * BD, s);
-            store_row32(base + (int64_t)O_LAYER * L + r * BD, y);
             base[O_ST * L + r * 4 + 2] = mean; base[O_ST * L + r * 4 + 3] = rs;
+            if (l == p.n_layers && r >= len) {              // transformer.py:51: the encoder output is masked
+#pragma unroll
+                for (int c = 0; c < BD; ++c) x[c] = 0.f;
+            }
         }
-        __syncthreads();      // LDS (K / V, the relative embeddings) is rewritten by the next layer
+        store_row32(cur + r * BD, x);
+        if (l < p.n_layers) {                             // q, k, v = conv_{q,k,v}(x)   (transformer.py:139-141)
+            const float* const* W = p.lw[l];
+            float y[BD];
+            matvec32(x, as_const(W[I_WQ]), as_const(W[I_BQ]), y); store_row32(cur + O_Q * L + r * BD, y);
+            matvec32(x, as_const(W[I_WK]), as_const(W[I_BK]), y); store_row32(cur + O_K * L + r * BD, y);
+            matvec32(x, as_const(W[I_WV]), as_const(W[I_BV]), y); store_row32(cur + O_V * L + r * BD, y);
+        }
     }
-    float* xfin = ws + (int64_t)p.n_layers * O_LAYER * L;
-    for (int idx = len * BD + t; idx < L * BD; idx += NT) xfin[idx] = 0.f;          // transformer.py:51
-    __syncthreads();
+    if (l < p.n_layers) return;
+    __syncthreads();                                                                  // row L - 1 was written by a thread of this block
     const bool mlast = L - 1 < len;                                                   // model.py:234-236
     for (int o = t; o < p.bio_out; o += NT) {
         float y = 0.f;
         if (mlast) {
             y = p.bs[o];
 #pragma unroll 8
-            for (int k = 0; k < BD; ++k) y = fmaf(xfin[(L - 1) * BD + k], p.Ws[o * BD + k], y);
+            for (int k = 0; k < BD; ++k) y = fmaf(cur[(L - 1) * BD + k], p.Ws[o * BD + k], y);
         }
         p.out[(int64_t)b * p.out_ld + o] = y;
+    }
+}
+
+// attention of layer l, head blockIdx.y of utterance blockIdx.x: thread per query row   (transformer.py:148-186)
+__global__ __launch_bounds__(NTA) void btse_attn_fwd_kernel(const SclBtseBio p, const int l) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float Eks[NR * BK], Evs[NR * BK];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x, L = p.L;
+    const int len = min(max(p.lens[b], 0), L);
+    float* base = p.ws + (int64_t)b * p.ws_stride + (int64_t)l * O_LAYER * L;
+    const float* const* W = p.lw[l];
+    float* Kh = lds;                 // [L][8]
+    float* Vh = lds + L * BK;
+    if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
+    for (int idx = t; idx < 2 * L; idx += NTA) {
+        const int j = idx >> 1, half = idx & 1;
+        ((float4*)(Kh + j * BK))[half] = ((const float4*)(base + O_K * L + j * BD + h * BK))[half];
+        ((float4*)(Vh + j * BK))[half] = ((const float4*)(base + O_V * L + j * BD + h * BK))[half];
+    }
+    __syncthreads();
+    for (int i = t; i < L; i += NTA) {
+        const bool mi = i < len;
+        float qs[BK];
+        {
+            const float4 q0 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[0], q1 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[1];
+            qs[0] = q0.x * QSCALE; qs[1] = q0.y * QSCALE; qs[2] = q0.z * QSCALE; qs[3] = q0.w * QSCALE;
+            qs[4] = q1.x * QSCALE; qs[5] = q1.y * QSCALE; qs[6] = q1.z * QSCALE; qs[7] = q1.w * QSCALE;
+        }
+        float mx = -INFINITY;
+#pragma unroll 4
+        for (int j = 0; j < L; ++j) {
+            const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, j - i) : FILL;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f, o[BK];
+#pragma unroll
+        for (int d = 0; d < BK; ++d) o[d] = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < L; ++j) {
+            const int dj = j - i;
+            const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, dj) : FILL;
+            const float e = __expf(s - mx);
+            sum += e;
+            const float4 v0 = ((const float4*)(Vh + j * BK))[0], v1 = ((const float4*)(Vh + j * BK))[1];
+            o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
+            o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
+            if ((unsigned)(dj + BW) <= 2u * BW) {
+                const float* ev = Evs + (dj + BW) * BK;
+#pragma unroll
+                for (int d = 0; d < BK; ++d) o[d] = fmaf(e, ev[d], o[d]);
+            }
+        }
+        const float inv = 1.f / sum;
+        float4* ao = (float4*)(base + O_A * L + i * BD + h * BK);
+        ao[0] = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        ao[1] = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+        base[O_LSE * L + h * L + i] = mx + logf(sum);
     }
 }
 
@@ -285,47 +312,52 @@ __device__ __forceinline__ void wgrad_rows(const float* __restrict__ dy, const f
     if (db && t < C) db[t] = accb;
 }
 
-// dgamma[c] = sum_r dy[r][c] xhat[r][c], dbeta[c] = sum_r dy[r][c] over this utterance's rows (8 row groups x 32 channels, combined in order)
+// dgamma[c] = sum_r dy[r][c] xhat[r][c], dbeta[c] = sum_r dy[r][c] over this utterance's rows (NT / 32 row groups x 32 channels, combined in order)
 __device__ __forceinline__ void ln_param_grads(const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ st, int so, int L,
                                                float* __restrict__ dg, float* __restrict__ dbeta, float* red, int t) {
     const int c = t & 31, rg = t >> 5;
     float a = 0.f, bsum = 0.f;
-    for (int r = rg; r < L; r += 8) {
+    for (int r = rg; r < L; r += NG) {
         const float d = dy[r * BD + c];
         a = fmaf(d, (pre[r * BD + c] - st[r * 4 + so]) * st[r * 4 + so + 1], a);
         bsum += d;
     }
     __syncthreads();
-    red[rg * BD + c] = a; red[8 * BD + rg * BD + c] = bsum;
+    red[rg * BD + c] = a; red[NG * BD + rg * BD + c] = bsum;
     __syncthreads();
     if (t < 2 * BD) {
         float s = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) s += red[(t >> 5) * 8 * BD + g * BD + (t & 31)];
+        for (int g = 0; g < NG; ++g) s += red[(t >> 5) * NG * BD + g * BD + (t & 31)];
         (t < BD ? dg : dbeta)[t & 31] = s;
     }
 }
 
-__global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
+// Backward launch structure (the mirror of the forward's): per layer, top down,
+//   rows kernel  : [the scoring conv's gradient | steps (4) + (6) of the layer above: relative-embedding and Q / K / V parameter gradients, input
+//                  gradient]  then steps (0) - (2) of this layer: LayerNorm / FFN / out-projection data gradients, one row per thread, and their
+//                  parameter gradients;
+//   attention (3): workgroup per (utterance, head), thread per QUERY row -> dq, delta, the band of dS / P the relative embeddings need;
+//   attention (5): workgroup per (utterance, head), thread per KEY row   -> dk, dv;
+// and a last rows kernel for (4) + (6) of layer 0 and the embedding gradient.  2 n_layers attention + n_layers + 1 row launches.
+__global__ __launch_bounds__(NT) void btse_rows_bwd_kernel(const SclBtseBio p, const int l6, const int l012) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float Eks[NR * BK], Evs[NR * BK], red[16 * BD], epart[2][3][NR * BK];
+    __shared__ float red[2 * NG * BD], epart[2][3][NR * BK];
     const int b = blockIdx.x, t = threadIdx.x, L = p.L;
     const int len = min(max(p.lens[b], 0), L);
     float* slab = p.slab + (int64_t)b * p.slab_ld;
     if (len < L) {      // the read-out position is padding: zero score, zero gradient (model.py:234-236)
-        for (int64_t idx = t; idx < p.slab_ld; idx += NT) slab[idx] = 0.f;
+        if (l6 < 0)
+            for (int64_t idx = t; idx < p.slab_ld; idx += NT) slab[idx] = 0.f;
         return;
     }
     float* ws = p.ws + (int64_t)b * p.ws_stride;
     const int32_t* tok = p.bio + (int64_t)b * L;
-    const float* dsc = p.d_out + (int64_t)b * p.dout_ld;
-    float* A0 = lds;                 // K, then Q * scale     [L][32]
-    float* A1 = lds + L * BD;        // V, then dA            [L][32]
-    float* lseS = lds + 2 * L * BD;  // [4][L]
-    float* delS = lseS + BH * L;     // [4][L]
     float* G = ws + ((int64_t)p.n_layers * O_LAYER + BD) * L;
     float* gdx = G + G_DX * L;
-    {   // scoring conv at the last position
+    const float* gda = G + G_DA * L;
+    if (l6 < 0) {   // scoring conv at the last position
+        const float* dsc = p.d_out + (int64_t)b * p.dout_ld;
         const float* xfin = ws + (int64_t)p.n_layers * O_LAYER * L + (L - 1) * BD;
         for (int o = t; o < p.bio_out; o += NT) slab[p.go_bs + o] = dsc[o];
         for (int idx = t; idx < p.bio_out * BD; idx += NT) slab[p.go_Ws + idx] = dsc[idx >> 5] * xfin[idx & 31];
@@ -335,14 +367,52 @@ __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
             for (int o = 0; o < p.bio_out; ++o) a = fmaf(dsc[o], p.Ws[o * BD + t], a);
             gdx[(L - 1) * BD + t] = a;
         }
+        __syncthreads();
+    } else {
+        float* base = ws + (int64_t)l6 * O_LAYER * L;
+        const float* const* W = p.lw[l6];
+        const int32_t* go = p.go[l6];
+        // (4) relative-embedding gradients: d emb_rel_k[r][d] = sum_(i,h) dS[i][i + r - 4] qs_i[d], d emb_rel_v[r][d] = sum P[i][i + r - 4] dA_i[d];
+        //     144 outputs x 3 row ranges, combined in order
+        for (int wi = t; wi < 3 * 2 * NR * BK; wi += NT) {
+            const int part = wi / (2 * NR * BK), e = wi % (2 * NR * BK), which = e / (NR * BK), rd = e % (NR * BK), r = rd >> 3, d = rd & 7;
+            const int i0 = (L * part) / 3, i1 = (L * (part + 1)) / 3;
+            const float* bsrc = G + (which ? G_BP : G_BS) * L;
+            const float* vsrc = which ? gda : base + O_Q * L;
+            const float sc = which ? 1.f : QSCALE;
+            float a = 0.f;
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int h = 0; h < BH; ++h) a = fmaf(bsrc[(i * BH + h) * NR + r], vsrc[i * BD + h * BK + d] * sc, a);
+            epart[which][part][rd] = a;
+        }
+        __syncthreads();
+        if (t < 2 * NR * BK) {
+            const int which = t / (NR * BK), rd = t % (NR * BK);
+            slab[go[which ? I_EV : I_EK] + rd] = (epart[which][0][rd] + epart[which][1][rd]) + epart[which][2][rd];
+        }
+        // (6) conv_q / conv_k / conv_v: parameter gradients; input gradient
+        const float* xin = base;
+        const float* ds1 = G + G_DS1 * L;
+        wgrad_rows<BD, BD>(G + G_Q * L, xin, L, slab + go[I_WQ], slab + go[I_BQ], lds, t);
+        wgrad_rows<BD, BD>(G + G_K * L, xin, L, slab + go[I_WK], slab + go[I_BK], lds, t);
+        wgrad_rows<BD, BD>(G + G_V * L, xin, L, slab + go[I_WV], slab + go[I_BV], lds, t);
+        __syncthreads();
+        for (int r = t; r < L; r += NT) {
+            float d[BD], y[BD];
+            load_row32(ds1 + r * BD, y);                       // the residual branch
+            load_row32(G + G_Q * L + r * BD, d); matvec32_t(d, as_const(W[I_WQ]), y);
+            load_row32(G + G_K * L + r * BD, d); matvec32_t(d, as_const(W[I_WK]), y);
+            load_row32(G + G_V * L + r * BD, d); matvec32_t(d, as_const(W[I_WV]), y);
+            store_row32(gdx + r * BD, y);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int l = p.n_layers - 1; l >= 0; --l) {
-        float* base = ws + (int64_t)l * O_LAYER * L;
-        const float* const* W = p.lw[l];
-        const int32_t* go = p.go[l];
+    if (l012 >= 0) {
+        float* base = ws + (int64_t)l012 * O_LAYER * L;
+        const float* const* W = p.lw[l012];
+        const int32_t* go = p.go[l012];
         const float* st = base + O_ST * L;
-        if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
         // (0) LayerNorm 2's parameter gradients need d x_out itself: before (1) re-uses the buffer
         ln_param_grads(gdx, base + O_S2 * L, st, 2, L, slab + go[I_G2], slab + go[I_B2], red, t);
         __syncthreads();
@@ -390,103 +460,7 @@ __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
         wgrad_rows<BF, BD>(G + G_DH * L, base + O_X1 * L, L, slab + go[I_W1], slab + go[I_C1], lds, t);
         wgrad_rows<BD, BD>(ds1, base + O_A * L, L, slab + go[I_WO], slab + go[I_BO], lds, t);
         ln_param_grads(gdx, base + O_S1 * L, st, 0, L, slab + go[I_G1], slab + go[I_B1], red, t);
-        __syncthreads();
-        // (3) attention, pass 1: thread per (query row, head) -> dq, delta, the band of dS / P for the relative-embedding gradients
-        for (int idx = t; idx < L * BD / 4; idx += NT) { ((float4*)A0)[idx] = ((const float4*)(base + O_K * L))[idx]; ((float4*)A1)[idx] = ((const float4*)(base + O_V * L))[idx]; }
-        __syncthreads();
-        const float* gda = G + G_DA * L;
-        for (int it = t; it < BH * L; it += NT) {
-            const int i = it >> 2, h = it & 3;
-            float qs[BK], da[BK], dq[BK];
-#pragma unroll
-            for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE; da[d] = gda[i * BD + h * BK + d]; dq[d] = 0.f; }
-            const float lse = base[O_LSE * L + h * L + i];
-            float delta = 0.f;
-            for (int j = 0; j < L; ++j) {
-                const int dj = j - i;
-                const float pij = __expf(score(qs, A0 + j * BD + h * BK, Eks, dj) - lse);
-                delta = fmaf(pij, score(da, A1 + j * BD + h * BK, Evs, dj), delta);
-            }
-            float* bS = G + G_BS * L + (i * BH + h) * NR;
-            float* bP = G + G_BP * L + (i * BH + h) * NR;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) { bS[r] = 0.f; bP[r] = 0.f; }
-            for (int j = 0; j < L; ++j) {
-                const int dj = j - i;
-                const float* kr = A0 + j * BD + h * BK;
-                const float pij = __expf(score(qs, kr, Eks, dj) - lse);
-                const float dS = pij * (score(da, A1 + j * BD + h * BK, Evs, dj) - delta);
-#pragma unroll
-                for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
-                if ((unsigned)(dj + BW) <= 2u * BW) {
-                    const float* ek = Eks + (dj + BW) * BK;
-#pragma unroll
-                    for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
-                    bS[dj + BW] = dS; bP[dj + BW] = pij;
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < BK; ++d) G[G_Q * L + i * BD + h * BK + d] = dq[d] * QSCALE;
-            lseS[h * L + i] = lse; delS[h * L + i] = delta;
-        }
-        __syncthreads();
-        // (4) relative-embedding gradients: d emb_rel_k[r][d] = sum_(i,h) dS[i][i + r - 4] qs_i[d], d emb_rel_v[r][d] = sum P[i][i + r - 4] dA_i[d];
-        //     144 outputs x 3 row ranges, combined in order;  then Q * scale and dA replace K and V in LDS for pass 2
-        for (int wi = t; wi < 3 * 2 * NR * BK; wi += NT) {
-            const int part = wi / (2 * NR * BK), e = wi % (2 * NR * BK), which = e / (NR * BK), rd = e % (NR * BK), r = rd >> 3, d = rd & 7;
-            const int i0 = (L * part) / 3, i1 = (L * (part + 1)) / 3;
-            const float* bsrc = G + (which ? G_BP : G_BS) * L;
-            const float* vsrc = which ? gda : base + O_Q * L;
-            const float sc = which ? 1.f : QSCALE;
-            float a = 0.f;
-            for (int i = i0; i < i1; ++i)
-#pragma unroll
-                for (int h = 0; h < BH; ++h) a = fmaf(bsrc[(i * BH + h) * NR + r], vsrc[i * BD + h * BK + d] * sc, a);
-            epart[which][part][rd] = a;
-        }
-        for (int idx = t; idx < L * BD; idx += NT) { A0[idx] = base[O_Q * L + idx] * QSCALE; A1[idx] = gda[idx]; }
-        __syncthreads();
-        if (t < 2 * NR * BK) {
-            const int which = t / (NR * BK), rd = t % (NR * BK);
-            slab[go[which ? I_EV : I_EK] + rd] = (epart[which][0][rd] + epart[which][1][rd]) + epart[which][2][rd];
-        }
-        // (5) attention, pass 2: thread per (key row, head) -> dk, dv
-        for (int it = t; it < BH * L; it += NT) {
-            const int j = it >> 2, h = it & 3;
-            float kj[BK], vj[BK], dk[BK], dv[BK];
-#pragma unroll
-            for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + j * BD + h * BK + d]; vj[d] = base[O_V * L + j * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
-            for (int i = 0; i < L; ++i) {
-                const int dj = j - i;
-                const float* qr = A0 + i * BD + h * BK;
-                const float* ar = A1 + i * BD + h * BK;
-                const bool band = (unsigned)(dj + BW) <= 2u * BW;
-                const float sij = dot8(qr, kj) + (band ? dot8_lds(qr, Eks + (dj + BW) * BK) : 0.f);      // q_i . (k_j + emb_rel_k[j - i + 4])
-                const float g = dot8(ar, vj) + (band ? dot8_lds(ar, Evs + (dj + BW) * BK) : 0.f);         // dA_i . (v_j + emb_rel_v[j - i + 4])
-                const float pij = __expf(sij - lseS[h * L + i]);
-                const float dS = pij * (g - delS[h * L + i]);
-#pragma unroll
-                for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
-            }
-#pragma unroll
-            for (int d = 0; d < BK; ++d) { G[G_K * L + j * BD + h * BK + d] = dk[d]; G[G_V * L + j * BD + h * BK + d] = dv[d]; }
-        }
-        __syncthreads();
-        // (6) conv_q / conv_k / conv_v: parameter gradients, LayerNorm 2's parameter gradients of the layer BELOW are due there; input gradient
-        const float* xin = base;
-        wgrad_rows<BD, BD>(G + G_Q * L, xin, L, slab + go[I_WQ], slab + go[I_BQ], lds, t);
-        wgrad_rows<BD, BD>(G + G_K * L, xin, L, slab + go[I_WK], slab + go[I_BK], lds, t);
-        wgrad_rows<BD, BD>(G + G_V * L, xin, L, slab + go[I_WV], slab + go[I_BV], lds, t);
-        __syncthreads();
-        for (int r = t; r < L; r += NT) {
-            float d[BD], y[BD];
-            load_row32(ds1 + r * BD, y);                       // the residual branch
-            load_row32(G + G_Q * L + r * BD, d); matvec32_t(d, as_const(W[I_WQ]), y);
-            load_row32(G + G_K * L + r * BD, d); matvec32_t(d, as_const(W[I_WK]), y);
-            load_row32(G + G_V * L + r * BD, d); matvec32_t(d, as_const(W[I_WV]), y);
-            store_row32(gdx + r * BD, y);
-        }
-        __syncthreads();
+        return;
     }
     for (int idx = t; idx < p.n_bios * BD; idx += NT) {      // embedding rows (model.py:228)
         const int tk = idx >> 5, cc = idx & 31;
@@ -494,6 +468,109 @@ __global__ __launch_bounds__(NT) void btse_bio_bwd_kernel(const SclBtseBio p) {
         for (int r = 0; r < L; ++r)
             if (min(max(tok[r], 0), p.n_bios - 1) == tk) a += gdx[r * BD + cc];
         slab[p.go_emb + idx] = a * EMB_SCALE;
+    }
+}
+
+// (3) attention backward, pass 1 of layer l: head blockIdx.y of utterance blockIdx.x, thread per QUERY row -> dq, delta, the band of dS / P
+__global__ __launch_bounds__(NTA) void btse_attn_bwd_q_kernel(const SclBtseBio p, const int l) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float Eks[NR * BK], Evs[NR * BK];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x, L = p.L;
+    if (min(max(p.lens[b], 0), L) < L) return;
+    float* ws = p.ws + (int64_t)b * p.ws_stride;
+    float* base = ws + (int64_t)l * O_LAYER * L;
+    const float* const* W = p.lw[l];
+    float* G = ws + ((int64_t)p.n_layers * O_LAYER + BD) * L;
+    const float* gda = G + G_DA * L;
+    float* Kh = lds;                 // [L][8]
+    float* Vh = lds + L * BK;
+    if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
+    for (int idx = t; idx < 2 * L; idx += NTA) {
+        const int j = idx >> 1, half = idx & 1;
+        ((float4*)(Kh + j * BK))[half] = ((const float4*)(base + O_K * L + j * BD + h * BK))[half];
+        ((float4*)(Vh + j * BK))[half] = ((const float4*)(base + O_V * L + j * BD + h * BK))[half];
+    }
+    __syncthreads();
+    for (int i = t; i < L; i += NTA) {
+        float qs[BK], da[BK], dq[BK];
+#pragma unroll
+        for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE; da[d] = gda[i * BD + h * BK + d]; dq[d] = 0.f; }
+        const float lse = base[O_LSE * L + h * L + i];
+        float delta = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < L; ++j) {
+            const int dj = j - i;
+            const float pij = __expf(score(qs, Kh + j * BK, Eks, dj) - lse);
+            delta = fmaf(pij, score(da, Vh + j * BK, Evs, dj), delta);
+        }
+        float* bS = G + G_BS * L + (i * BH + h) * NR;
+        float* bP = G + G_BP * L + (i * BH + h) * NR;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { bS[r] = 0.f; bP[r] = 0.f; }
+#pragma unroll 4
+        for (int j = 0; j < L; ++j) {
+            const int dj = j - i;
+            const float* kr = Kh + j * BK;
+            const float pij = __expf(score(qs, kr, Eks, dj) - lse);
+            const float dS = pij * (score(da, Vh + j * BK, Evs, dj) - delta);
+#pragma unroll
+            for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
+            if ((unsigned)(dj + BW) <= 2u * BW) {
+                const float* ek = Eks + (dj + BW) * BK;
+#pragma unroll
+                for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
+                bS[dj + BW] = dS; bP[dj + BW] = pij;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < BK; ++d) G[G_Q * L + i * BD + h * BK + d] = dq[d] * QSCALE;
+        G[G_DELTA * L + h * L + i] = delta;
+    }
+}
+
+// (5) attention backward, pass 2: thread per KEY row -> dk, dv (the head's Q * scale, dA, log-sum-exp and delta rows in LDS)
+__global__ __launch_bounds__(NTA) void btse_attn_bwd_kv_kernel(const SclBtseBio p, const int l) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float Eks[NR * BK], Evs[NR * BK];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x, L = p.L;
+    if (min(max(p.lens[b], 0), L) < L) return;
+    float* ws = p.ws + (int64_t)b * p.ws_stride;
+    float* base = ws + (int64_t)l * O_LAYER * L;
+    const float* const* W = p.lw[l];
+    float* G = ws + ((int64_t)p.n_layers * O_LAYER + BD) * L;
+    const float* gda = G + G_DA * L;
+    float* Qh = lds;                 // [L][8], scaled
+    float* Ah = lds + L * BK;        // [L][8]
+    float* lseS = lds + 2 * L * BK;  // [L]
+    float* delS = lseS + L;          // [L]
+    if (t < NR * BK) { Eks[t] = W[I_EK][t]; Evs[t] = W[I_EV][t]; }
+    for (int idx = t; idx < 2 * L; idx += NTA) {
+        const int i = idx >> 1, half = idx & 1;
+        const float4 q = ((const float4*)(base + O_Q * L + i * BD + h * BK))[half];
+        ((float4*)(Qh + i * BK))[half] = make_float4(q.x * QSCALE, q.y * QSCALE, q.z * QSCALE, q.w * QSCALE);
+        ((float4*)(Ah + i * BK))[half] = ((const float4*)(gda + i * BD + h * BK))[half];
+    }
+    for (int i = t; i < L; i += NTA) { lseS[i] = base[O_LSE * L + h * L + i]; delS[i] = G[G_DELTA * L + h * L + i]; }
+    __syncthreads();
+    for (int j = t; j < L; j += NTA) {
+        float kj[BK], vj[BK], dk[BK], dv[BK];
+#pragma unroll
+        for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + j * BD + h * BK + d]; vj[d] = base[O_V * L + j * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll 4
+        for (int i = 0; i < L; ++i) {
+            const int dj = j - i;
+            const float* qr = Qh + i * BK;
+            const float* ar = Ah + i * BK;
+            const bool band = (unsigned)(dj + BW) <= 2u * BW;
+            const float sij = dot8(qr, kj) + (band ? dot8_lds(qr, Eks + (dj + BW) * BK) : 0.f);      // q_i . (k_j + emb_rel_k[j - i + 4])
+            const float g = dot8(ar, vj) + (band ? dot8_lds(ar, Evs + (dj + BW) * BK) : 0.f);         // dA_i . (v_j + emb_rel_v[j - i + 4])
+            const float pij = __expf(sij - lseS[i]);
+            const float dS = pij * (g - delS[i]);
+#pragma unroll
+            for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
+        }
+#pragma unroll
+        for (int d = 0; d < BK; ++d) { G[G_K * L + j * BD + h * BK + d] = dk[d]; G[G_V * L + j * BD + h * BK + d] = dv[d]; }
     }
 }
 
@@ -569,19 +646,26 @@ extern "C" int64_t scl_btse_bio_ws_floats(int n_layers, int L) { return ((int64_
 extern "C" int scl_btse_bio_fwd(const SclBtseBio* p, void* stream) {
     const int rc = bio_check(p, "btse_bio_fwd", false);
     if (rc != SCL_OK) return rc;
-    const size_t lds = (size_t)2 * p->L * BD * sizeof(float);
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)btse_bio_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(btse_bio_fwd_kernel, dim3(p->B), dim3(NT), lds, (hipStream_t)stream, *p);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * p->L * BK * sizeof(float);      // one head's K and V slices
+    for (int l = 0; l <= p->n_layers; ++l) {
+        hipLaunchKernelGGL(btse_rows_fwd_kernel, dim3(p->B), dim3(NT), 0, s, *p, l);
+        if (l < p->n_layers) hipLaunchKernelGGL(btse_attn_fwd_kernel, dim3(p->B, BH), dim3(NTA), lds, s, *p, l);
+    }
     return scl_check_launch("scl_btse_bio_fwd");
 }
 extern "C" int scl_btse_bio_bwd(const SclBtseBio* p, void* stream) {
     const int rc = bio_check(p, "btse_bio_bwd", true);
     if (rc != SCL_OK) return rc;
-    size_t lds = (size_t)(2 * p->L * BD + 2 * BH * p->L) * sizeof(float);      // K / V (then Q / dA) + the rows' log-sum-exp and delta
+    hipStream_t s = (hipStream_t)stream;
     const size_t stage = (size_t)RC * (BD + BF) * sizeof(float);                 // the widest weight-gradient staging chunk
-    if (lds < stage) lds = stage;
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)btse_bio_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(btse_bio_bwd_kernel, dim3(p->B), dim3(NT), lds, (hipStream_t)stream, *p);
+    const size_t lds_q = (size_t)2 * p->L * BK * sizeof(float), lds_kv = (size_t)(2 * p->L * BK + 2 * p->L) * sizeof(float);
+    for (int l = p->n_layers - 1; l >= 0; --l) {
+        hipLaunchKernelGGL(btse_rows_bwd_kernel, dim3(p->B), dim3(NT), stage, s, *p, l + 1 < p->n_layers ? l + 1 : -1, l);
+        hipLaunchKernelGGL(btse_attn_bwd_q_kernel, dim3(p->B, BH), dim3(NTA), lds_q, s, *p, l);
+        hipLaunchKernelGGL(btse_attn_bwd_kv_kernel, dim3(p->B, BH), dim3(NTA), lds_kv, s, *p, l);
+    }
+    hipLaunchKernelGGL(btse_rows_bwd_kernel, dim3(p->B), dim3(NT), stage, s, *p, 0, -1);
     return scl_check_launch("scl_btse_bio_bwd");
 }
 extern "C" int scl_btse_join_fwd(const float* emb, const float* s, const float* W1, const float* b1, float* b, int B, int C, int bio_out, int is_add,
