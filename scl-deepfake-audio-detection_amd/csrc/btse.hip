@@ -29,7 +29,7 @@
 #include "common.h"
 
 namespace {
-constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, NG = NT / 32, NTA = 256, MAXL = 512, RC = 64;
+constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, NG = NT / 32, NTA = 256, KS = 4, RPB = NTA / KS, MAXL = 512, RC = 64;
 constexpr float QSCALE = 0.35355339059327373f;      // 1 / sqrt(k_channels = 8), transformer.py:155
 constexpr float EMB_SCALE = 5.656854249492381f;     // sqrt(bio_dim = 32), model.py:228
 constexpr float FILL = -1e4f, EPS = 1e-5f;          // transformer.py:168, modules.py:28
@@ -224,7 +224,14 @@ __global__ __launch_bounds__(NT) void btse_rows_fwd_kernel(const SclBtseBio p, c
     }
 }
 
-// attention of layer l, head blockIdx.y of utterance blockIdx.x: thread per query row   (transformer.py:148-186)
+// sum / max over the KS lanes of a row's group (adjacent lanes: two DPP-class shuffles)
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return v; }
+
+// attention of layer l, head blockIdx.y of utterance blockIdx.x, RPB rows per block (blockIdx.z): KS = 4 adjacent lanes share a query row, lane s
+// takes the keys j = s (mod 4) — the four lanes read four ADJACENT key rows of the head's LDS slice — and the row's maximum / sum / output
+// are combined with two shuffles each.  4 x the threads of a thread-per-row launch: eight waves per SIMD hide the LDS and exp latencies that a
+// 2 x 199-key loop behind two waves per SIMD exposed (95 -> see profiles/r5_btse_bio_probe_final.txt).   (transformer.py:148-186)
 __global__ __launch_bounds__(NTA) void btse_attn_fwd_kernel(const SclBtseBio p, const int l) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float Eks[NR * BK], Evs[NR * BK];
@@ -241,38 +248,44 @@ __global__ __launch_bounds__(NTA) void btse_attn_fwd_kernel(const SclBtseBio p, 
         ((float4*)(Vh + j * BK))[half] = ((const float4*)(base + O_V * L + j * BD + h * BK))[half];
     }
     __syncthreads();
-    for (int i = t; i < L; i += NTA) {
-        const bool mi = i < len;
-        float qs[BK];
-        {
-            const float4 q0 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[0], q1 = ((const float4*)(base + O_Q * L + i * BD + h * BK))[1];
-            qs[0] = q0.x * QSCALE; qs[1] = q0.y * QSCALE; qs[2] = q0.z * QSCALE; qs[3] = q0.w * QSCALE;
-            qs[4] = q1.x * QSCALE; qs[5] = q1.y * QSCALE; qs[6] = q1.z * QSCALE; qs[7] = q1.w * QSCALE;
-        }
-        float mx = -INFINITY;
-#pragma unroll 4
-        for (int j = 0; j < L; ++j) {
-            const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, j - i) : FILL;
-            mx = fmaxf(mx, s);
-        }
-        float sum = 0.f, o[BK];
+    const int i = blockIdx.z * RPB + (t >> 2), ks = t & 3;
+    const int ir = min(i, L - 1);                         // the lanes of rows past L run the loops on row L - 1 (shuffles need whole groups), store nothing
+    const bool mi = ir < len;
+    float qs[BK];
+    {
+        const float4 q0 = ((const float4*)(base + O_Q * L + ir * BD + h * BK))[0], q1 = ((const float4*)(base + O_Q * L + ir * BD + h * BK))[1];
+        qs[0] = q0.x * QSCALE; qs[1] = q0.y * QSCALE; qs[2] = q0.z * QSCALE; qs[3] = q0.w * QSCALE;
+        qs[4] = q1.x * QSCALE; qs[5] = q1.y * QSCALE; qs[6] = q1.z * QSCALE; qs[7] = q1.w * QSCALE;
+    }
+    float mx = -INFINITY;
+#pragma unroll 2
+    for (int j = ks; j < L; j += KS) {
+        const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, j - ir) : FILL;
+        mx = fmaxf(mx, s);
+    }
+    mx = quad_max(mx);
+    float sum = 0.f, o[BK];
 #pragma unroll
-        for (int d = 0; d < BK; ++d) o[d] = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < L; ++j) {
-            const int dj = j - i;
-            const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, dj) : FILL;
-            const float e = __expf(s - mx);
-            sum += e;
-            const float4 v0 = ((const float4*)(Vh + j * BK))[0], v1 = ((const float4*)(Vh + j * BK))[1];
-            o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
-            o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
-            if ((unsigned)(dj + BW) <= 2u * BW) {
-                const float* ev = Evs + (dj + BW) * BK;
+    for (int d = 0; d < BK; ++d) o[d] = 0.f;
+#pragma unroll 2
+    for (int j = ks; j < L; j += KS) {
+        const int dj = j - ir;
+        const float s = (mi && j < len) ? score(qs, Kh + j * BK, Eks, dj) : FILL;
+        const float e = __expf(s - mx);
+        sum += e;
+        const float4 v0 = ((const float4*)(Vh + j * BK))[0], v1 = ((const float4*)(Vh + j * BK))[1];
+        o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
+        o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
+        if ((unsigned)(dj + BW) <= 2u * BW) {
+            const float* ev = Evs + (dj + BW) * BK;
 #pragma unroll
-                for (int d = 0; d < BK; ++d) o[d] = fmaf(e, ev[d], o[d]);
-            }
+            for (int d = 0; d < BK; ++d) o[d] = fmaf(e, ev[d], o[d]);
         }
+    }
+    sum = quad_sum(sum);
+#pragma unroll
+    for (int d = 0; d < BK; ++d) o[d] = quad_sum(o[d]);
+    if (ks == 0 && i < L) {
         const float inv = 1.f / sum;
         float4* ao = (float4*)(base + O_A * L + i * BD + h * BK);
         ao[0] = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
@@ -471,7 +484,8 @@ __global__ __launch_bounds__(NT) void btse_rows_bwd_kernel(const SclBtseBio p, c
     }
 }
 
-// (3) attention backward, pass 1 of layer l: head blockIdx.y of utterance blockIdx.x, thread per QUERY row -> dq, delta, the band of dS / P
+// (3) attention backward, pass 1 of layer l: head blockIdx.y of utterance blockIdx.x, four lanes per QUERY row (keys j = s mod 4, as the forward)
+//     -> dq, delta, the band of dS / P
 __global__ __launch_bounds__(NTA) void btse_attn_bwd_q_kernel(const SclBtseBio p, const int l) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float Eks[NR * BK], Evs[NR * BK];
@@ -491,44 +505,55 @@ __global__ __launch_bounds__(NTA) void btse_attn_bwd_q_kernel(const SclBtseBio p
         ((float4*)(Vh + j * BK))[half] = ((const float4*)(base + O_V * L + j * BD + h * BK))[half];
     }
     __syncthreads();
-    for (int i = t; i < L; i += NTA) {
-        float qs[BK], da[BK], dq[BK];
+    const int i = blockIdx.z * RPB + (t >> 2), ks = t & 3;
+    const int ir = min(i, L - 1);
+    float qs[BK], da[BK], dq[BK];
 #pragma unroll
-        for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + i * BD + h * BK + d] * QSCALE; da[d] = gda[i * BD + h * BK + d]; dq[d] = 0.f; }
-        const float lse = base[O_LSE * L + h * L + i];
-        float delta = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < L; ++j) {
-            const int dj = j - i;
-            const float pij = __expf(score(qs, Kh + j * BK, Eks, dj) - lse);
-            delta = fmaf(pij, score(da, Vh + j * BK, Evs, dj), delta);
+    for (int d = 0; d < BK; ++d) { qs[d] = base[O_Q * L + ir * BD + h * BK + d] * QSCALE; da[d] = gda[ir * BD + h * BK + d]; dq[d] = 0.f; }
+    const float lse = base[O_LSE * L + h * L + ir];
+    float delta = 0.f;
+#pragma unroll 2
+    for (int j = ks; j < L; j += KS) {
+        const int dj = j - ir;
+        const float pij = __expf(score(qs, Kh + j * BK, Eks, dj) - lse);
+        delta = fmaf(pij, score(da, Vh + j * BK, Evs, dj), delta);
+    }
+    delta = quad_sum(delta);
+    float* bS = G + G_BS * L + (ir * BH + h) * NR;
+    float* bP = G + G_BP * L + (ir * BH + h) * NR;
+    if (i < L) {
+        // band entry r belongs to key j = i + r - 4 and is written by that key's lane; entries whose key lies outside the sequence are zero
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = i + r - BW;
+            if (((j & 3) == ks) && (j < 0 || j >= L)) { bS[r] = 0.f; bP[r] = 0.f; }
         }
-        float* bS = G + G_BS * L + (i * BH + h) * NR;
-        float* bP = G + G_BP * L + (i * BH + h) * NR;
+    }
+#pragma unroll 2
+    for (int j = ks; j < L; j += KS) {
+        const int dj = j - ir;
+        const float* kr = Kh + j * BK;
+        const float pij = __expf(score(qs, kr, Eks, dj) - lse);
+        const float dS = pij * (score(da, Vh + j * BK, Evs, dj) - delta);
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { bS[r] = 0.f; bP[r] = 0.f; }
-#pragma unroll 4
-        for (int j = 0; j < L; ++j) {
-            const int dj = j - i;
-            const float* kr = Kh + j * BK;
-            const float pij = __expf(score(qs, kr, Eks, dj) - lse);
-            const float dS = pij * (score(da, Vh + j * BK, Evs, dj) - delta);
+        for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
+        if ((unsigned)(dj + BW) <= 2u * BW) {
+            const float* ek = Eks + (dj + BW) * BK;
 #pragma unroll
-            for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, kr[d], dq[d]);
-            if ((unsigned)(dj + BW) <= 2u * BW) {
-                const float* ek = Eks + (dj + BW) * BK;
-#pragma unroll
-                for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
-                bS[dj + BW] = dS; bP[dj + BW] = pij;
-            }
+            for (int d = 0; d < BK; ++d) dq[d] = fmaf(dS, ek[d], dq[d]);
+            if (i < L) { bS[dj + BW] = dS; bP[dj + BW] = pij; }
         }
+    }
+#pragma unroll
+    for (int d = 0; d < BK; ++d) dq[d] = quad_sum(dq[d]);
+    if (ks == 0 && i < L) {
 #pragma unroll
         for (int d = 0; d < BK; ++d) G[G_Q * L + i * BD + h * BK + d] = dq[d] * QSCALE;
         G[G_DELTA * L + h * L + i] = delta;
     }
 }
 
-// (5) attention backward, pass 2: thread per KEY row -> dk, dv (the head's Q * scale, dA, log-sum-exp and delta rows in LDS)
+// (5) attention backward, pass 2: four lanes per KEY row (queries i = s mod 4) -> dk, dv (the head's Q * scale, dA, log-sum-exp and delta rows in LDS)
 __global__ __launch_bounds__(NTA) void btse_attn_bwd_kv_kernel(const SclBtseBio p, const int l) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float Eks[NR * BK], Evs[NR * BK];
@@ -552,23 +577,27 @@ __global__ __launch_bounds__(NTA) void btse_attn_bwd_kv_kernel(const SclBtseBio 
     }
     for (int i = t; i < L; i += NTA) { lseS[i] = base[O_LSE * L + h * L + i]; delS[i] = G[G_DELTA * L + h * L + i]; }
     __syncthreads();
-    for (int j = t; j < L; j += NTA) {
-        float kj[BK], vj[BK], dk[BK], dv[BK];
+    const int j = blockIdx.z * RPB + (t >> 2), ks = t & 3;
+    const int jr = min(j, L - 1);
+    float kj[BK], vj[BK], dk[BK], dv[BK];
 #pragma unroll
-        for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + j * BD + h * BK + d]; vj[d] = base[O_V * L + j * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
-#pragma unroll 4
-        for (int i = 0; i < L; ++i) {
-            const int dj = j - i;
-            const float* qr = Qh + i * BK;
-            const float* ar = Ah + i * BK;
-            const bool band = (unsigned)(dj + BW) <= 2u * BW;
-            const float sij = dot8(qr, kj) + (band ? dot8_lds(qr, Eks + (dj + BW) * BK) : 0.f);      // q_i . (k_j + emb_rel_k[j - i + 4])
-            const float g = dot8(ar, vj) + (band ? dot8_lds(ar, Evs + (dj + BW) * BK) : 0.f);         // dA_i . (v_j + emb_rel_v[j - i + 4])
-            const float pij = __expf(sij - lseS[i]);
-            const float dS = pij * (g - delS[i]);
+    for (int d = 0; d < BK; ++d) { kj[d] = base[O_K * L + jr * BD + h * BK + d]; vj[d] = base[O_V * L + jr * BD + h * BK + d]; dk[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll 2
+    for (int i = ks; i < L; i += KS) {
+        const int dj = jr - i;
+        const float* qr = Qh + i * BK;
+        const float* ar = Ah + i * BK;
+        const bool band = (unsigned)(dj + BW) <= 2u * BW;
+        const float sij = dot8(qr, kj) + (band ? dot8_lds(qr, Eks + (dj + BW) * BK) : 0.f);      // q_i . (k_j + emb_rel_k[j - i + 4])
+        const float g = dot8(ar, vj) + (band ? dot8_lds(ar, Evs + (dj + BW) * BK) : 0.f);         // dA_i . (v_j + emb_rel_v[j - i + 4])
+        const float pij = __expf(sij - lseS[i]);
+        const float dS = pij * (g - delS[i]);
 #pragma unroll
-            for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
-        }
+        for (int d = 0; d < BK; ++d) { dk[d] = fmaf(dS, qr[d], dk[d]); dv[d] = fmaf(pij, ar[d], dv[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < BK; ++d) { dk[d] = quad_sum(dk[d]); dv[d] = quad_sum(dv[d]); }
+    if (ks == 0 && j < L) {
 #pragma unroll
         for (int d = 0; d < BK; ++d) { G[G_K * L + j * BD + h * BK + d] = dk[d]; G[G_V * L + j * BD + h * BK + d] = dv[d]; }
     }
@@ -650,7 +679,7 @@ extern "C" int scl_btse_bio_fwd(const SclBtseBio* p, void* stream) {
     const size_t lds = (size_t)2 * p->L * BK * sizeof(float);      // one head's K and V slices
     for (int l = 0; l <= p->n_layers; ++l) {
         hipLaunchKernelGGL(btse_rows_fwd_kernel, dim3(p->B), dim3(NT), 0, s, *p, l);
-        if (l < p->n_layers) hipLaunchKernelGGL(btse_attn_fwd_kernel, dim3(p->B, BH), dim3(NTA), lds, s, *p, l);
+        if (l < p->n_layers) hipLaunchKernelGGL(btse_attn_fwd_kernel, dim3(p->B, BH, (p->L + RPB - 1) / RPB), dim3(NTA), lds, s, *p, l);
     }
     return scl_check_launch("scl_btse_bio_fwd");
 }
@@ -662,8 +691,8 @@ extern "C" int scl_btse_bio_bwd(const SclBtseBio* p, void* stream) {
     const size_t lds_q = (size_t)2 * p->L * BK * sizeof(float), lds_kv = (size_t)(2 * p->L * BK + 2 * p->L) * sizeof(float);
     for (int l = p->n_layers - 1; l >= 0; --l) {
         hipLaunchKernelGGL(btse_rows_bwd_kernel, dim3(p->B), dim3(NT), stage, s, *p, l + 1 < p->n_layers ? l + 1 : -1, l);
-        hipLaunchKernelGGL(btse_attn_bwd_q_kernel, dim3(p->B, BH), dim3(NTA), lds_q, s, *p, l);
-        hipLaunchKernelGGL(btse_attn_bwd_kv_kernel, dim3(p->B, BH), dim3(NTA), lds_kv, s, *p, l);
+        hipLaunchKernelGGL(btse_attn_bwd_q_kernel, dim3(p->B, BH, (p->L + RPB - 1) / RPB), dim3(NTA), lds_q, s, *p, l);
+        hipLaunchKernelGGL(btse_attn_bwd_kv_kernel, dim3(p->B, BH, (p->L + RPB - 1) / RPB), dim3(NTA), lds_kv, s, *p, l);
     }
     hipLaunchKernelGGL(btse_rows_bwd_kernel, dim3(p->B), dim3(NT), stage, s, *p, 0, -1);
     return scl_check_launch("scl_btse_bio_bwd");
