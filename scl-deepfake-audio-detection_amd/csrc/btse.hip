@@ -21,15 +21,17 @@
 // scratch row in every trip 1.80 / 4.06 ms (at batch 64); thread-per-row with scalar weights, one workgroup per utterance for the whole encoder
 // 1.00 / 2.05 ms (half the CUs idle, one wave per SIMD on the rest, 796 (row, head) items behind 256 threads); 512 threads per utterance
 // 0.74 / 1.71 ms; the attention as its own launch per layer with a workgroup per (utterance, head) 0.59 / 1.20 ms (2 n_layers + 1 launches
-// forward, 3 n_layers + 1 backward; 512 tokens: 3.9 / 8.0 -> 1.46 / 3.43 ms).  What is left is the row launches: ~1500 scalar weight loads
-// per row phase behind a single wave per SIMD.
+// forward, 3 n_layers + 1 backward); four lanes per attention row over interleaved keys 0.50 / 1.03 ms; the forward's row launches as 64-thread
+// workgroups over (utterance, 64-row chunk) — the same per-thread work on all 256 CUs instead of four waves on each of B — 0.42 / 1.02 ms
+// (512 tokens: 3.9 / 8.0 -> 0.59 / 2.40 ms).  What is left is the backward's row + reduction launches (4 x ~170 us: one workgroup per
+// utterance, ~1500 scalar weight loads per row phase behind a single wave per SIMD, six weight-gradient reductions in sequence).
 // The activations the backward needs go to a per-utterance scratch row in HBM (L2-resident: 392 L floats per layer).
 // model.py:236 reads the LAST padded position times its mask: an utterance shorter than L scores exactly zero and contributes no
 // gradient — the backward writes a zero row for it and returns.
 #include "common.h"
 
 namespace {
-constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, NG = NT / 32, NTA = 256, KS = 4, RPB = NTA / KS, MAXL = 512, RC = 64;
+constexpr int BD = 32, BH = 4, BK = 8, BF = 128, BW = 4, NR = 2 * BW + 1, NT = 256, NG = NT / 32, NTA = 256, KS = 4, RPB = NTA / KS, NTR = 64, MAXL = 512, RC = 64;
 constexpr float QSCALE = 0.35355339059327373f;      // 1 / sqrt(k_channels = 8), transformer.py:155
 constexpr float EMB_SCALE = 5.656854249492381f;     // sqrt(bio_dim = 32), model.py:228
 constexpr float FILL = -1e4f, EPS = 1e-5f;          // transformer.py:168, modules.py:28
@@ -141,13 +143,15 @@ __device__ __forceinline__ float dot8_lds(const float* __restrict__ a, const flo
 // scratch row already, so the split adds no traffic.
 
 // rows kernel `l` (0 .. n_layers): [embedding | the post-attention half of layer l - 1] -> x;  [Q, K, V of layer l | the read-out]
-__global__ __launch_bounds__(NT) void btse_rows_fwd_kernel(const SclBtseBio p, const int l) {
+__global__ __launch_bounds__(NTR) void btse_rows_fwd_kernel(const SclBtseBio p, const int l) {
     const int b = blockIdx.x, t = threadIdx.x, L = p.L;
     const int len = min(max(p.lens[b], 0), L);            // commons.sequence_mask: arange(L) < length
     float* ws = p.ws + (int64_t)b * p.ws_stride;
     const int32_t* tok = p.bio + (int64_t)b * L;
     float* cur = ws + (int64_t)l * O_LAYER * L;           // layer l's block: its input rows first
-    for (int r = t; r < L; r += NT) {
+    {
+        const int r = blockIdx.y * NTR + t;
+        if (r < L) {
         float x[BD];
         if (l == 0) {                                     // model.py:228,232 + transformer.py:42
             const int tk = min(max(tok[r], 0), p.n_bios - 1);
@@ -209,11 +213,12 @@ __global__ __launch_bounds__(NT) void btse_rows_fwd_kernel(const SclBtseBio p, c
             matvec32(x, as_const(W[I_WK]), as_const(W[I_BK]), y); store_row32(cur + O_K * L + r * BD, y);
             matvec32(x, as_const(W[I_WV]), as_const(W[I_BV]), y); store_row32(cur + O_V * L + r * BD, y);
         }
+        }
     }
-    if (l < p.n_layers) return;
+    if (l < p.n_layers || (int)blockIdx.y != (L - 1) / NTR) return;       // the read-out is the work of the block that owns row L - 1
     __syncthreads();                                                                  // row L - 1 was written by a thread of this block
     const bool mlast = L - 1 < len;                                                   // model.py:234-236
-    for (int o = t; o < p.bio_out; o += NT) {
+    for (int o = t; o < p.bio_out; o += NTR) {
         float y = 0.f;
         if (mlast) {
             y = p.bs[o];
@@ -678,7 +683,7 @@ extern "C" int scl_btse_bio_fwd(const SclBtseBio* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)2 * p->L * BK * sizeof(float);      // one head's K and V slices
     for (int l = 0; l <= p->n_layers; ++l) {
-        hipLaunchKernelGGL(btse_rows_fwd_kernel, dim3(p->B), dim3(NT), 0, s, *p, l);
+        hipLaunchKernelGGL(btse_rows_fwd_kernel, dim3(p->B, (p->L + NTR - 1) / NTR), dim3(NTR), 0, s, *p, l);
         if (l < p->n_layers) hipLaunchKernelGGL(btse_attn_fwd_kernel, dim3(p->B, BH, (p->L + RPB - 1) / RPB), dim3(NTA), lds, s, *p, l);
     }
     return scl_check_launch("scl_btse_bio_fwd");
