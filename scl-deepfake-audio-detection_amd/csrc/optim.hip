@@ -62,7 +62,9 @@ extern "C" int scl_adamw_flat(float* p, const float* g, float* m, float* v, void
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    // one float4 per thread, no grid-stride trips: 8192 blocks x 38 trips ran at 4.8 - 5.75 TB/s (box to box), 308 k blocks at 6.0 - 6.2
+    // (tools/adamw_probe.py; non-temporal loads / stores made no difference)
+    if (blocks > (1 << 20)) blocks = 1 << 20;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
