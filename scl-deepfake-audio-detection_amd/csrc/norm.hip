@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256, (NCH <= 2 ? 3 : 2)) void ln_bwd_kernel(const v
     // fed the residual must be taken of dres x keep-mask of THAT linear's dropout (din), and (b) the bf16 copy of the output, which
     // is only ever the dY operand of the next linear's weight / data gradient GEMMs, carries that linear's mask (dout).  Masks are
     // recomputed from (seed, element index = row * C + column), exactly as the forward GEMM epilogue drew them.
+    // Tried in round 5 (tools/ln_probe.py, 12736 x 1024, x f32 / dy bf16 / dres f32 -> dx f32 + bf16: 48 - 51 us = 4.1 - 4.3 TB/s): requesting
+    // `dres` together with x and dy — one memory round trip per row instead of two — costs 16 registers, i.e. the third resident block per
+    // CU: 61 us; rows per block 8 ... 40 instead of 20: 48 - 59 us, the present choice is at the optimum.
     // sum_dres: also emit the column sums of `dres` (third partial row).  In a pre-LN transformer block the residual gradient
     // that enters this LayerNorm's backward IS the gradient of the preceding linear's output (fc2 / out_proj), so its column
     // sum is that linear's bias gradient — read here anyway, summed for free instead of by a separate pass over [M, C].
