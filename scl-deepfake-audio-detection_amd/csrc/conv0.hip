@@ -285,13 +285,20 @@ __global__ void conv0_reduce_kernel(const float* __restrict__ part, int nparts, 
 
 }  // namespace
 
-// frames per backward block: ~512 blocks in all (2 resident blocks x 256 CUs), 64 <= rows <= 1024
+// frames per backward block.  Two blocks are resident per CU (216 registers): 512 slots, every block of a launch runs equally long, so the
+// launch costs ceil(blocks / 512) rounds x (rows + a fixed part: staging the taps, the 4-wave combine, one partial row).  The first form
+// aimed at "~512 blocks" with rows <= 1024 and got 13 chunks x 64 utterances = 832 blocks: two rounds of 1024 frames where 16 chunks are two
+// rounds of 800.  Pick the chunk count with the smallest cost (rows 64 ... 1024).
 static int conv0_bwd_rows(int B, int T0) {
-    int chunks = 512 / (B > 0 ? B : 1); if (chunks < 1) chunks = 1;
-    int rows = (T0 + chunks - 1) / chunks;
-    if (rows < 64) rows = 64;
-    if (rows > 1024) rows = 1024;
-    return rows;
+    int best_rows = 1024; long long best = -1;
+    for (int chunks = (T0 + 1023) / 1024; chunks <= (T0 + 63) / 64; ++chunks) {
+        const int rows = (T0 + chunks - 1) / chunks;
+        const long long blocks = (long long)B * ((T0 + rows - 1) / rows);
+        const long long cost = ((blocks + 511) / 512) * (rows + 48);
+        if (best < 0 || cost < best) { best = cost; best_rows = rows; }
+        if (blocks > 8192) break;      // the partial-sum tree is sized for a few thousand rows
+    }
+    return best_rows < 64 ? 64 : best_rows;
 }
 
 extern "C" int scl_conv0_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
