@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 tag=$1; shift
 rm -rf gpurun_out/prof_gs
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_gs -o bench -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 "$@" > /dev/null 2>&1
-python3 - "$tag" <<'PY' > gpurun_out/r5_${1:-x}_grids.txt
+python3 - "$tag" <<'PY' > gpurun_out/r5_${tag}_grids.txt
 import csv, glob, collections, sys
 f = glob.glob('gpurun_out/prof_gs/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
@@ -20,5 +20,4 @@ for r in steps:
 for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])[:45]:
     print("%-72s %5.1f calls %8.1f us  %7.3f ms/step  grids %s" % (k, v[1] / 2, v[0] / 1e3 / v[1], v[0] / 2e6, dict(v[2].most_common(3))))
 PY
-mv gpurun_out/r5_x_grids.txt gpurun_out/r5_${tag}_grids.txt 2>/dev/null
 rm -rf gpurun_out/prof_gs
