@@ -227,7 +227,7 @@ int scl_pad_nhwc_f32(const float* src, int64_t rows, int C, void* dst, int dst_b
  * implicit-GEMM convolution: fwd [Co][kh][kw][Cp] (zero channels Ci..Cp) and bwd [Ci][kh][kw][Cop] with flipped taps (zero channels Co..Cop). */
 int scl_conv_pack_weights(const float* w, float* fwd, float* bwd, int Co, int Ci, int kh, int kw, int Cp, int Cop, void* stream);
 /* grad [Co][Ci][kh][kw] (+)= sum over nslab slabs [Co][kh][kw][Cp] in slab order (the conv weight gradient's split-K / per-utterance partials,
- * what torch's conv backward + AccumulateGrad produce); accumulate = 0 overwrites. */
+ * what torch's conv backward + AccumulateGrad produce); accumulate = 0 overwrites.  Cp % 4 == 0, slabs 16-byte aligned. */
 int scl_conv_wgrad_finish(const float* slabs, float* grad, int nslab, int Co, int Ci, int kh, int kw, int Cp, int accumulate, void* stream);
 /* F.max_pool2d(x, (3, 3)) of a single-channel map given by strides (elements): y [B, H/3, W/3], idx = flat argmax inside x[b]
  * (model/wav2vec2_aasist.py:517); the backward scatters dy into a zeroed dx. */
