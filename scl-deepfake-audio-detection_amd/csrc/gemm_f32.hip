@@ -65,17 +65,25 @@ template <int TM> struct F32Stage<TM, false> {      // K-contiguous: TM rows x 3
         }
         kcur = kbegin + 4 * (tid & 7); kend = kend_;
     }
-    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[NV]) const {
+    // The fetches of a step go out back to back; what a partial vector at the K tail needs (K % 4 != 0 is legal for f32 operands whose ld
+    // keeps rows 16-byte aligned) is done by fix() when the registers are consumed.  With the zeroing inside this loop every load sat
+    // between two exec-masked branches and the compiler put a vmcnt wait at each join: half a step's fetches waited for the other half.
+    __device__ __forceinline__ int load(const OpK& o, u32x4 (&r)[NV]) const {      // returns the k still valid at this thread's vector (>= 4: whole)
         const unsigned koff = col_off(o, (unsigned)kcur);
-        const int nvalid = kend - kcur;
+        const int nv_ld = kend - kcur;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const unsigned off = (nvalid > 0 && rowoff[i] != OOB) ? rowoff[i] + koff : OOB;
+            const unsigned off = (nv_ld > 0 && rowoff[i] != OOB) ? rowoff[i] + koff : OOB;
             r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            if (nvalid < 4) {     // partial vector at the K tail (K % 4 != 0 is legal for f32 operands whose ld keeps rows 16-byte aligned)
+        }
+        return nv_ld;
+    }
+    __device__ __forceinline__ void fix(u32x4 (&r)[NV], int nv_ld) const {
+        if (nv_ld < 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (e >= nvalid) r[i][e] = 0u;
-            }
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e >= nv_ld) r[i][e] = 0u;
         }
     }
     __device__ __forceinline__ void store(float* img, const u32x4 (&r)[NV], int tid) const {
@@ -114,16 +122,21 @@ template <int TM> struct F32Stage<TM, true> {       // transposed: 32 k rows x T
         coloff = nv > 0 ? col_off(o, (unsigned)col) : OOB;
         kcur = kbegin + tid / CPR; kend = kend_;
     }
-    __device__ __forceinline__ void load(const OpK& o, u32x4 (&r)[NV]) const {
+    __device__ __forceinline__ int load(const OpK& o, u32x4 (&r)[NV]) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int rr = kcur + KSTEP * i;
             const unsigned off = (rr < kend && coloff != OOB) ? row_off(o, (unsigned)rr) + coloff : OOB;
             r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            if (ncolvalid < 4) {
+        }
+        return 4;
+    }
+    __device__ __forceinline__ void fix(u32x4 (&r)[NV], int) const {      // columns past the operand's edge (a partial 4-column vector)
+        if (ncolvalid < 4) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (e >= ncolvalid) r[i][e] = 0u;
-            }
         }
     }
     __device__ __forceinline__ void store(float* img, const u32x4 (&r)[NV], int tid) const {
@@ -201,15 +214,17 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
         for (int j = 0; j < G::NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[F32Stage<TM, AT>::NV], rb[F32Stage<TM, BT>::NV];
-    if (nk > 0) {
-        sa.load(d.A, ra); sb.load(d.B, rb);
+    {   // no branch around a fetch or around the store that consumes it (see scl_gemm_f32p_kernel): past the last step the offsets are out of
+        // range, the loads return zeros without traffic and the images written are never read
+        const int na = sa.load(d.A, ra), nb = sb.load(d.B, rb);
+        sa.fix(ra, na); sb.fix(rb, nb);
         sa.store(smem, ra, tid); sb.store(smem + G::IMG, rb, tid);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) { sa.advance(); sb.advance(); sa.load(d.A, ra); sb.load(d.B, rb); }
+        sa.advance(); sb.advance();
+        const int na = sa.load(d.A, ra), nb = sb.load(d.B, rb);
         const float* tA = smem + cur * 2 * G::IMG;
         const float* tB = tA + G::IMG;
         float fa[G::NB][8], fb[G::NB][8];
@@ -239,8 +254,9 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
                     for (int n = 0; n < G::NB; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0);
         }
-        if (more) {
+        {
             float* nA = smem + (cur ^ 1) * 2 * G::IMG;
+            sa.fix(ra, na); sb.fix(rb, nb);
             sa.store(nA, ra, tid); sb.store(nA + G::IMG, rb, tid);
         }
         __syncthreads();
@@ -273,7 +289,8 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32_kernel(c
 //  * a THREE-part form (a = p0 + p1 + p2 carries all 24 mantissa bits; the six terms of weight >= 2^-16) as a replacement for the exact
 //    v_mfma_f32_16x16x4_f32 kernel: same error against fp64 (1.0e-6 vs 1.3e-6) at 96 instead of 256 matrix-core cycles per 16x16x32
 //    block, but 745 vs 759 us / 286 vs 254 us — three images per operand are 120 KB of LDS (one block per CU) and 1.5x the LDS traffic;
-//  * a second register set (fetch distance 2): no change (354 vs 355 us) at +42 VGPRs.
+//  * a second register set (fetch distance 2) on the loop as first written: no change (354 vs 355 us) — the fetch and the conversion sat behind
+//    step-index branches and the compiler's vmcnt placement drained the queue anyway; the branch-free form below is what runs now.
 //  Ablations on the QKV shape: full 354 us; without the global fetches 257; without the MFMAs 237; without the split + image stores 297 —
 //  no single resource bounds it: fetch issue, fragment reads, MFMAs and image stores run back to back inside a wave and two blocks
 //  per CU overlap them only partly (LDS traffic ~= MFMA time at this tile shape).
@@ -308,17 +325,29 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32p_kernel(
     for (int i = 0; i < G::NB; ++i)
 #pragma unroll
         for (int j = 0; j < G::NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 ra[F32Stage<TM, AT>::NV], rb[F32Stage<TM, BT>::NV];
-    if (nk > 0) {
-        sa.load(d.A, ra); sb.load(d.B, rb);
-        sa.store_pair(psm, psm + IMGB, ra, tid); sb.store_pair(psm + 2 * IMGB, psm + 3 * IMGB, rb, tid);
-    }
+    // Two register sets: the fetches of step kt + 2 go out before the MFMAs of step kt, and the set split + stored behind those MFMAs (step
+    // kt + 1) landed a step ago — its conversion has no memory wait in front of it and can issue in the shadow of the matrix instructions.
+    constexpr int NV = F32Stage<TM, false>::NV;
+    u32x4 ra0[NV], rb0[NV], ra1[NV], rb1[NV];
+    int na0 = 4, nb0 = 4, na1 = 4, nb1 = 4;
+    // Nothing in the pipeline below is conditional on the step index: a fetch past the last step has every offset out of range (the buffer
+    // loads return zeros without traffic), its images are zeros, and an odd step count runs one extra step on them that adds exact zeros.
+    // Every branch around a fetch or around the conversion that consumes one makes the compiler's vmcnt placement assume the path that did
+    // NOT wait — it then drains the whole fetch queue at the loop header.  Measured on one box against the one-register-set loop of the round's
+    // first form (QKV-shaped scoring GEMM / ResNet 128 -> 128 data-gradient convolution, TFLOP/s of f32-equivalent work): 224 - 232 / 152 ->
+    // 234 - 237 / 164 - 166; cutting the conversion into pieces between the MFMA row blocks: 226 / 157 (dropped).
+    na0 = sa.load(d.A, ra0); nb0 = sb.load(d.B, rb0);
+    sa.advance(); sb.advance(); na1 = sa.load(d.A, ra1); nb1 = sb.load(d.B, rb1);
+    sa.fix(ra0, na0); sb.fix(rb0, nb0);
+    sa.store_pair(psm, psm + IMGB, ra0, tid); sb.store_pair(psm + 2 * IMGB, psm + 3 * IMGB, rb0, tid);
     __syncthreads();
-    int cur = 0;
     const int frow = (lane & 15) * (PK * 2) + ((((lane >> 4) ^ (lane >> 2)) & 3) << 4);      // a lane's row and its (swizzled) chunk of 8 consecutive k inside a 16-row block
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) { sa.advance(); sb.advance(); sa.load(d.A, ra); sb.load(d.B, rb); }
+    // one step: LDS buffer `cur` holds step kt, (rn_a, rn_b) hold step kt + 1, (rf_a, rf_b) are free for step kt + 2
+    auto step = [&](int cur, u32x4 (&rf_a)[NV], u32x4 (&rf_b)[NV], int& nf_a, int& nf_b, u32x4 (&rn_a)[NV], u32x4 (&rn_b)[NV], int nn_a, int nn_b) {
+        // unconditional: past the last step every offset is out of range and the buffer loads return zeros without traffic.  Behind a branch the
+        // compiler must place the vmcnt waits of the conversion below for the path that issued nothing, i.e. wait for THESE fetches too.
+        sa.advance(); sb.advance(); nf_a = sa.load(d.A, rf_a); nf_b = sb.load(d.B, rf_b);
+        __builtin_amdgcn_sched_barrier(0);      // the fetches stay FIRST: sunk below the fragment reads, their registers alias the fragments' and the loop header waits vmcnt(0)
         const char* t0 = psm + cur * 4 * IMGB;
         bf16x8 ah[G::NB], al[G::NB], bh[G::NB], bl[G::NB];
 #pragma unroll
@@ -337,12 +366,14 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32p_kernel(
                 acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], al[i], acc[i][n], 0, 0, 0);
                 acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], ah[i], acc[i][n], 0, 0, 0);
             }
-        if (more) {
-            char* nb = psm + (cur ^ 1) * 4 * IMGB;
-            sa.store_pair(nb, nb + IMGB, ra, tid); sb.store_pair(nb + 2 * IMGB, nb + 3 * IMGB, rb, tid);
-        }
+        char* nbuf = psm + (cur ^ 1) * 4 * IMGB;
+        sa.fix(rn_a, nn_a); sb.fix(rn_b, nn_b);
+        sa.store_pair(nbuf, nbuf + IMGB, rn_a, tid); sb.store_pair(nbuf + 2 * IMGB, nbuf + 3 * IMGB, rn_b, tid);
         __syncthreads();
-        cur ^= 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(0, ra0, rb0, na0, nb0, ra1, rb1, na1, nb1);
+        step(1, ra1, rb1, na1, nb1, ra0, rb0, na0, nb0);
     }
     if constexpr (G::NB == 4) {
         f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0][0]);
@@ -361,11 +392,6 @@ __global__ __launch_bounds__(256, (TM == 64 ? 4 : 2)) void scl_gemm_f32p_kernel(
 template <int TM>
 void f32p_launch(const GemmK& k, dim3 grid, hipStream_t s) {
     const size_t lds = (size_t)2 * 4 * TM * PK * 2;
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536) {
-        (void)hipFuncSetAttribute((const void*)scl_gemm_f32p_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     SCL_LAUNCH((scl_gemm_f32p_kernel<TM>), grid, dim3(256), lds, s, k);
 }
 
