@@ -54,6 +54,8 @@ def parse():
                     "is_train False, no grad) on batches of 64600-sample clips (Dataset_for_eval's pad length); both scoring precisions are timed")
     ap.add_argument("--tiny", action="store_true", help="2-layer toy encoder (plumbing check only; not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-gemm-launches", default=None, metavar="FILE", help="write every profiled GEMM-family launch (ms, M, N, K, flags, z, variant) in "
+                    "issue order as JSON: the input of tools/gemm_classes.py (profiles/r6_gemm_classes.txt)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
 
@@ -308,6 +310,10 @@ def main():
     dt = time.perf_counter() - t0
     ops.prof_enable(KID_GEMM, False)
     ops.prof_enable(KID_AUG, False)
+    if args.dump_gemm_launches and rank == 0:
+        with open(args.dump_gemm_launches, "w") as f:
+            json.dump({"batch": B, "samples": L, "model": args.model, "profiled_steps": n_prof, "gemm_src_sha": gemm_source_sha(),
+                       "launches": [[ms] + list(meta) for ms, meta in ops.prof_read_launches(KID_GEMM)]}, f)
     n_launch, gemm_ms, gemm_flops = ops.prof_read(KID_GEMM)
     aug_launch, aug_ms, _ = ops.prof_read(KID_AUG)
     loss_val = float(last.item())
@@ -329,7 +335,7 @@ def main():
     # same command (profiles/r5_pmc_hbm_traffic.json, or a previous round's; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — but only
     # while the GEMM sources are the ones that pass was taken with (its "gemm_src_sha"), else null
     traffic = None
-    for tag in ("r5", "r4", "r3"):
+    for tag in ("r6", "r5", "r4", "r3"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)) as f:
                 pmc = json.load(f)

@@ -246,6 +246,12 @@ def main(argv=None):
     data_mod = importlib.import_module("datautils." + config["data"]["name"])
     genList, Dataset_for, Dataset_for_eval = data_mod.genList, data_mod.Dataset_for, data_mod.Dataset_for_eval
     # --seed initialises the weights (02_train.sh: "random seed to initialize the weight") and, with the rank, the dropout stream
+    if config["model"]["name"] == "wav2vec2_btse" and not config["model"].get("bio_tokenizer"):
+        # run_epoch / the scoring loops call model(x) as the reference's train_epoch does (main.py:60): the plugin then needs its tokeniser,
+        # and the reference's own (model/wav2vec2_btse/biosegment) is a dangling symlink.  Say so now, not at the first forward.
+        sys.exit("main.py: model wav2vec2_btse needs the YAML key model.bio_tokenizer = '<module>:<callable>' (waveforms [bz, L] numpy, "
+                 "sample_rate) -> equal-length token rows; the reference's biosegment package does not exist, so %s cannot run as shipped "
+                 "(scl_amd/model_btse.py; bench.py --model wav2vec2_btse feeds synthetic tokens)" % args.config)
     model = MODEL_REGISTRY[config["model"]["name"]](config["model"], device, seed=args.seed, rank=rank)
     print("nb_params:", sum(p.numel() for p in model.parameters()))
 

@@ -307,6 +307,97 @@ def gen_train_step():
     print("train_step.npz", len(out), "arrays")
 
 
+def gen_trajectory():
+    """SIX optimizer steps through the reference's OWN train_epoch (main.py:47-84, imported from the file) with AdamW as main.py:339 and the
+    per-epoch CyclicLR of main.py:341 stepped as main.py:416 — two epochs of three packs, so steps 1-3 run at the scheduler's first rate and
+    steps 4-6 at its second.  Model = the reference linear plugin with the oracle's tiny wav2vec2 restatement injected (as gen_train_step),
+    train mode with every Dropout p = 0 (its RNG cannot be shared).  Input packs are the 3-D [1, L, V] tensors of --batch_size 1
+    (main.py:59-61).  Stored per step: the three loss terms (captured at Model.loss, the values train_epoch sums), the learning rate the
+    step ran at, and five weights after the step; per epoch: train_epoch's own running_loss / accuracy / detail."""
+    import importlib.util
+    import model.wav2vec2_linear_nll as M
+    from oracle import wav2vec2 as W
+    spec = importlib.util.spec_from_file_location("ref_main", os.path.join(REF, "main.py"))
+    ref_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_main)
+    cfg = W.W2VConfig.tiny()
+
+    class Enc(torch.nn.Module):
+        out_dim = cfg.embed
+
+        def __init__(self):
+            super().__init__()
+            sd = W.init_state(cfg, seed=11)
+            self.names = list(sd)
+            self.model = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v) for k, v in sd.items()})
+
+        def sd(self):
+            return {k: self.model[k.replace(".", "/")] for k in self.names}
+
+        def extract_feat(self, x, is_train=True):
+            return W.forward(self.sd(), cfg, x)
+
+    M.SSLModel = lambda device: Enc()
+    torch.manual_seed(5)
+    conf = {"model": {"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}}
+    m = M.Model(conf["model"], "cpu")
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    out = {}
+    for k, v in m.state_dict().items():
+        if not k.startswith("ssl_model"):
+            out["sd:" + k] = v.detach().clone().numpy()
+    max_lr, min_lr, wd = 4e-4, 1e-4, 1e-4          # CLI arguments of main.py (--max_lr / --min_lr / --weight_decay); large enough to move bf16 copies
+    opt = torch.optim.AdamW(m.parameters(), lr=max_lr, weight_decay=wd)                                            # main.py:339
+    sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=min_lr, max_lr=max_lr, step_size_up=3, mode="exp_range", gamma=0.85,
+                                              cycle_momentum=False)                                                # main.py:341
+    g = torch.Generator().manual_seed(4321)
+    V, L, n_epochs, n_steps = 4, 4000, 2, 3
+    xs = 0.1 * torch.randn(n_epochs * n_steps, 1, L, V, generator=g)
+    ys = torch.tensor([[1, 1, 0, 0], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 0, 0], [0, 0, 1, 1], [1, 0, 1, 0]]).view(-1, 1, V)
+    watch = {"LL.weight": m.LL.weight, "backend.m_utt_level.weight": m.backend.m_utt_level.weight,
+             "ssl_model.model.encoder.layers.0.self_attn.q_proj.weight": m.ssl_model.model["encoder/layers/0/self_attn/q_proj/weight"],
+             "ssl_model.model.encoder.layers.1.fc2.weight": m.ssl_model.model["encoder/layers/1/fc2/weight"],
+             "ssl_model.model.feature_extractor.conv_layers.0.0.weight": m.ssl_model.model["feature_extractor/conv_layers/0/0/weight"]}
+    rec = {"losses": [], "lr": [], "w": {k: [] for k in watch}}
+    ref_loss = m.loss
+    # the same six packs through the UNTRAINED weights (train mode, no step): what a trajectory that never moved would report — the
+    # tests use the distance between this and the trained losses to show that their tolerance can tell the two apart
+    m.train()
+    frozen = []
+    with torch.no_grad():
+        for i in range(n_epochs * n_steps):
+            o, f, e = m(xs[i].squeeze(0).transpose(0, 1))
+            r = ref_loss(o, f, e, ys[i].view(-1), conf, "pack%d" % i)
+            frozen.append([float(r[k]) for k in ("L_CE", "L_CF1", "L_CF2")])
+
+    def spy_loss(*a, **kw):
+        r = ref_loss(*a, **kw)
+        rec["losses"].append([float(r[k]) for k in ("L_CE", "L_CF1", "L_CF2")])
+        return r
+    m.loss = spy_loss
+
+    def post(optimizer, args, kwargs):
+        rec["lr"].append(optimizer.param_groups[0]["lr"])
+        for k, p in watch.items():
+            rec["w"][k].append(p.detach().clone().numpy())
+    opt.register_step_post_hook(post)
+    epoch_rows = []
+    for ep in range(n_epochs):
+        loader = [("pack%d" % i, xs[i], ys[i]) for i in range(ep * n_steps, (ep + 1) * n_steps)]
+        running, acc, detail = ref_main.train_epoch(loader, m, min_lr, opt, "cpu", conf)                            # main.py:408
+        epoch_rows.append([running, acc] + [detail[k] for k in ("L_CE", "L_CF1", "L_CF2")])
+        sched.step()                                                                                               # main.py:416
+    assert len(rec["lr"]) == n_epochs * n_steps and m.training
+    out.update(x=xs.numpy(), y=ys.numpy(), losses=np.array(rec["losses"]), losses_frozen=np.array(frozen), lr=np.array(rec["lr"], dtype=np.float64),
+               epochs=np.array(epoch_rows), hyper=np.array([max_lr, min_lr, wd]))
+    for k, lst in rec["w"].items():
+        out["w:" + k] = np.stack(lst)
+    np.savez_compressed(os.path.join(OUT, "trajectory.npz"), **out)
+    print("trajectory.npz", len(out), "arrays; lr per step", rec["lr"], "loss totals", [round(sum(r), 5) for r in rec["losses"]])
+
+
 def gen_w2v_hf():
     """Pin the wav2vec2 restatement against transformers.Wav2Vec2Model with copied weights."""
     from transformers import Wav2Vec2Config, Wav2Vec2Model
@@ -747,6 +838,6 @@ if __name__ == "__main__":
         gen_w2v_hf()          # before the stand-in modules exist: transformers probes for torchaudio
     import_reference()
     for name, fn in (("rawboost", gen_rawboost), ("multiview", gen_multiview), ("pack", gen_pack), ("pack_variants", gen_pack_variants),
-                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop), ("conformer", gen_conformer), ("btse", gen_btse)):
+                     ("head_loss", gen_head_loss), ("train_step", gen_train_step), ("trajectory", gen_trajectory), ("eer", gen_eer), ("aasist", gen_aasist), ("resnet", gen_resnet), ("audio_int16", gen_audio_int16), ("audioop", gen_audioop), ("conformer", gen_conformer), ("btse", gen_btse)):
         if want(name):
             fn()

@@ -113,6 +113,11 @@ class BtseHead(nn.Module):
         return out + [bs.bio_scoring.weight, bs.bio_scoring.bias]
 
     @staticmethod
+    def check_tokens(mod):
+        """Waits for the device-side range check of the last forward with device-resident tokens and raises IndexError if it failed."""
+        _raise_if_bad_tokens(mod, mod.btse_args["n_bios"], wait=True)
+
+    @staticmethod
     def forward(mod, feats, bio=None, bio_lengths=None):
         if bio is None:
             bio, bio_lengths = mod.__dict__["_bio"]
@@ -176,6 +181,34 @@ def _plan(mod, B, T, Lt, dev):
     return pl
 
 
+# Device-resident tokens (bench.py, real training) are range-checked WITHOUT a host round trip: the forward queues "any token outside
+# [0, n_bios)?" into a pinned flag behind an event, and the next forward (or check_tokens()) raises nn.Embedding's IndexError once that
+# event has completed — one step late instead of never (the kernel clamps for memory safety; model.py:228 would have raised).
+def _queue_token_check(mod, bio_i32, n_bios):
+    st = mod.__dict__.setdefault("_tokchk", {"host": torch.zeros(1, dtype=torch.int32).pin_memory(), "ev": torch.cuda.Event(), "pending": False, "bad": False})
+    if st["pending"]:
+        if not st["ev"].query():
+            return                      # the previous check is still in flight: keep it (its pinned flag must not be overwritten)
+        st["bad"] = st["bad"] or bool(st["host"][0].item())
+    st["host"].copy_(((bio_i32 < 0) | (bio_i32 >= n_bios)).any().to(torch.int32).view(1), non_blocking=True)
+    st["ev"].record()
+    st["pending"] = True
+
+
+def _raise_if_bad_tokens(mod, n_bios, wait=False):
+    st = mod.__dict__.get("_tokchk")
+    if st is None:
+        return
+    if st["pending"] and (wait or st["ev"].query()):
+        st["ev"].synchronize()
+        st["bad"] = st["bad"] or bool(st["host"][0].item())
+        st["pending"] = False
+    if st["bad"]:
+        st["bad"] = False
+        raise IndexError("wav2vec2_btse: a bio token of an earlier forward was out of range [0, %d) (the kernel clamped it; the reference's "
+                         "nn.Embedding raises: model/wav2vec2_btse/model.py:228)" % n_bios)
+
+
 class _BtseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, feats, bio, bio_lengths, *params):
@@ -188,6 +221,7 @@ class _BtseFn(torch.autograd.Function):
                              % (tuple(bio.shape), tuple(bio_lengths.shape), B))
         if not bio.is_cuda and bio.numel() and (int(bio.min()) < 0 or int(bio.max()) >= a["n_bios"]):
             raise IndexError("wav2vec2_btse: bio token out of range [0, %d)" % a["n_bios"])          # nn.Embedding's error (model.py:228)
+        _raise_if_bad_tokens(mod, a["n_bios"])          # a device-side check queued by an EARLIER forward, if it has completed
         Lt = bio.shape[1]
         pl = _plan(mod, B, T, Lt, dev)
         if pl["ptrs"] != [p.data_ptr() for p in BtseHead.bio_params(mod)]:
@@ -200,12 +234,14 @@ class _BtseFn(torch.autograd.Function):
         seeds = [(s0 + 7919 * j) & 0x7FFFFFFF for j in range(3)]
         pl["bio"].copy_(bio.to(torch.int32), non_blocking=True)
         pl["lens"].copy_(bio_lengths.to(torch.int32), non_blocking=True)
+        if bio.is_cuda and bio.numel():
+            _queue_token_check(mod, pl["bio"], a["n_bios"])
         x = feats.contiguous()
         w = params[:6]
         prev = x
         for j in range(3):       # linear.py:27-36 on the exact-fp32 GEMM: bias + LeakyReLU(0.01) + dropout in the epilogue, pre-activation kept
             ops.gemm(Op(prev, HID), Op(w[2 * j].detach(), HID), pl["h"][j], M, HID, HID, bias=w[2 * j + 1].detach(), act=ACT_LEAKY, c2=pl["pre"][j],
-                     drop_p=drop, drop_seed=seeds[j])
+                     drop_p=drop, drop_seed=seeds[j], x3=False)       # x3=False: the EXACT f32 kernel, as model_linear's head (not the SCL_F32X3 default)
             prev = pl["h"][j]
         ops.meanpool_fwd(prev, pl["emb"], B, T, HID)                              # linear.py:62
         ops.btse_bio_fwd(pl["desc"])                                              # model.py:328
@@ -250,15 +286,15 @@ class _BtseFn(torch.autograd.Function):
             ops.colsum_reduce(dpre, pl["cs"], gw[2 * j + 1], M, HID)
             gw[2 * j] = f32(HID, HID)
             if sk > 1:
-                ops.gemm(Op(dpre, HID), Op(inp, HID), pl["wslab"], HID, HID, M, a_t=True, b_t=True, splitk=sk, c_split_stride=HID * HID)
+                ops.gemm(Op(dpre, HID), Op(inp, HID), pl["wslab"], HID, HID, M, a_t=True, b_t=True, splitk=sk, c_split_stride=HID * HID, x3=False)
                 ops.reduce_slabs(pl["wslab"], gw[2 * j], HID * HID, sk, HID * HID)
             else:
-                ops.gemm(Op(dpre, HID), Op(inp, HID), gw[2 * j], HID, HID, M, a_t=True, b_t=True)
+                ops.gemm(Op(dpre, HID), Op(inp, HID), gw[2 * j], HID, HID, M, a_t=True, b_t=True, x3=False)
             wj = Op(params[2 * j].detach(), HID)
             if j > 0:
                 ops.gemm(Op(dpre, HID), wj, pl["dpre"][j - 1], M, HID, HID, b_t=True, R=pl["pre"][j - 1], rmode=2, ract=ACT_LEAKY, drop_p=drop,
-                         drop_seed=seeds[j - 1])
+                         drop_seed=seeds[j - 1], x3=False)
             else:
-                ops.gemm(Op(dpre, HID), wj, d_feats, M, HID, HID, b_t=True)      # backend.py:41-43: no activation between LL and the MLP
+                ops.gemm(Op(dpre, HID), wj, d_feats, M, HID, HID, b_t=True, x3=False)      # backend.py:41-43: no activation between LL and the MLP
         grads = gw + gbio + ([dfc1w, dfc1b] if is_add else []) + [dfc2w, dfc2b]
         return (None, d_feats, None, None) + tuple(grads)

@@ -11,8 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libscl_hip.so")
+# SCL_BUILD_TAG=<tag>: an A/B build (usually with SCL_BUILD_DEFINES) into build_<tag>/, library included — the shipped
+# libscl_hip.so next to this file is left alone; run a tool against it with LD_LIBRARY_PATH / SCL_LIB_PATH
+TAG = os.environ.get("SCL_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build_" + TAG if TAG else "build")
+LIB = os.path.join(OBJ if TAG else HERE, "libscl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
          "-fno-gpu-rdc"] + os.environ.get("SCL_BUILD_DEFINES", "").split()      # extra -D switches for A/B builds of one kernel (same-box comparisons)

@@ -24,9 +24,11 @@ int scl_check_launch(const char* what) {
 // ---- profiling ---------------------------------------------------------------------------------
 namespace {
 struct ProfPair { hipEvent_t a, b; };
+struct ProfMeta { int32_t v[8]; };      // what the launch was: M, N, K, flags, z (batch x split-K), kernel variant, 0, 0 (scl_prof_note)
 struct ProfState {
     bool on = false;
     std::vector<ProfPair> used;
+    std::vector<ProfMeta> meta;      // parallel to `used`
     std::vector<ProfPair> pool;
     double flops = 0.0;
 };
@@ -45,11 +47,19 @@ SclProfScope::SclProfScope(int kid_, hipStream_t s_, double flops, bool dispatch
     if (!st.pool.empty()) { p = st.pool.back(); st.pool.pop_back(); }
     else { if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; }
     st.used.push_back(p);
+    st.meta.push_back(ProfMeta{{0, 0, 0, 0, 0, 0, 0, 0}});
     st.flops += flops;
     slot = (void*)(uintptr_t)st.used.size();  // index + 1
     ea = p.a; eb = p.b;
     if (dispatch) scl_prof_active = this;      // the launch inside the scope takes the two events itself
     else hipEventRecord(p.a, s);
+}
+void SclProfScope::note(int M, int N, int K, int flags, int z, int variant) {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    const size_t i = (size_t)(uintptr_t)slot - 1;
+    if (i < st.meta.size()) st.meta[i] = ProfMeta{{M, N, K, flags, z, variant, 0, 0}};
 }
 SclProfScope::~SclProfScope() {
     if (dispatch && scl_prof_active == this) scl_prof_active = nullptr;
@@ -83,6 +93,23 @@ extern "C" int scl_prof_reserve(int kid, int n_pairs) {
     return SCL_OK;
 }
 
+// per-launch view of what scl_prof_read sums: call it BEFORE scl_prof_read (which recycles the events)
+extern "C" int scl_prof_read_launches(int kid, int cap, float* ms, int32_t* meta8, int64_t* n_launches) {
+    SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX && cap >= 0 && (cap == 0 || (ms && meta8)), "prof: bad launch read (%d, %d)", kid, cap);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& st = g_prof[kid];
+    const size_t n = st.used.size();
+    if (n_launches) *n_launches = (int64_t)n;
+    for (size_t i = 0; i < n && i < (size_t)cap; ++i) {
+        if (hipEventSynchronize(st.used[i].b) != hipSuccess) { scl_set_error("prof: event sync failed"); return SCL_ELAUNCH; }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, st.used[i].a, st.used[i].b) != hipSuccess) t = 0.f;
+        ms[i] = t;
+        for (int j = 0; j < 8; ++j) meta8[8 * i + j] = st.meta[i].v[j];
+    }
+    return SCL_OK;
+}
+
 extern "C" int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops) {
     SCL_REQUIRE(kid >= 0 && kid < SCL_KID_MAX, "prof: bad kernel id %d", kid);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -98,6 +125,7 @@ extern "C" int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, dou
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = st.flops;
     st.used.clear();
+    st.meta.clear();
     st.flops = 0.0;
     return SCL_OK;
 }

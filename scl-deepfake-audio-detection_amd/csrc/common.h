@@ -190,6 +190,7 @@ struct SclProfScope {  // brackets a launch with two events when profiling of `k
     bool dispatch, taken;
     SclProfScope(int kid, hipStream_t s, double flops, bool dispatch = false);
     ~SclProfScope();
+    void note(int M, int N, int K, int flags, int z, int variant);      // what this launch is (scl_prof_read_launches)
 };
 // The scope a launch on this thread belongs to (dispatch mode only).  The kernel's own dispatch packet then carries the two time
 // stamps (hipExtLaunchKernelGGL) instead of two hipEventRecord barrier packets around it, which cost ~20 us of queue bubble each

@@ -780,7 +780,17 @@ static int gemm_fill_k(const SclGemmDesc& d, GemmK& k) {
     k.c_rpb = (unsigned)d.c_rpb; make_magic((unsigned)d.c_rpb, &k.c_magic, &k.c_shift);
     k.ldc = d.ldc; k.M = d.M; k.N = d.N; k.K = d.K; k.nb2 = d.nb2; k.splitk = d.splitk; k.flags = d.flags;
     k.alpha = d.alpha; k.drop_p = d.drop_p; k.drop_seed = d.drop_seed;
-    const int group_m_env = 8;      // 2 .. 62 swept in round 3: 8 and 16 equal, the extremes slower
+#ifdef SCL_EXPERIMENTS
+    // round-6 A/B of the tile order (tools/xcd_order_probe.sh): SCL_GEMM_GROUP_M = rows of a group (1 .. 255), SCL_GEMM_XCD_ROWS = R of the
+    // R x 8/R region grid (1, 2, 4, 8; 0 = shipped order)
+    static const int group_m_env = [] {
+        const char* e = getenv("SCL_GEMM_GROUP_M"); const char* x = getenv("SCL_GEMM_XCD_ROWS");
+        const int g = e ? atoi(e) : 8, r = x ? atoi(x) : 0;
+        return (g >= 1 && g <= 255 ? g : 8) | ((r == 1 || r == 2 || r == 4 || r == 8 ? r : 0) << 8);
+    }();
+#else
+    const int group_m_env = 8;      // 2 .. 62 swept in round 3: 8 and 16 equal, the extremes slower; round 6 added the XCD region grid to the sweep (profiles/r6_xcd_order_ab.txt)
+#endif
     static const bool epi_generic = [] { const char* e = getenv("SCL_W8_EPI_GENERIC"); return e && atoi(e) != 0; }();
     k.group_m = group_m_env; k.tile_m = 0; k.debug = epi_generic ? 16 : 0;      // bit 4: generic epilogue loops (A/B); the wide launch sets its own bits
     // 4-wide vector epilogue needs every 4-column group 16-byte (f32) / 8-byte (bf16) aligned in C, C2, R and bias
@@ -827,6 +837,9 @@ static int gemm_group_run(const SclGemmDesc* descs, const int32_t* tile0, const 
     }
     {
         SclProfScope prof(SCL_KID_GEMM, (hipStream_t)stream, flops, true);
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += ntile ? ntile[i] : scl_gemm_w8_group_tiles(ks[i]);
+        prof.note(descs[0].M, descs[0].N, descs[0].K, tiles, n, 4);
         scl_gemm_w8_group_launch(ks, n, tile0, ntile, (hipStream_t)stream);
     }
     return scl_check_launch(what);
@@ -894,6 +907,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool x2 = false;
 #endif
         const bool w8 = !x2 && dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
+        prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? 1 + plan.variant : 0));
         if (x2) {
 #ifdef SCL_EXPERIMENTS
             scl_gemm_x2_launch(k, at, bt, plan, zdim, s);

@@ -60,10 +60,32 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int nvalid) {  // keep the f
 // workgroup id -> output tile.  (1) XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD gets a
 // contiguous run of tile ids; (2) grouped order inside the run: 8 tile-rows are walked for one tile-column before moving to
 // the next column, so the ~64 tiles resident on an XCD at a time touch 8 A row-panels and 8 B column-panels (~4 MiB = its L2).
+// SEQ: `bid` already IS the position in the tile sequence (the grouped launch lays ITS blocks out XCD-major over all members).
+template <bool SEQ = false>
 __device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tile = SEQ ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#ifdef SCL_EXPERIMENTS
+    // A/B of the XCD ownership axis (round 6, tools/xcd_order_probe.sh): bits 8..11 of the group word = R, the chip's 8 XCDs as an
+    // R x (8 / R) grid of regions over the tile matrix (R row bands x 8 / R column bands).  The tile sequence walks region after region
+    // (grouped order inside each), and XCD x still owns the x-th eighth of that sequence, so its run is its region up to a few tiles.
+    // R = 0: the shipped order (one grouped walk over the whole matrix).
+    const int R = (GROUP_M >> 8) & 15;
+    GROUP_M &= 255;
+    int row0 = 0, col0 = 0;
+    if (R > 0) {
+        const int C = 8 / R;
+        int left = tile, found = 0;
+        for (int reg = 0; reg < 8; ++reg) {
+            const int ri = reg / C, ci = reg - ri * C;
+            const int r0 = (tiles_m * ri) / R, r1 = (tiles_m * (ri + 1)) / R, c0 = (tiles_n * ci) / C, c1 = (tiles_n * (ci + 1)) / C;
+            const int cnt = (r1 - r0) * (c1 - c0);
+            if (!found && left < cnt) { found = 1; row0 = r0; col0 = c0; tiles_m = r1 - r0; tiles_n = c1 - c0; tile = left; }
+            if (!found) left -= cnt;
+        }
+    }
+#endif
     const int per_group = GROUP_M * tiles_n;
     const int group = tile / per_group;
     const int first_m = group * GROUP_M;
@@ -72,8 +94,13 @@ __device__ __forceinline__ void tile_coords(int bid, int ntiles, int tiles_m, in
     // block-uniform results, but the integer divisions above run on the vector ALU and the compiler keeps everything derived from them
     // (K offsets of the LDS-DMA pieces, output bases) in VGPRs: a buffer load whose scalar offset sits in a VGPR becomes a waterfall loop
     // (readfirstlane + compare + exec mask + branch, per instruction).  Hand the values back as SGPRs.
+#ifdef SCL_EXPERIMENTS
+    tm = __builtin_amdgcn_readfirstlane(row0 + first_m + in_group % gsize);
+    tn = __builtin_amdgcn_readfirstlane(col0 + in_group / gsize);
+#else
     tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsize);
     tn = __builtin_amdgcn_readfirstlane(in_group / gsize);
+#endif
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

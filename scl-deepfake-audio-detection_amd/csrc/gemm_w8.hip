@@ -493,7 +493,7 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
 
 // One output tile of the single-barrier loop: `bid` of `nblk` blocks in x (the tile id within ITS problem), `bz` the batch / split-K index.
 // The plain kernel passes its own block indices; the grouped kernel (several problems in one launch) passes the position inside the member.
-template <bool AT, bool BT, int RB0, int RB1>
+template <bool AT, bool BT, int RB0, int RB1, bool SEQ = false>
 __device__ __forceinline__ void w8s_tile(const GemmK& d, char* smem, const int bid, const int nblk, const int bz) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
@@ -508,7 +508,7 @@ __device__ __forceinline__ void w8s_tile(const GemmK& d, char* smem, const int b
 #endif
     const int tiles_m = (d.M + d.tile_m - 1) / d.tile_m, tiles_n = (d.N + W8_BN - 1) / W8_BN;
     int tm, tn;
-    tile_coords(bid, nblk, tiles_m, tiles_n, tm, tn, d.group_m);
+    tile_coords<SEQ>(bid, nblk, tiles_m, tiles_n, tm, tn, d.group_m);
     const int m0 = tm * d.tile_m, n0 = tn * W8_BN;
     const int mlimit = min(d.M, m0 + d.tile_m);
     int z = bz;
@@ -565,17 +565,31 @@ struct GemmGroupK {
     int tile0[W8_GROUP_MAX];          // the member's first tile inside ITS problem (a member may be a RANGE of a problem's tiles: carry-over)
     int ntiles[W8_GROUP_MAX];         // tiles of the whole problem (tile_coords needs the full count)
     int n;
+    int xcd_major;                    // 1: blocks laid out XCD-major over the launch's whole tile sequence (default); 0: round 5's per-member runs
 };
 typedef const __attribute__((address_space(4))) GemmGroupK* W8GArg;
+// Block -> tile (round 6).  Every block of this launch streams its two operand panels ([K rows] x 256 columns each: 6.5 MB at K = 12736)
+// through its XCD's L2 once, and the 32 blocks of an XCD walk K in step, so what the XCD fetches over the fabric is the number of DISTINCT
+// panels among its 32 tiles.  Rounds 5's mapping gave every member's tiles to the XCDs eight at a time (the per-member XCD run of
+// tile_coords): 8 x 1 or 4 x 2 patches, ~28 distinct panels per XCD — 1.6 - 1.8 GB of FETCH_SIZE per launch (profiles/r6_gemm_classes.txt),
+// 5.3 TB/s of fabric traffic under a 320-us launch: the launch was paced by that, not by its MFMAs (271 / 336 / 348 us at 128 / 192 / 256
+// tiles, tools/group_fill_probe.py).  Now the launch's block sequence is XCD-major over ALL members: XCD x owns positions
+// [x * total / 8, (x + 1) * total / 8) of the concatenated tile sequence, i.e. 32 consecutive tiles of (mostly) one problem in the grouped
+// order — an 8 x 4 or 4 x 8 patch with 12 distinct panels.
 template <bool AT, bool BT, int RB0, int RB1>
 __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_group_kernel(const GemmGroupK g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     W8GArg gp = (W8GArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const int total = g.first[W8_GROUP_MAX];
+    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3, q = total >> 3, r = total & 7;
+    const int pos = (g.xcd_major ? ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx) : (int)blockIdx.x);
     int mem = 0;
 #pragma unroll
-    for (int i = 1; i < W8_GROUP_MAX; ++i) mem += (i < g.n && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
+    for (int i = 1; i < W8_GROUP_MAX; ++i) mem += (i < g.n && pos >= g.first[i]) ? 1 : 0;
     mem = __builtin_amdgcn_readfirstlane(mem);
-    w8s_tile<AT, BT, RB0, RB1>(*(const GemmK*)&gp->k[mem], smem, (int)blockIdx.x - gp->first[mem] + gp->tile0[mem], gp->ntiles[mem], 0);
+    const int t = __builtin_amdgcn_readfirstlane(pos - gp->first[mem] + gp->tile0[mem]);
+    if (g.xcd_major) w8s_tile<AT, BT, RB0, RB1, true>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0);
+    else w8s_tile<AT, BT, RB0, RB1, false>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0);
 }
 
 #ifdef SCL_EXPERIMENTS      // opt-in experiment, not part of the shipped library (see gemm.hip)
@@ -864,6 +878,8 @@ int scl_gemm_w8_group_launch(GemmK* ks, int n, const int* tile0, const int* ntil
     }
     for (int i = n; i <= W8_GROUP_MAX; ++i) g.first[i] = total;
     g.n = n;
+    static const int xcd_major = [] { const char* e = getenv("SCL_WGRAD_XCD_MAJOR"); return e ? atoi(e) : 1; }();      // 0: round 5's per-member XCD runs (A/B)
+    g.xcd_major = xcd_major;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_group_kernel<true, true, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);

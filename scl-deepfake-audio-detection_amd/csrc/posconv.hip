@@ -302,6 +302,7 @@ extern "C" int scl_posconv_wgrad(const void* dypad, int dy_row0, const void* xpa
     }
     hipStream_t s = (hipStream_t)stream;
     SclProfScope prof(SCL_KID_GEMM, s, 2.0 * B * T * (double)Cg * K * Cg * G, true);
+    prof.note(Cg * K, Cg * G, B * T, 2, G, 5);
     SCL_LAUNCH(posconv_wgrad_kernel, dim3((unsigned)(G * (K / PW_TAPS))), dim3(512), PW_LDS, s, (const bf16_t*)dypad, (const bf16_t*)xpad, dw, B, T, K, G,
                dy_row0);
     return scl_check_launch("scl_posconv_wgrad");
@@ -325,6 +326,7 @@ extern "C" int scl_posconv_mfma(const void* xpad, const void* w, float* C, const
     hipStream_t s = (hipStream_t)stream;
     // counted with the bf16 MFMA GEMM family (bench.py's roofline): the contraction scl_gemm_bf16 performed for this layer before
     SclProfScope prof(SCL_KID_GEMM, s, 2.0 * B * T * (double)Cg * K * Cg * G, true);
+    prof.note(B * T, Cg * G, Cg * K, fwd ? 1 : 0, G, 5);
     if (fwd) SCL_LAUNCH((posconv_mfma_kernel<true>), grid, block, PC_LDS, s, (const bf16_t*)xpad, (const bf16_t*)w, C, bias, (bf16_t*)c2, R, B, T, K, G);
     else SCL_LAUNCH((posconv_mfma_kernel<false>), grid, block, PC_LDS, s, (const bf16_t*)xpad, (const bf16_t*)w, C, bias, (bf16_t*)c2, R, B, T, K, G);
     return scl_check_launch("scl_posconv_mfma");

@@ -80,21 +80,26 @@ _ZERO_POOL = {}
 
 
 def _zeros_acquire(key, numel, dtype, dev):
+    """-> entry [tensor, busy, generation].  The generation is bumped on every hand-out: whoever releases (or reads, in a backward) passes
+    the generation it was given, so a stale owner — the finaliser of a graph whose backward already released the entry, after a later
+    forward took it — can neither free nor silently read a buffer that now belongs to someone else (round-5 advisory)."""
     if torch.cuda.is_current_stream_capturing():
-        return [torch.zeros(numel, dtype=dtype, device=dev), True]
+        return [torch.zeros(numel, dtype=dtype, device=dev), True, 1]
     lst = _ZERO_POOL.setdefault((key, numel, dtype, dev.index, torch.cuda.current_stream(dev).cuda_stream), [])
     for ent in lst:
         if not ent[1]:
             ent[1] = True
+            ent[2] += 1
             return ent
-    ent = [torch.zeros(numel, dtype=dtype, device=dev), True]
+    ent = [torch.zeros(numel, dtype=dtype, device=dev), True, 1]
     if len(lst) < 8:
         lst.append(ent)
     return ent
 
 
-def _zeros_release(ent):
-    ent[1] = False
+def _zeros_release(ent, gen=None):
+    if gen is None or ent[2] == gen:
+        ent[1] = False
 
 
 def _ceil(v, m):
@@ -130,8 +135,8 @@ class _Conv2dFn(torch.autograd.Function):
         xp = ent[0]
         xc = x.contiguous()
         ops.pad_nhwc(xc, B * H * W, Ci, xp, rowmap)
-        ctx.xp_ent = ent
-        weakref.finalize(ctx, _zeros_release, ent)
+        ctx.xp_ent, ctx.xp_gen = ent, ent[2]
+        weakref.finalize(ctx, _zeros_release, ent, ent[2])
         wk = _packed_conv(weight, dtype, Co, Ci, kh, kw, Cp, _ceil(Co, vec))[0]
         K = kh * kw * Cp
         y = torch.empty(B, OH, OW, Co, dtype=torch.float32, device=dev)
@@ -147,6 +152,9 @@ class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xp, weight = ctx.saved_tensors
+        if ctx.xp_ent[2] != ctx.xp_gen:
+            raise RuntimeError("hipnn.conv2d: this node's padded input was handed to a later forward (generation %d, node holds %d) — "
+                               "a second backward through a graph whose first backward already released it" % (ctx.xp_ent[2], ctx.xp_gen))
         B, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, Cp, Hp, Wp, OH, OW, dtype, has_bias = ctx.geom
         x3_bwd = ctx.x3_bwd
         dev = dy.device
@@ -221,7 +229,7 @@ class _Conv2dFn(torch.autograd.Function):
                      nb1=B, c_bs1=H * W * Ci, x3=x3_bwd)
         if ent_p is not None:
             _zeros_release(ent_p)
-        _zeros_release(ctx.xp_ent)
+        _zeros_release(ctx.xp_ent, ctx.xp_gen)
         return dx, dw, db, None, None, None, None, None, (dy if ctx.needs_input_grad[8] else None)
 
 

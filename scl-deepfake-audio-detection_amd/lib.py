@@ -10,7 +10,7 @@ import torch  # noqa: F401  — MUST precede CDLL: torch ships its own libamdhip
 #                             runtimes in the process and the kernels would see "no ROCm-capable device"
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libscl_hip.so")
+LIB_PATH = os.environ.get("SCL_LIB_PATH") or os.path.join(HERE, "libscl_hip.so")      # SCL_LIB_PATH: an A/B build of build.py (SCL_BUILD_TAG)
 FLAT = 0x7FFFFFFF
 
 _lib = None
@@ -112,6 +112,7 @@ def _protos():
         "scl_prof_enable": ([_i32, _i32], _i32),
         "scl_prof_reserve": ([_i32, _i32], _i32),
         "scl_prof_read": ([_i32, P(_i64), P(_f64), P(_f64)], _i32),
+        "scl_prof_read_launches": ([_i32, _i32, P(ctypes.c_float), P(_i32), P(_i64)], _i32),
         "scl_gemm_bf16": ([P(SclGemmDesc), _vp], _i32),
         "scl_gemm_bf16_group_ok": ([P(SclGemmDesc), _i32], _i32),
         "scl_gemm_bf16_group": ([P(SclGemmDesc), _i32, _vp], _i32),

@@ -267,6 +267,19 @@ def prof_reserve(kid, n_pairs):
     _call("scl_prof_reserve", kid, n_pairs)
 
 
+def prof_read_launches(kid, cap=65536):
+    """[(ms, (M, N, K, flags, z, variant, 0, 0))] of the launches scl_prof_read would sum, in issue order; call before prof_read."""
+    n = ctypes.c_int64(0)
+    _call("scl_prof_read_launches", kid, 0, None, None, ctypes.byref(n))
+    k = min(int(n.value), cap)
+    if k == 0:
+        return []
+    ms = (ctypes.c_float * k)()
+    meta = (ctypes.c_int32 * (8 * k))()
+    _call("scl_prof_read_launches", kid, k, ms, meta, ctypes.byref(n))
+    return [(float(ms[i]), tuple(int(meta[8 * i + j]) for j in range(8))) for i in range(k)]
+
+
 def prof_read(kid):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     _call("scl_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))

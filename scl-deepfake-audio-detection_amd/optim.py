@@ -72,6 +72,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.P.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.P.device)
         self.step_count = 0
+        self._consolidated_at = 0      # shard mode: the step count at which every rank last held the WHOLE moments (consolidate_state)
         self.grad_sync = grad_sync
         model.grad_sync = grad_sync
         # optional on a single GPU: run the update underneath the backward (see _StepOverlap).  Off by default — measured on
@@ -133,13 +134,25 @@ class FusedAdamW(torch.optim.Optimizer):
             lo, hi = self.model.trainable_range() if hasattr(self.model, "trainable_range") else (0, self.P.n_train)
             gs.gather_params(self.exp_avg[lo:hi])
             gs.gather_params(self.exp_avg_sq[lo:hi])
+        self._consolidated_at = self.step_count
+
+    def _sharded(self):
+        gs = self.grad_sync
+        return gs is not None and getattr(gs, "mode", "allreduce") == "shard" and gs.active
 
     def state_dict(self):
+        # After sharded steps the moments outside this rank's shards are stale: a checkpoint written from them would resume wrongly and
+        # silently (round-5 advisory).  state_dict() stays local (no collective: `if rank == 0: save` cannot deadlock) and refuses instead.
+        if self._sharded() and self._consolidated_at != self.step_count:
+            raise RuntimeError("FusedAdamW.state_dict(): SCL_DP_MODE=shard and %d step(s) since the moments were last whole on this rank — call "
+                               "consolidate_state() on EVERY rank first (it is a collective), then state_dict() on the rank that saves"
+                               % (self.step_count - self._consolidated_at))
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        self._consolidated_at = self.step_count
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for k, v in sd["param_groups"][0].items():

@@ -213,6 +213,19 @@ def test_c_abi_refuses_what_the_kernel_does_not_serve(dev):
         BtseHead.forward(head, torch.zeros(1, 4, 128, device=dev), torch.full((1, 5), 3, dtype=torch.int32), torch.tensor([5]))
     with pytest.raises(ValueError, match="is_add needs bio_out"):
         BtseHead(OB.default_args(is_add=True, bio_out=64))
+    # device-resident tokens (bench.py, training): no host round trip in the forward — the check is queued on the device and surfaces at
+    # the next forward (or check_tokens()); in-range tokens pass silently
+    feats = torch.zeros(1, 4, 128, device=dev)
+    BtseHead.forward(head, feats, torch.full((1, 5), 2, dtype=torch.int32, device=dev), torch.tensor([5], device=dev))
+    BtseHead.check_tokens(head)
+    BtseHead.forward(head, feats, torch.full((1, 5), 7, dtype=torch.int32, device=dev), torch.tensor([5], device=dev))      # clamped by the kernel
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="earlier forward"):
+        BtseHead.forward(head, feats, torch.full((1, 5), 1, dtype=torch.int32, device=dev), torch.tensor([5], device=dev))
+    BtseHead.forward(head, feats, torch.tensor([[0, 1, -1, 2, 0]], dtype=torch.int32, device=dev), torch.tensor([5], device=dev))
+    with pytest.raises(IndexError):
+        BtseHead.check_tokens(head)
+    BtseHead.check_tokens(head)          # raised once, then clear
 
 
 # ---- the whole plugin ------------------------------------------------------------------------------------------------------------------

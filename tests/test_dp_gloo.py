@@ -194,3 +194,59 @@ def test_global_loss_gather_backward_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _worker_consolidate(rank, world, port, q):
+    """FusedAdamW.state_dict() in the sharded mode: refuses while the moments outside the rank's shards are stale, whole after the
+    collective consolidate_state() (the HIP update itself is not run here: the rank writes its own shards of the moments by hand)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from scl_amd.optim import FusedAdamW
+    from scl_amd.parallel import GradSync
+    n = 1003
+    w = torch.nn.Parameter(torch.zeros(n))
+    P = types.SimpleNamespace(params={"w": w}, n_train=n, device=torch.device("cpu"), flat=w.data, grad=torch.zeros(n))
+    model = types.SimpleNamespace(P=P, grad_sync=None)
+    sync = GradSync(P.grad, bucket_elems=251, mode="shard")
+    opt = FusedAdamW(model, lr=1e-3, grad_sync=sync, overlap=False)
+    ok = isinstance(opt.state_dict()["exp_avg"], torch.Tensor)          # nothing stepped yet: whole by construction
+    sync.begin(); sync.finish()
+    for a, b in sync.owned():                                           # what a sharded step leaves behind: only the owner's ranges are current
+        opt.exp_avg[a:b] = torch.arange(a, b, dtype=torch.float32) + 1.0
+        opt.exp_avg_sq[a:b] = 2.0 * torch.arange(a, b, dtype=torch.float32) + 1.0
+    opt.step_count = 3
+    try:
+        opt.state_dict()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "consolidate_state" in str(e)
+    opt.consolidate_state()                                             # collective
+    sd = opt.state_dict()
+    lo_b, hi_b = sync.bounds[-1]                                        # the non-dividing remainder bucket is replicated (all-reduce fallback): both ranks wrote it
+    ref = torch.arange(n, dtype=torch.float32)
+    ok = ok and sd["step"] == 3 and torch.equal(sd["exp_avg"], ref + 1.0) and torch.equal(sd["exp_avg_sq"], 2.0 * ref + 1.0)
+    opt.step_count = 4
+    try:
+        opt.state_dict()
+        ok = False
+    except RuntimeError:
+        pass
+    opt.load_state_dict(sd)
+    ok = ok and opt.step_count == 3 and isinstance(opt.state_dict(), dict)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_state_needs_consolidation_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_consolidate, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -144,3 +144,40 @@ def test_conv2d_residual_is_added_in_the_epilogue_and_passes_the_gradient_throug
     y2.backward(dy)
     assert (y - y2).abs().max().item() < 1e-5 * y2.abs().max().item()
     assert torch.equal(r.grad, dy) and torch.equal(gx, x.grad) and torch.equal(gw, w.grad)
+
+
+def test_padded_input_pool_survives_a_dying_older_graph(dev):
+    """Lifetime of the pooled zero-bordered input map (round-5 advisory): step 0's graph is still alive (main.py's run_epoch keeps `out` /
+    the loss) when step 1's forward A re-acquires the entry step 0's backward released; dropping the old graph must not free the entry under
+    A, a further forward B of the same convolution must get its own map, and A's backward must still see A's input (weight gradient against
+    float64).  A second backward through an already-released node is refused instead of reading someone else's map."""
+    import gc
+    from scl_amd import hipnn
+    g = torch.Generator().manual_seed(11)
+    w = torch.nn.Parameter((torch.randn(16, 8, 3, 3, generator=g) * 0.2).to(dev))
+    hipnn.weights_changed()
+
+    def fwd(seed):
+        x = torch.randn(2, 12, 10, 8, generator=torch.Generator().manual_seed(seed))
+        return x, hipnn.conv2d(x.to(dev).requires_grad_(True), w, None, (1, 1), (1, 1))
+
+    _, y0 = fwd(1)
+    dy = torch.randn(y0.shape, generator=g)
+    y0.backward(dy.to(dev), retain_graph=True)      # released by the backward; the graph (and its finaliser) stays alive through y0
+    xa, ya = fwd(2)                                  # takes the entry step 0 released
+    ent_a = ya.grad_fn.xp_ent
+    assert ent_a is y0.grad_fn.xp_ent and ent_a[1] and ya.grad_fn.xp_gen == ent_a[2] != y0.grad_fn.xp_gen
+    with pytest.raises(RuntimeError, match="later forward"):
+        y0.backward(dy.to(dev))                      # step 0's node no longer owns the map
+    del y0
+    gc.collect()                                     # step 0's finaliser fires: wrong generation, the entry stays A's
+    assert ent_a[1]
+    xb, yb = fwd(3)
+    assert yb.grad_fn.xp_ent is not ent_a            # B got its own map, A's input is intact
+    w.grad = None
+    ya.backward(dy.to(dev))
+    wr = w.detach().double().cpu().requires_grad_(True)
+    F.conv2d(xa.double().permute(0, 3, 1, 2), wr, None, padding=1).permute(0, 2, 3, 1).backward(dy.double())
+    err = (w.grad.double().cpu() - wr.grad).abs().max().item() / wr.grad.abs().max().item()
+    assert err < 2e-5, err
+    assert not ent_a[1] and yb.grad_fn.xp_ent[1]     # A released its own entry, B's is still held

@@ -177,6 +177,45 @@ def test_train_step_matches_reference_train_epoch_iteration():
             np.testing.assert_allclose(got, g[k], atol=2e-6, err_msg=k)
 
 
+def test_six_step_trajectory_matches_the_reference_train_epoch_and_scheduler():
+    """tests/golden/trajectory.npz = six optimizer steps through the reference's own train_epoch + per-epoch CyclicLR (gen_trajectory).
+    The oracle's train_step, carried from step to step with ONE AdamW and the scheduler stepped after every third pack, must land on
+    the same losses, learning rates and weights — what pins steps 2..6 (bias correction at t > 1, the scheduler writing lr)."""
+    g = load("trajectory.npz")
+    cfg = W.W2VConfig.tiny()
+    ssl = W.init_state(cfg, seed=11)
+    head = {k[3:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("sd:") and "first_bn" not in k}
+    max_lr, min_lr, wd = (float(v) for v in g["hyper"])
+    opt = sched = None
+    step = 0
+    for ep in range(2):
+        for i in range(3):
+            x = torch.from_numpy(g["x"][step, 0]).transpose(0, 1).contiguous()          # [1, L, V] pack -> [V, L] (main.py:59-61)
+            y = torch.from_numpy(g["y"][step]).view(-1)
+            if opt is None:
+                # the first call builds the optimizer over the oracle's tensors (AdamW(lr=max_lr), then CyclicLR writes base_lr: main.py:339-341);
+                # it must exist BEFORE the first step runs, so do a zero-cost construction through train_step's own path
+                params = [ssl[n] for n, _, tr in W.param_shapes(cfg) if tr] + list(head.values())
+                opt = torch.optim.AdamW(params, lr=max_lr, weight_decay=wd)
+                sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=min_lr, max_lr=max_lr, step_size_up=3, mode="exp_range", gamma=0.85,
+                                                          cycle_momentum=False)
+            assert abs(opt.param_groups[0]["lr"] - float(g["lr"][step])) < 1e-15
+            losses, _, _, _ = OH.train_step(ssl, head, cfg, x, y, loss_type=1, opt_state=opt)
+            for j, k in enumerate(("L_CE", "L_CF1", "L_CF2")):
+                ref = float(g["losses"][step, j])
+                assert abs(losses[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (step, k, losses[k], ref)
+            for k in g.files:
+                if k.startswith("w:"):
+                    name = k[2:]
+                    got = (ssl[name[len("ssl_model.model."):]] if name.startswith("ssl_model.model.") else head[name]).detach().numpy()
+                    ref = g[k][step]
+                    assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3) + 1e-6, (step, name, np.abs(got - ref).max())
+            step += 1
+        sched.step()
+    ep_rows = g["epochs"]          # train_epoch's own returns: running loss = the sum of the three steps' totals
+    assert abs(ep_rows[0, 0] - g["losses"][:3].sum()) < 1e-4 and abs(ep_rows[1, 0] - g["losses"][3:].sum()) < 1e-4
+
+
 def test_eer_known_answers():
     g = load("eer.npz")
     for tag, full in (("la19_conf3", 0.0288370), ("itw_conf3", 0.0450978)):

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     const int Ns[4] = {3072, 1024, 4096, 1024}, Ks[4] = {1024, 1024, 1024, 4096};
     for (int i = 0; i < 4; ++i) {
         cases.push_back({std::string(nm[i]) + " fwd", M, Ns[i], Ks[i], false, false, 1, i == 2 ? 1 : (i == 0 ? 0 : 2)});
-        cases.push_back({std::string(nm[i]) + " dgrad", M, Ks[i], Ns[i], false, true, 1, 0});
+        cases.push_back({std::string(nm[i]) + " dgrad", M, Ks[i], Ns[i], false, true, 1, i == 3 ? 3 : 0});      // fc2's data gradient: x gelu'(R)
         for (int sk : {2, 4}) cases.push_back({std::string(nm[i]) + " wgrad sk" + std::to_string(sk), Ns[i], Ks[i], M, true, true, sk, 0});
     }
     cases.push_back({"conv2 fwd", B * 6399, 512, 1536, false, false, 1, 0});
@@ -58,14 +58,16 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dB[i], h.data() + (i * 1931 + 7) % 4096, maxB * 2, hipMemcpyHostToDevice));
     }
     CK(hipMalloc(&dC2, maxC * 2)); CK(hipMalloc(&dBias, 65536 * 4)); CK(hipMalloc(&dR, maxC * 4));
-    CK(hipMemset(dBias, 0, 65536 * 4)); CK(hipMemset(dR, 0, maxC * 4));
+    CK(hipMemset(dBias, 0, 65536 * 4)); CK(hipMemset(dR, 0, maxC * 4)); CK(hipMemset(dC2, 0x3F, maxC * 2));      // bf16 0x3F3F = 0.746
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<char> out0, out1;
 
     struct Var { const char* name; int flags; };
-    const Var vars[] = {{"t128", SCL_GEMM_NO_W8 | SCL_GEMM_NO_P8 | SCL_GEMM_NO_BIG}, {"p8", SCL_GEMM_FORCE_P8 | SCL_GEMM_NO_W8}, {"w8", SCL_GEMM_FORCE_W8}};
-    const int NV = 3;
+    const Var vars3[] = {{"t128", SCL_GEMM_NO_W8 | SCL_GEMM_NO_P8 | SCL_GEMM_NO_BIG}, {"p8", SCL_GEMM_FORCE_P8 | SCL_GEMM_NO_W8}, {"w8", SCL_GEMM_FORCE_W8}};
+    const Var vars1[] = {{"w8", SCL_GEMM_FORCE_W8}, {"", 0}, {"", 0}};
+    const Var* vars = getenv("GEMM_BENCH_W8_ONLY") ? vars1 : vars3;
+    const int NV = getenv("GEMM_BENCH_W8_ONLY") ? 1 : 3;      // W8_ONLY: only the automatic choice (vars[0] below), e.g. under rocprofv3 --pmc
     printf("%-18s %6s %5s %5s | %s\n", "case", "M", "N", "K", "variant: us TFLOP/s ... | bitwise vs t128");
     for (auto& c : cases) {
         if (only && c.name.find(only) == std::string::npos) continue;
@@ -77,7 +79,8 @@ int main(int argc, char** argv) {
             d.alpha = 1.f;
             d.flags = vflags | (c.at ? SCL_GEMM_A_T : 0) | (c.bt ? SCL_GEMM_B_T : 0);
             if (c.splitk > 1) { d.flags |= SCL_GEMM_C_F32; d.c_split_stride = (int64_t)c.M * c.N; }
-            if (c.extra == 1) { d.flags |= SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (1 << SCL_GEMM_ACT_SHIFT); d.bias = dBias; d.C2 = dC2; }
+            if (c.extra == 1) { d.flags |= SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT); d.bias = dBias; d.C2 = dC2; }      // fc1 forward as the encoder launches it
+            if (c.extra == 3) { d.flags |= (2 << SCL_GEMM_RMODE_SHIFT) | (4 << SCL_GEMM_RACT_SHIFT); d.R = dC2; }                              // fc2 data gradient x stored gelu' (bf16)
             if (c.extra == 2) { d.flags |= SCL_GEMM_HAS_BIAS | SCL_GEMM_C_F32 | SCL_GEMM_R_F32 | (1 << SCL_GEMM_RMODE_SHIFT); d.bias = dBias; d.R = dR; }
             return d;
         };
@@ -110,7 +113,8 @@ int main(int argc, char** argv) {
             med[v] = t[v][t[v].size() / 2];
             printf(" %s %7.1f us %6.0f TF |", vars[v].name, med[v], fl / med[v] / 1e6);
         }
-        printf(" w8/t128 x%.2f  bitwise p8:%d w8:%d\n", med[0] / med[2], (int)same[1], (int)same[2]);
+        if (NV == 3) printf(" w8/t128 x%.2f  bitwise p8:%d w8:%d\n", med[0] / med[2], (int)same[1], (int)same[2]);
+        else printf("\n");
         if (getenv("STAMPS")) {   // one stamped launch of the wide kernel: where a block's time goes
             SclGemmDesc d = desc(1, SCL_GEMM_FORCE_W8 | SCL_GEMM_STAMPS);
             scl_gemm_bf16(&d, st); CK(hipStreamSynchronize(st));
