@@ -58,7 +58,7 @@ int scl_prof_reserve(int kid, int n_pairs);
 int scl_prof_read(int kid, int64_t* n_launches, double* total_ms, double* total_flops);
 /* The same launches one by one, in issue order (call it before scl_prof_read, which recycles the events): ms[i] and eight int32 per
  * launch — M, N, K, flags, batch x split-K, kernel variant (0: 128 x 128, 1 / 2: wide ping-pong / single-barrier, 3: two-per-CU,
- * 4: grouped weight gradients [M, N, K of the first member, flags = tiles], 5: pos-conv), 0, 0.  *n_launches = how many there are
+ * 4: grouped weight gradients [M, N, K of the first member, flags = tiles], 5: pos-conv, 6: the 112-row wide tile), 0, 0.  *n_launches = how many there are
  * (also when cap is smaller).  tools/gemm_classes.py builds profiles/r6_gemm_classes.txt from it. */
 int scl_prof_read_launches(int kid, int cap, float* ms, int32_t* meta8, int64_t* n_launches);
 

@@ -123,12 +123,72 @@ def run_epoch(loader, model, optimizer, device, config, train):
     return float(total_sum), float(correct) / max(n_total, 1.0) * 100.0, detail
 
 
-def _score_loop(dataset, model, device, batch_size, fn):
-    loader = DataLoader(dataset, batch_size, shuffle=False, drop_last=False)
+def _score_loop(dataset, model, device, batch_size, fn, workers=None):
+    """Scoring loop of produce_evaluation_file / _prediction_file / _emb_file (reference main.py:120-214: a DataLoader over Dataset_for_eval).
+    Round 6: the reference decodes on DataLoader workers; here a thread pool decodes and pads the files (the FLAC decoder is C behind ctypes:
+    no GIL), batches are assembled in pinned memory and uploaded asynchronously, and `fn` — which reads results back to the host — runs for
+    batch i - 1 AFTER batch i has been launched, so the GPU never waits for a file or for the host's result formatting.
+    Order of `fn` calls and of the lines they write = protocol order, as before.  SCL_EVAL_THREADS=1: the plain loop."""
+    from concurrent.futures import ThreadPoolExecutor
+    from collections import deque
+    if workers is None:
+        workers = max(1, int(os.environ.get("SCL_EVAL_THREADS", "8")))
     model.eval()
-    with torch.no_grad():
-        for batch_x, utt_id in loader:
-            fn(model(batch_x.to(device)), list(utt_id))
+    n = len(dataset)
+    if workers <= 1 or n == 0:
+        loader = DataLoader(dataset, batch_size, shuffle=False, drop_last=False)
+        with torch.no_grad():
+            for batch_x, utt_id in loader:
+                fn(model(batch_x.to(device)), list(utt_id))
+        return
+    use_gpu = torch.device(device).type == "cuda"
+    ahead = max(4 * batch_size, 4 * workers)            # items decoded or being decoded beyond the batch in flight
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(min(old_switch, 5e-4))        # the launch thread shares the interpreter lock with the decoders (scl_amd/prefetch.py)
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="scl-eval") as pool, torch.no_grad():
+        futs = deque()
+        nxt = 0
+
+        def top_up():
+            nonlocal nxt
+            while nxt < n and len(futs) < ahead:
+                futs.append(pool.submit(dataset.__getitem__, nxt))
+                nxt += 1
+        top_up()
+        pending = None                                   # (host copies of the previous batch's results, their event, its ids)
+
+        def to_host(res):
+            # results -> pinned host tensors by an ASYNCHRONOUS copy queued right behind the batch's own kernels.  (A `.cpu()` inside
+            # `fn` is a blocking copy that is ordered behind everything queued so far — i.e. behind the NEXT batch's forward: the
+            # host then sat out every forward and assembled the following batch with the GPU idle: 70 instead of 44 ms per batch.)
+            def one(t):
+                if not (torch.is_tensor(t) and t.is_cuda):
+                    return t
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                return h
+            out = tuple(one(t) for t in res) if isinstance(res, (tuple, list)) else one(res)
+            ev = torch.cuda.Event() if use_gpu else None
+            if ev is not None:
+                ev.record()
+            return out, ev
+        while futs:
+            items = [futs.popleft().result() for _ in range(min(batch_size, len(futs)))]
+            top_up()
+            xs, ids = [it[0] for it in items], [it[1] for it in items]
+            host = torch.empty((len(xs),) + tuple(xs[0].shape), dtype=xs[0].dtype, pin_memory=use_gpu)
+            torch.stack(xs, out=host)
+            res, ev = to_host(model(host.to(device, non_blocking=True)))
+            if pending is not None:
+                if pending[1] is not None:
+                    pending[1].synchronize()             # batch i - 1's copy: done long ago, batch i is what the GPU works on now
+                fn(pending[0], pending[2])
+            pending = (res, ev, ids)
+        if pending is not None:
+            if pending[1] is not None:
+                pending[1].synchronize()
+            fn(pending[0], pending[2])
+    sys.setswitchinterval(old_switch)
 
 
 def produce_evaluation_file(dataset, model, device, save_path, batch_size=10):
@@ -308,6 +368,10 @@ def main(argv=None):
         return 0
 
     repeat = args.padding_type == "repeat"
+    # RawBoost parameter draws of the pack builder: "fast" = every builder thread's own numpy Generator, batched closed-form filter design,
+    # ISD positions without a 64000-element permutation per clip (same distributions; scl_amd/augment.py); SCL_PACK_SAMPLER=reference =
+    # the reference's draw-for-draw order on the global np.random stream (what the pack goldens pin; 0.5 ms more host time per clip)
+    args.rawboost_sampler = os.environ.get("SCL_PACK_SAMPLER", "fast")
     d_label_trn, file_train = genList(dir_meta=proto, is_train=True, is_eval=False, is_dev=False)
     print("no. of training trials", len(file_train))
     train_set = Dataset_for(args, list_IDs=file_train, labels=d_label_trn, base_dir=args.database_path + "/", algo=args.algo,

@@ -8,6 +8,8 @@ GPU: every stage below is a HIP kernel from csrc/augment.hip reached through the
 """
 import math
 
+import threading
+
 import numpy as np
 import torch
 from scipy import signal
@@ -102,12 +104,30 @@ def _draw_ssi(a, L, fs):
 # is NOT draw-for-draw reproducible against the reference, and (b) all notch filters of a batch are designed at once:
 # firwin in closed form, the five band-stop sections multiplied in the frequency domain, freqz = the first 512 bins of a
 # 1024-point FFT.  ~25x less host time per clip than the per-filter scipy calls of the reference-compatible sampler.
-_FAST_RNG = np.random.default_rng(1234)
+# A numpy Generator is not safe under concurrent draws, and the pack builder runs on several threads (scl_amd/prefetch.py): every thread
+# gets its own generator, spawned from one seed sequence in the order the threads first ask (the launch thread of bench.py is always the
+# first: its stream is np.random.default_rng(seed)'s own, as before).
+_FAST_ROOT = {"seq": np.random.SeedSequence(1234), "epoch": 0, "first": True}
+_FAST_LOCAL = threading.local()
+_FAST_LOCK = threading.Lock()
+
+
+def _fast_rng():
+    loc = _FAST_LOCAL
+    if getattr(loc, "epoch", -1) != _FAST_ROOT["epoch"]:
+        with _FAST_LOCK:
+            if _FAST_ROOT["first"]:
+                loc.rng = np.random.default_rng(_FAST_ROOT["seq"])          # == default_rng(seed) for the first (main) thread
+                _FAST_ROOT["first"] = False
+            else:
+                loc.rng = np.random.default_rng(_FAST_ROOT["seq"].spawn(1)[0])
+            loc.epoch = _FAST_ROOT["epoch"]
+    return loc.rng
 
 
 def seed_fast_sampler(seed):
-    global _FAST_RNG
-    _FAST_RNG = np.random.default_rng(seed)
+    with _FAST_LOCK:
+        _FAST_ROOT.update(seq=np.random.SeedSequence(seed), epoch=_FAST_ROOT["epoch"] + 1, first=True)
 
 
 def design_notch_filters(fc, bw, c, G, fs):
@@ -142,7 +162,7 @@ def design_notch_filters(fc, bw, c, G, fs):
 
 
 def _fast_notch(a, n, minG, maxG, fs):
-    r = _FAST_RNG
+    r = _fast_rng()
     fc = r.uniform(a.minF, a.maxF, (n, a.nBands))
     bw = r.uniform(a.minBW, a.maxBW, (n, a.nBands))
     c = r.uniform(a.minCoeff, a.maxCoeff, (n, a.nBands)).astype(np.int64)   # int() truncation, then made odd (RawBoost.py:33-36)
@@ -162,7 +182,7 @@ def _fast_lnl(a, n, fs):
 
 
 def _fast_isd(a, n, L):
-    r = _FAST_RNG
+    r = _fast_rng()
     draws = []
     for beta in r.uniform(0, a.P, n):
         k = int(L * (beta / 100))
@@ -172,7 +192,7 @@ def _fast_isd(a, n, L):
 
 
 def _fast_ssi(a, n, L, fs):
-    r = _FAST_RNG
+    r = _fast_rng()
     taps = _fast_notch(a, n, a.minG, a.maxG, fs)
     snr = r.uniform(a.SNRmin, a.SNRmax, n)
     return [(r.standard_normal(L).astype(np.float32), taps[i], float(snr[i])) for i in range(n)]

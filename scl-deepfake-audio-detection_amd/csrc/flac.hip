@@ -17,7 +17,21 @@ namespace {
 struct Bits {
     const uint8_t* p; size_t n, pos = 0; uint64_t acc = 0; int have = 0; bool bad = false;
     Bits(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+    // after fill(): have >= 57.  Fast path (round 6: the byte loop was a third of the decoder's time): one unaligned big-endian 8-byte
+    // load, of which the (64 - have) / 8 whole bytes that fit are taken.
     inline void fill() {
+        if (have > 56) return;
+        if (pos + 8 <= n) {
+            uint64_t w;
+            memcpy(&w, p + pos, 8);
+            w = __builtin_bswap64(w);
+            const int take = (64 - have) >> 3;          // 1 .. 8 bytes
+            const int tot = have + 8 * take;            // 57 .. 64 valid bits afterwards; the partial byte behind them stays unread
+            acc |= (w >> have) & (tot >= 64 ? ~0ull : ~(~0ull >> tot));
+            pos += (size_t)take;
+            have += 8 * take;
+            return;
+        }
         while (have <= 56) {
             uint64_t b = 0;
             if (pos < n) b = p[pos]; else if (pos >= n + 8) { bad = true; }
@@ -49,6 +63,26 @@ struct Bits {
             acc <<= (z + 1); have -= (z + 1);
             return q;
         }
+    }
+    // one Rice-coded residual with parameter k (< 32): unary quotient, stop bit, k remainder bits — from ONE refill when they fit
+    // the 57+ bits a fill() guarantees (quotients are short: the encoder picks k so that they average ~1)
+    inline int32_t read_rice(int k) {
+        fill();
+        uint32_t u;
+        if (acc != 0) {
+            const int z = __builtin_clzll(acc);
+            if (z + 1 + k <= have) {
+                const uint64_t a = acc << (z + 1);
+                const uint32_t rem = k ? (uint32_t)(a >> (64 - k)) : 0u;
+                acc = k ? (a << k) : a;
+                have -= z + 1 + k;
+                u = ((uint32_t)z << k) | rem;
+                return (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+            }
+        }
+        const uint32_t q = read_unary();
+        u = (q << k) | read(k);
+        return (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
     }
     inline size_t byte_pos() const { return pos - (size_t)(have / 8); }     // valid when aligned
     inline void align() { const int r = have & 7; acc <<= r; have -= r; }
@@ -83,32 +117,40 @@ struct Md5 {
     uint8_t buf[64]; size_t fill = 0; uint64_t total = 0;
     static inline uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
     void block(const uint8_t* m) {
-        static const uint32_t K[64] = {
-            0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,
-            0x6b901122,0xfd987193,0xa679438e,0x49b40821,0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,
-            0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,
-            0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
-            0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,
-            0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391};
-        static const int S[64] = {7,12,17,22,7,12,17,22,7,12,17,22,7,12,17,22,5,9,14,20,5,9,14,20,5,9,14,20,5,9,14,20,
-                                  4,11,16,23,4,11,16,23,4,11,16,23,4,11,16,23,6,10,15,21,6,10,15,21,6,10,15,21,6,10,15,21};
         uint32_t w[16];
-        for (int i = 0; i < 16; ++i) w[i] = (uint32_t)m[4 * i] | ((uint32_t)m[4 * i + 1] << 8) | ((uint32_t)m[4 * i + 2] << 16) | ((uint32_t)m[4 * i + 3] << 24);
+        memcpy(w, m, 64);      // little-endian host (x86-64 / the image's only target)
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
-        for (int i = 0; i < 64; ++i) {
-            uint32_t f; int g;
-            if (i < 16) { f = (b & c) | (~b & d); g = i; }
-            else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
-            else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
-            else { f = c ^ (b | ~d); g = (7 * i) & 15; }
-            const uint32_t t = d; d = c; c = b;
-            b = b + rol(a + f + K[i] + w[g], S[i]);
-            a = t;
-        }
+#define MD5_F(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
+#define MD5_G(x, y, z) ((y) ^ ((z) & ((x) ^ (y))))
+#define MD5_H(x, y, z) ((x) ^ (y) ^ (z))
+#define MD5_I(x, y, z) ((y) ^ ((x) | ~(z)))
+#define MD5_STEP(f, a, b, c, d, x, t, s) (a) += f((b), (c), (d)) + (x) + (t); (a) = rol((a), (s)); (a) += (b);
+        MD5_STEP(MD5_F, a, b, c, d, w[0], 0xd76aa478, 7) MD5_STEP(MD5_F, d, a, b, c, w[1], 0xe8c7b756, 12) MD5_STEP(MD5_F, c, d, a, b, w[2], 0x242070db, 17) MD5_STEP(MD5_F, b, c, d, a, w[3], 0xc1bdceee, 22)
+        MD5_STEP(MD5_F, a, b, c, d, w[4], 0xf57c0faf, 7) MD5_STEP(MD5_F, d, a, b, c, w[5], 0x4787c62a, 12) MD5_STEP(MD5_F, c, d, a, b, w[6], 0xa8304613, 17) MD5_STEP(MD5_F, b, c, d, a, w[7], 0xfd469501, 22)
+        MD5_STEP(MD5_F, a, b, c, d, w[8], 0x698098d8, 7) MD5_STEP(MD5_F, d, a, b, c, w[9], 0x8b44f7af, 12) MD5_STEP(MD5_F, c, d, a, b, w[10], 0xffff5bb1, 17) MD5_STEP(MD5_F, b, c, d, a, w[11], 0x895cd7be, 22)
+        MD5_STEP(MD5_F, a, b, c, d, w[12], 0x6b901122, 7) MD5_STEP(MD5_F, d, a, b, c, w[13], 0xfd987193, 12) MD5_STEP(MD5_F, c, d, a, b, w[14], 0xa679438e, 17) MD5_STEP(MD5_F, b, c, d, a, w[15], 0x49b40821, 22)
+        MD5_STEP(MD5_G, a, b, c, d, w[1], 0xf61e2562, 5) MD5_STEP(MD5_G, d, a, b, c, w[6], 0xc040b340, 9) MD5_STEP(MD5_G, c, d, a, b, w[11], 0x265e5a51, 14) MD5_STEP(MD5_G, b, c, d, a, w[0], 0xe9b6c7aa, 20)
+        MD5_STEP(MD5_G, a, b, c, d, w[5], 0xd62f105d, 5) MD5_STEP(MD5_G, d, a, b, c, w[10], 0x02441453, 9) MD5_STEP(MD5_G, c, d, a, b, w[15], 0xd8a1e681, 14) MD5_STEP(MD5_G, b, c, d, a, w[4], 0xe7d3fbc8, 20)
+        MD5_STEP(MD5_G, a, b, c, d, w[9], 0x21e1cde6, 5) MD5_STEP(MD5_G, d, a, b, c, w[14], 0xc33707d6, 9) MD5_STEP(MD5_G, c, d, a, b, w[3], 0xf4d50d87, 14) MD5_STEP(MD5_G, b, c, d, a, w[8], 0x455a14ed, 20)
+        MD5_STEP(MD5_G, a, b, c, d, w[13], 0xa9e3e905, 5) MD5_STEP(MD5_G, d, a, b, c, w[2], 0xfcefa3f8, 9) MD5_STEP(MD5_G, c, d, a, b, w[7], 0x676f02d9, 14) MD5_STEP(MD5_G, b, c, d, a, w[12], 0x8d2a4c8a, 20)
+        MD5_STEP(MD5_H, a, b, c, d, w[5], 0xfffa3942, 4) MD5_STEP(MD5_H, d, a, b, c, w[8], 0x8771f681, 11) MD5_STEP(MD5_H, c, d, a, b, w[11], 0x6d9d6122, 16) MD5_STEP(MD5_H, b, c, d, a, w[14], 0xfde5380c, 23)
+        MD5_STEP(MD5_H, a, b, c, d, w[1], 0xa4beea44, 4) MD5_STEP(MD5_H, d, a, b, c, w[4], 0x4bdecfa9, 11) MD5_STEP(MD5_H, c, d, a, b, w[7], 0xf6bb4b60, 16) MD5_STEP(MD5_H, b, c, d, a, w[10], 0xbebfbc70, 23)
+        MD5_STEP(MD5_H, a, b, c, d, w[13], 0x289b7ec6, 4) MD5_STEP(MD5_H, d, a, b, c, w[0], 0xeaa127fa, 11) MD5_STEP(MD5_H, c, d, a, b, w[3], 0xd4ef3085, 16) MD5_STEP(MD5_H, b, c, d, a, w[6], 0x04881d05, 23)
+        MD5_STEP(MD5_H, a, b, c, d, w[9], 0xd9d4d039, 4) MD5_STEP(MD5_H, d, a, b, c, w[12], 0xe6db99e5, 11) MD5_STEP(MD5_H, c, d, a, b, w[15], 0x1fa27cf8, 16) MD5_STEP(MD5_H, b, c, d, a, w[2], 0xc4ac5665, 23)
+        MD5_STEP(MD5_I, a, b, c, d, w[0], 0xf4292244, 6) MD5_STEP(MD5_I, d, a, b, c, w[7], 0x432aff97, 10) MD5_STEP(MD5_I, c, d, a, b, w[14], 0xab9423a7, 15) MD5_STEP(MD5_I, b, c, d, a, w[5], 0xfc93a039, 21)
+        MD5_STEP(MD5_I, a, b, c, d, w[12], 0x655b59c3, 6) MD5_STEP(MD5_I, d, a, b, c, w[3], 0x8f0ccc92, 10) MD5_STEP(MD5_I, c, d, a, b, w[10], 0xffeff47d, 15) MD5_STEP(MD5_I, b, c, d, a, w[1], 0x85845dd1, 21)
+        MD5_STEP(MD5_I, a, b, c, d, w[8], 0x6fa87e4f, 6) MD5_STEP(MD5_I, d, a, b, c, w[15], 0xfe2ce6e0, 10) MD5_STEP(MD5_I, c, d, a, b, w[6], 0xa3014314, 15) MD5_STEP(MD5_I, b, c, d, a, w[13], 0x4e0811a1, 21)
+        MD5_STEP(MD5_I, a, b, c, d, w[4], 0xf7537e82, 6) MD5_STEP(MD5_I, d, a, b, c, w[11], 0xbd3af235, 10) MD5_STEP(MD5_I, c, d, a, b, w[2], 0x2ad7d2bb, 15) MD5_STEP(MD5_I, b, c, d, a, w[9], 0xeb86d391, 21)
+#undef MD5_STEP
+#undef MD5_F
+#undef MD5_G
+#undef MD5_H
+#undef MD5_I
         h[0] += a; h[1] += b; h[2] += c; h[3] += d;
     }
     void update(const uint8_t* p, size_t n) {
         total += n;
+        if (fill == 0) while (n >= 64) { block(p); p += 64; n -= 64; }      // whole blocks straight from the source
         while (n) {
             const size_t k = 64 - fill < n ? 64 - fill : n;
             memcpy(buf + fill, p, k); fill += k; p += k; n -= k;
@@ -179,15 +221,47 @@ bool decode_residual(Bits& br, int32_t* out, int blocksize, int pred_order) {
             const int nb = (int)br.read(5);
             for (int k = 0; k < count; ++k) out[i++] = br.read_signed(nb);
         } else {
-            for (int k = 0; k < count; ++k) {
-                const uint32_t q = br.read_unary();
-                const uint32_t u = (q << param) | br.read(param);
-                out[i++] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
-            }
+            for (int k = 0; k < count; ++k) out[i++] = br.read_rice(param);
         }
         if (br.bad) return false;
     }
     return i == blocksize;
+}
+
+// s[i] += (sum_j coef[j] * s[i - 1 - j]) >> shift: the order as a compile-time constant for the orders encoders use (the loop is one
+// dependent chain per sample; unrolled, the products of the older samples run ahead of it)
+template <int ORDER>
+void lpc_restore_n(int32_t* s, int blocksize, const int32_t* coef, int shift) {
+    int64_t c[ORDER];
+    for (int j = 0; j < ORDER; ++j) c[j] = coef[j];
+    for (int i = ORDER; i < blocksize; ++i) {
+        int64_t p = 0;
+#pragma unroll
+        for (int j = 0; j < ORDER; ++j) p += c[j] * s[i - 1 - j];
+        s[i] = (int32_t)(s[i] + (p >> shift));
+    }
+}
+void lpc_restore(int32_t* s, int blocksize, int order, const int32_t* coef, int shift) {
+    switch (order) {
+        case 1: return lpc_restore_n<1>(s, blocksize, coef, shift);
+        case 2: return lpc_restore_n<2>(s, blocksize, coef, shift);
+        case 3: return lpc_restore_n<3>(s, blocksize, coef, shift);
+        case 4: return lpc_restore_n<4>(s, blocksize, coef, shift);
+        case 5: return lpc_restore_n<5>(s, blocksize, coef, shift);
+        case 6: return lpc_restore_n<6>(s, blocksize, coef, shift);
+        case 7: return lpc_restore_n<7>(s, blocksize, coef, shift);
+        case 8: return lpc_restore_n<8>(s, blocksize, coef, shift);
+        case 9: return lpc_restore_n<9>(s, blocksize, coef, shift);
+        case 10: return lpc_restore_n<10>(s, blocksize, coef, shift);
+        case 11: return lpc_restore_n<11>(s, blocksize, coef, shift);
+        case 12: return lpc_restore_n<12>(s, blocksize, coef, shift);
+        default: break;
+    }
+    for (int i = order; i < blocksize; ++i) {
+        int64_t p = 0;
+        for (int j = 0; j < order; ++j) p += (int64_t)coef[j] * s[i - 1 - j];
+        s[i] = (int32_t)(s[i] + (p >> shift));
+    }
 }
 
 bool decode_subframe(Bits& br, int32_t* s, int blocksize, int bps) {
@@ -206,16 +280,12 @@ bool decode_subframe(Bits& br, int32_t* s, int blocksize, int bps) {
         for (int i = 0; i < order; ++i) s[i] = br.read_signed(bps);
         if (!decode_residual(br, s, blocksize, order)) return false;
         // the sums can exceed 32 bits for 32-bit streams only in malformed input; int64 keeps it defined
-        for (int i = order; i < blocksize; ++i) {
-            int64_t p = 0;
-            switch (order) {
-                case 1: p = s[i - 1]; break;
-                case 2: p = 2 * (int64_t)s[i - 1] - s[i - 2]; break;
-                case 3: p = 3 * (int64_t)s[i - 1] - 3 * (int64_t)s[i - 2] + s[i - 3]; break;
-                case 4: p = 4 * (int64_t)s[i - 1] - 6 * (int64_t)s[i - 2] + 4 * (int64_t)s[i - 3] - s[i - 4]; break;
-                default: break;
-            }
-            s[i] = (int32_t)(s[i] + p);
+        switch (order) {      // (the switch outside the loops)
+            case 1: for (int i = 1; i < blocksize; ++i) s[i] = (int32_t)(s[i] + (int64_t)s[i - 1]); break;
+            case 2: for (int i = 2; i < blocksize; ++i) s[i] = (int32_t)(s[i] + 2 * (int64_t)s[i - 1] - s[i - 2]); break;
+            case 3: for (int i = 3; i < blocksize; ++i) s[i] = (int32_t)(s[i] + 3 * (int64_t)s[i - 1] - 3 * (int64_t)s[i - 2] + s[i - 3]); break;
+            case 4: for (int i = 4; i < blocksize; ++i) s[i] = (int32_t)(s[i] + 4 * (int64_t)s[i - 1] - 6 * (int64_t)s[i - 2] + 4 * (int64_t)s[i - 3] - s[i - 4]); break;
+            default: break;
         }
     } else if (type >= 32) {
         const int order = (type & 31) + 1;
@@ -228,11 +298,7 @@ bool decode_subframe(Bits& br, int32_t* s, int blocksize, int bps) {
         int32_t coef[32];
         for (int j = 0; j < order; ++j) coef[j] = br.read_signed(prec);
         if (!decode_residual(br, s, blocksize, order)) return false;
-        for (int i = order; i < blocksize; ++i) {
-            int64_t p = 0;
-            for (int j = 0; j < order; ++j) p += (int64_t)coef[j] * s[i - 1 - j];
-            s[i] = (int32_t)(s[i] + (p >> shift));
-        }
+        lpc_restore(s, blocksize, order, coef, shift);
     } else {
         return false;      // reserved subframe type
     }
@@ -351,9 +417,14 @@ extern "C" int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* ou
             const int64_t total = written * si.channels;
             for (int64_t i0 = 0; i0 < total; i0 += 65536) {
                 const int64_t m = total - i0 < 65536 ? total - i0 : 65536;
-                for (int64_t i = 0; i < m; ++i) {
-                    const uint32_t v = (uint32_t)out[i0 + i];
-                    for (int b = 0; b < bytes; ++b) tmp[(size_t)i * bytes + b] = (uint8_t)(v >> (8 * b));
+                if (bytes == 2) {
+                    int16_t* t16 = reinterpret_cast<int16_t*>(tmp.data());
+                    for (int64_t i = 0; i < m; ++i) t16[i] = (int16_t)out[i0 + i];
+                } else {
+                    for (int64_t i = 0; i < m; ++i) {
+                        const uint32_t v = (uint32_t)out[i0 + i];
+                        for (int b = 0; b < bytes; ++b) tmp[(size_t)i * bytes + b] = (uint8_t)(v >> (8 * b));
+                    }
                 }
                 md.update(tmp.data(), (size_t)m * bytes);
             }

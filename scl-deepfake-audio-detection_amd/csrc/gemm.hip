@@ -738,7 +738,7 @@ extern "C" int scl_gemm_uses_wide_tiles(const SclGemmDesc* dp) {
     const bool at = dp->flags & SCL_GEMM_A_T, bt = dp->flags & SCL_GEMM_B_T;
     const long long zdim = (long long)dp->nb1 * dp->nb2 * dp->splitk;
     if (gemm_pick_x2(k, at, bt, *dp, zdim, &plan)) return 3;
-    return gemm_pick_w8(k, at, bt, *dp, zdim, &plan) ? 1 + plan.variant : 0;
+    return gemm_pick_w8(k, at, bt, *dp, zdim, &plan) ? (plan.variant == 2 ? 4 : 1 + plan.variant) : 0;      // 4: the 112-row wide tile
 }
 
 // partial rows of the fused column sums (SclGemmDesc.colsum_part): wide tiles of gemm_w8.hip only, one un-batched problem, whole 8-column
@@ -748,7 +748,9 @@ static int gemm_colsum_rows(const SclGemmDesc& d) {
     GemmK k; W8Plan plan;
     const bool at = d.flags & SCL_GEMM_A_T, bt = d.flags & SCL_GEMM_B_T;
     const bool a_whole = at ? (d.M % 8 == 0) : (d.K % 8 == 0), b_whole = bt ? (d.N % 8 == 0) : (d.K % 8 == 0);
-    if (!a_whole || !b_whole || (d.flags & SCL_GEMM_NO_DMA) || gemm_pick_x2(k, at, bt, d, 1, &plan) || !gemm_pick_w8(k, at, bt, d, 1, &plan)) return 0;
+    SclGemmDesc dq = d;      // plan as the launch WITH the partial rows will be planned (the 112-row tile does not write them: scl_gemm_w8_plan)
+    if (!dq.colsum_part) dq.colsum_part = reinterpret_cast<float*>(16);
+    if (!a_whole || !b_whole || (d.flags & SCL_GEMM_NO_DMA) || gemm_pick_x2(k, at, bt, dq, 1, &plan) || !gemm_pick_w8(k, at, bt, dq, 1, &plan)) return 0;
     return plan.tiles_m * 4;
 }
 extern "C" int scl_gemm_colsum_rows(const SclGemmDesc* dp) { return dp ? gemm_colsum_rows(*dp) : 0; }
@@ -907,7 +909,7 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool x2 = false;
 #endif
         const bool w8 = !x2 && dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
-        prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? 1 + plan.variant : 0));
+        prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? (plan.variant == 2 ? 6 : 1 + plan.variant) : 0));
         if (x2) {
 #ifdef SCL_EXPERIMENTS
             scl_gemm_x2_launch(k, at, bt, plan, zdim, s);

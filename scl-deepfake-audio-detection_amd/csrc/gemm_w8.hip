@@ -396,7 +396,7 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
     constexpr int NRD = RBW + 4, OPA = AT ? 2 : 1, OPB = BT ? 2 : 1;
     // reads issued before quarter 0 / 1 / 2 (cumulative), none before quarter 3: the last read of a set has a quarter of MFMAs to
     // complete before anything waits for it (3 / 3 / 3 / 2 measured equal)
-    constexpr int RQ0 = 4, RQ1 = 8, RQ2 = NRD;
+    constexpr int RQ0 = NRD < 4 ? NRD : 4, RQ1 = NRD < 8 ? NRD : 8, RQ2 = NRD;      // (RBW = 3: seven fragments per set)
     typedef W8SRead<AT, BT, RBW> RD;
     // LDS operations of the first n fragments of a set
     auto ops_upto = [](int n) constexpr { return (n > 0 ? OPB : 0) + (n > 1 ? (n - 1 < RBW ? n - 1 : RBW) * OPA : 0) + (n > RBW + 1 ? (n - RBW - 1) * OPB : 0); };
@@ -473,9 +473,18 @@ __device__ __forceinline__ void w8s_body(const GemmK& d, char* smem, const typen
         const float* bias = (d.flags & SCL_GEMM_HAS_BIAS) ? d.bias + z2 * d.bias_bs2 : nullptr;
         char* wlds = smem + wave * 16384;
         char* wextra = smem + 8 * 16384 + wave * 4096;      // the 32 KiB above the eight transposition blocks: R staging
-        f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
         float* cs0 = d.colsum ? d.colsum + ((long long)(m0 / d.tile_m) * 4 + (wave >> 2) * 2) * d.N : nullptr;
-        w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        if constexpr (RBW >= 4) {
+            f32x4 (&alo)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]);
+            w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, alo, 4, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        } else {      // the 112-row tile's second wave row: three row blocks
+            f32x4 lo[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lo[i][j] = (i < RBW) ? acc[(i < RBW) ? i : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            w8_epilogue_pass<4, ((RBW < 8 && !AT) ? 0x1E : 0)>(d, lo, RBW, wlds, wextra, m0 + ab * 16, n0 + wc * 64, mlimit, cbase, bias, lane, cs0);
+        }
         if (RBW > 4) {
             f32x4 hi[4][4];
 #pragma unroll
@@ -812,6 +821,21 @@ void w8_launch_rb(const GemmK& k, bool at, bool bt, dim3 grid, hipStream_t s, in
     else SCL_LAUNCH((scl_gemm_w8_kernel<true, true, RB0, RB1>), grid, block, W8_LDS, s, k);
 }
 
+// 112-row tiles (4 + 3 row blocks; round 6): the single-barrier loop with K-contiguous A only (forward and data-gradient launches).
+// Why: at M = 32 x 199 = 6368 rows an N = 1024 linear is 31 x 4 = 124 tiles of 208 rows — half the CUs — and ran on the 128 x 128 kernel
+// instead (600 - 735 TFLOP/s); 57 x 4 = 228 tiles of 112 rows fill one round.  Same LDS images, rings and epilogue; rows 112.. of the A
+// image are out-of-range pieces (no traffic).
+void w8_launch_43(const GemmK& k, bool bt, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, false, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_kernel<false, true, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+        attr_set = true;
+    }
+    if (!bt) SCL_LAUNCH((scl_gemm_w8s_kernel<false, false, 4, 3>), grid, dim3(512), W8_LDS, s, k);
+    else SCL_LAUNCH((scl_gemm_w8s_kernel<false, true, 4, 3>), grid, dim3(512), W8_LDS, s, k);
+}
+
 }  // namespace
 
 namespace sclg {
@@ -828,10 +852,17 @@ bool scl_gemm_w8_plan(const GemmK& k, bool at, bool bt, const SclGemmDesc& d, lo
     if (!a_ok || !b_ok || (d.K % BK) != 0) return false;
     const long long tiles_n = (d.N + W8_BN - 1) / W8_BN;
     long long best = -1;
-    for (int v = 0; v < 2; ++v) {
+    // variant 2 = 112-row tiles: K-contiguous A, one un-batched problem, no fused column sums (their partial rows assume two epilogue passes
+    // per wave row), the single-barrier loop (SCL_W8_MODE=0 keeps the ping-pong, which has no 112-row form)
+    // (read per call, like SCL_W8_MODE: the bit-identity tests run the same shapes on both tilings in one process)
+    const char* e43 = getenv("SCL_W8_TILE112");
+    const char* epp = getenv("SCL_W8_MODE");
+    const bool v43_env = !e43 || atoi(e43) != 0, pingpong_env = epp && *epp && atoi(epp) == 0;
+    const bool v43_ok = v43_env && !pingpong_env && !at && zdim == 1 && !d.colsum_part && !(d.flags & SCL_GEMM_STAMPS);
+    for (int v = 0; v < (v43_ok ? 3 : 2); ++v) {
         // the K loop of either tile is bound by the per-CU L2 -> LDS feed (stamps + ablation, profiles/r2_gemm_*): a round costs
         // ~ (tile rows + 256 columns) x K bytes per CU, not the MFMA count
-        const int bm = v == 0 ? 208 : 256;
+        const int bm = v == 0 ? 208 : (v == 1 ? 256 : 112);
         const long long ntm = (d.M + bm - 1) / bm;      // (round 5: 64 tiles of 199 rows instead of 62 of 206 at M = 12736 — a full last round, 3.4 % fewer rows per tile — measured 113.7 vs 112.5 us per launch: no gain, not kept)
         const long long rounds = (ntm * tiles_n * zdim + ncu - 1) / ncu;
         const long long cost = rounds * (bm + W8_BN);
@@ -948,7 +979,8 @@ int scl_gemm_w8_launch(GemmK& k, bool at, bool bt, const W8Plan& plan, long long
         if (plan.variant == 0 && (pv >= 8 || rounds >= 2) && G >= 8 && G < plan.tiles) { mode = 2; g = dim3((unsigned)G, 1, 1); ++w8p_launches; }
     }
 #endif
-    if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
+    if (plan.variant == 2) w8_launch_43(k, bt, g, s);
+    else if (plan.variant == 0) w8_launch_rb<7, 6>(k, at, bt, g, s, mode);
     else w8_launch_rb<8, 8>(k, at, bt, g, s, mode);
     return 0;
 }

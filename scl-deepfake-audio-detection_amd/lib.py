@@ -256,21 +256,44 @@ def _protos():
     }
 
 
+def _bind(lib):
+    for name, (argtypes, restype) in _protos().items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
 def load():
+    """The library through ctypes.CDLL: every call RELEASES the interpreter lock — right for the calls that run long on the host (the FLAC
+    decoder, profiling reads that wait for events)."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SclError("libscl_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the product path)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    protos = _protos()
-    for name, (argtypes, restype) in protos.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
-        fn.argtypes = argtypes
-        fn.restype = restype
-    _lib = lib
-    return lib
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+_launch_lib = None
+
+
+def load_launch():
+    """The same library (same dlopen handle underneath, same state) through ctypes.PyDLL: calls KEEP the interpreter lock.  For the
+    kernel-launch entry points — microseconds each, ~760 per train step: with CDLL every one of them dropped the lock and had to win it
+    back, and beside pack-builder / decoder threads (scl_amd/prefetch.py, main._score_loop) each hand-back could take a whole switch
+    interval — 2 builder threads made a PACKS=3 step 37 % slower, 8 decoder threads left the scoring loop at 1.39 x its forward time
+    (profiles/r6_pack_builder.txt).  SCL_CTYPES_GIL=release: the round-5 behaviour (A/B)."""
+    global _launch_lib
+    if _launch_lib is None:
+        if os.environ.get("SCL_CTYPES_GIL", "hold") == "release":
+            _launch_lib = load()
+        else:
+            load()      # existence check + error message
+            _launch_lib = _bind(ctypes.PyDLL(LIB_PATH))
+    return _launch_lib
 
 
 def all_symbol_names():

@@ -65,8 +65,11 @@ def stream_wait(waiter, signaler):
     _call("scl_stream_wait_stream", ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaler.cuda_stream))
 
 
+_BLOCKING = ("scl_prof_read", "scl_flac", "scl_debug")      # entry points that may wait or run long on the host: they release the interpreter lock
+
+
 def _call(name, *args, keep=None):
-    fn = getattr(L.load(), name)
+    fn = getattr(L.load() if name.startswith(_BLOCKING) else L.load_launch(), name)      # launches keep the lock (lib.load_launch)
     rc = fn(*args)
     if rc != 0:
         L.check(rc, name)

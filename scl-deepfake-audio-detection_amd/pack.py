@@ -16,6 +16,7 @@ File decoding is host IO (out of the kernel path): WAV through the stdlib, anyth
 `soundfile` when it is installed; `set_audio_loader()` lets callers (and the tests) supply arrays.
 """
 import os
+import threading
 import random
 import wave
 
@@ -146,21 +147,36 @@ def _dev(args):
 # view, background_noise.py:40-42): an LRU of device tensors bounded by SCL_AUDIO_BANK_GB (default 8 of the 288 GB).
 _BANK, _BANK_BYTES = {}, 0
 _BANK_LIMIT = int(float(os.environ.get("SCL_AUDIO_BANK_GB", "8")) * (1 << 30))
+_BANK_LOCK = threading.Lock()      # several pack-builder threads (scl_amd/prefetch.py), each on its own HIP stream
 
 
 def bank_tensor(path, sr, args, kind):
-    """kind 'i16': int16 PCM as pydub's AudioSegment.from_file would hold it; 'f32': float waveform (RIRs)."""
+    """kind 'i16': int16 PCM as pydub's AudioSegment.from_file would hold it; 'f32': float waveform (RIRs).
+    A tensor enters the bank only when the stream that made it has finished (once per file: the builder threads that find it there
+    later run on other streams), and every user marks it on its own stream, so an LRU eviction cannot hand its memory out under a kernel
+    that is still reading it."""
     global _BANK_BYTES
     key = (path, sr, kind, str(_dev(args)))
-    t = _BANK.pop(key, None)
+    with _BANK_LOCK:
+        t = _BANK.pop(key, None)
+        if t is not None:
+            _BANK[key] = t        # most recently used last
     if t is None:
-        x = _to_dev(load_audio(path, sr), args)
+        x = _to_dev(load_audio(path, sr), args)          # decode + upload outside the lock: other builders keep going
         t = augment.to_int16(x) if kind == "i16" else x
-        _BANK_BYTES += t.numel() * t.element_size()
-        while _BANK_BYTES > _BANK_LIMIT and _BANK:
-            old = _BANK.pop(next(iter(_BANK)))
-            _BANK_BYTES -= old.numel() * old.element_size()
-    _BANK[key] = t            # most recently used last
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        with _BANK_LOCK:
+            if key in _BANK:                              # another builder decoded the same file meanwhile: keep one copy
+                t = _BANK.pop(key)
+            else:
+                _BANK_BYTES += t.numel() * t.element_size()
+            _BANK[key] = t
+            while _BANK_BYTES > _BANK_LIMIT and len(_BANK) > 1:
+                old = _BANK.pop(next(iter(_BANK)))
+                _BANK_BYTES -= old.numel() * old.element_size()
+    if t.is_cuda:
+        t.record_stream(torch.cuda.current_stream(t.device))
     return t
 
 
@@ -179,8 +195,11 @@ def RawBoost12(x, args, sr=16000, audio_path=None):
 
 
 def RawBoost12_online(x, args, sr=16000):
+    """args.rawboost_sampler = "fast" (main.py's training default, SCL_PACK_SAMPLER): the draws come from the builder thread's own numpy
+    Generator (no 64000-element permutation for the ISD positions, batched closed-form filter design) instead of the reference's
+    draw-for-draw order on the global np.random stream ("reference": the default here, what the pack goldens pin)."""
     xd = _to_dev(x, args)
-    return augment.rawboost_batch(xd[None], args, 5, sr)[0]
+    return augment.rawboost_batch(xd[None], args, 5, sr, sampler=getattr(args, "rawboost_sampler", "reference"))[0]
 
 
 def background_noise_wrapper(x, args, sr=16000, audio_path=None):

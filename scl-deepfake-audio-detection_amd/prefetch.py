@@ -1,26 +1,141 @@
-"""Host pipeline: build pack i+1 (decode, parameter sampling, GPU augmentation) while pack i trains.
+"""Host pipeline: build packs i+1, i+2, ... (decode, parameter sampling, GPU augmentation) while pack i trains.
 
-The reference hides its augmentation behind 8 forked DataLoader workers (main.py:379).  Here the augmentation runs on the GPU, so
-forked workers are out (the parent has initialised the GPU) — a THREAD iterates the DataLoader instead: file decoding, scipy / numpy
-filter design and the C-ABI launches all release the GIL, and the thread issues its kernels on its own HIP stream, so they overlap the
-training step's kernels instead of queueing behind them.  Hand-over is an event: the consumer's stream waits for it and the tensors
-are marked as used on that stream (allocator safety).  Exceptions of the producer surface in the consumer.
+The reference hides its augmentation behind 8 forked DataLoader workers (main.py:379,392).  Here the augmentation runs on the GPU, so
+forked workers are out (the parent has initialised the GPU) — THREADS build the batches instead: file decoding (the FLAC decoder is C
+behind ctypes), numpy filter design and the C-ABI launches all release the GIL, and every builder thread issues its kernels on its OWN
+HIP stream, so they overlap the training step's kernels instead of queueing behind them.
+
+Round 6: one builder thread made 98 packs/s = 1078 utterances/s against a GPU that trains 1500+ — `workers` threads now take the
+DataLoader's own index batches (its batch_sampler: shuffle / drop_last / Subset semantics unchanged) one sequence number each, build them
+concurrently and hand them over IN ORDER.  With one worker (or a loader that is not a plain in-process DataLoader) the loader is simply
+iterated on one thread, as before.  Hand-over is an event: the consumer's stream waits for it and the tensors are marked as used on that
+stream (allocator safety).  Exceptions of a producer surface in the consumer.  Like the reference's workers, concurrent builders draw
+from the process-wide `random` / `np.random` streams in whatever order they run: every draw has the right distribution, the assignment of
+draws to packs is not reproducible (SCL_PREFETCH_THREADS=1 restores one sequential stream).
 """
+import os
 import queue
+import sys
 import threading
 
 import torch
 
 
+def default_workers():
+    """Two builders by default: measured on an MI355X box (profiles/r6_pack_builder.txt) the builder alone peaks at 2 threads (186 packs/s
+    of 11 views; more threads only fight for the interpreter lock), and inside a training run every builder thread competes with the
+    LAUNCH thread for that lock — at PACKS=6 four builders cost the step 31 %, one 8 %."""
+    try:
+        return max(1, int(os.environ.get("SCL_PREFETCH_THREADS", "2")))
+    except ValueError:
+        return 2
+
+
 class Prefetcher:
-    def __init__(self, loader, depth=2, device=None):
+    def __init__(self, loader, depth=2, device=None, workers=None):
         self.loader, self.depth = loader, max(1, int(depth))
         self.device = torch.device(device) if device is not None else None
+        self.workers = default_workers() if workers is None else max(1, int(workers))
 
     def __len__(self):
         return len(self.loader)
 
+    def _parallel_ok(self):
+        ld = self.loader
+        return (self.workers > 1 and isinstance(ld, torch.utils.data.DataLoader) and ld.num_workers == 0 and ld.batch_sampler is not None
+                and not isinstance(ld.dataset, torch.utils.data.IterableDataset))
+
     def __iter__(self):
+        return self._iter_parallel() if self._parallel_ok() else self._iter_serial()
+
+    # ---- several builders, ordered hand-over ------------------------------------------------------------------------------------
+    def _iter_parallel(self):
+        ld = self.loader
+        dataset, collate = ld.dataset, ld.collate_fn
+        use_gpu = self.device is not None and self.device.type == "cuda"
+        batches = iter(ld.batch_sampler)
+        lock, cv = threading.Lock(), threading.Condition()
+        slots = threading.Semaphore(self.depth + self.workers)      # batches built or being built but not yet consumed
+        stop = threading.Event()
+        done = {}                    # sequence number -> (item | exception, event)
+        state = {"next": 0, "end": None}
+
+        def build(wid):
+            side = torch.cuda.Stream(device=self.device) if use_gpu else None
+            try:
+                if use_gpu:
+                    torch.cuda.set_device(self.device)
+                ctx = torch.cuda.stream(side) if use_gpu else _null()
+                with ctx:
+                    while not stop.is_set():
+                        if not slots.acquire(timeout=0.1):
+                            continue
+                        with lock:                      # the sampler is not thread-safe; the sequence number fixes the hand-over order
+                            try:
+                                idxs = next(batches)
+                            except StopIteration:
+                                if state["end"] is None:
+                                    state["end"] = state["next"]
+                                slots.release()
+                                with cv:
+                                    cv.notify_all()
+                                return
+                            seq = state["next"]
+                            state["next"] += 1
+                        try:
+                            item = collate([dataset[i] for i in idxs])
+                            ev = None
+                            if use_gpu:
+                                ev = torch.cuda.Event()
+                                ev.record(side)
+                            res = (item, ev)
+                        except BaseException as e:      # noqa: BLE001 - re-raised in the consumer, in order
+                            res = (e, None)
+                        with cv:
+                            done[seq] = res
+                            cv.notify_all()
+            except BaseException as e:                  # noqa: BLE001 - a failure outside a batch (stream creation, sampler)
+                with cv:
+                    done[-1] = (e, None)
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=build, args=(w,), name="scl-prefetch-%d" % w, daemon=True) for w in range(self.workers)]
+        # The launch thread (the consumer) replays ~760 short C calls per step and needs the interpreter lock back after each: with the
+        # default 5 ms switch interval a builder in a pure-Python stretch keeps it waiting up to 5 ms per hand-over.
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 5e-4))
+        for th in threads:
+            th.start()
+        try:
+            seq = 0
+            while True:
+                with cv:
+                    while seq not in done and -1 not in done and not (state["end"] is not None and seq >= state["end"]):
+                        cv.wait(timeout=0.5)
+                    if -1 in done:
+                        raise done[-1][0]
+                    if seq not in done:
+                        break
+                    item, ev = done.pop(seq)
+                slots.release()
+                if isinstance(item, BaseException):
+                    raise item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for t in _tensors(item):
+                        if t.is_cuda:
+                            t.record_stream(cur)
+                yield item
+                seq += 1
+        finally:
+            stop.set()
+            for th in threads:
+                th.join(timeout=5.0)
+            sys.setswitchinterval(old_switch)
+
+    # ---- one builder iterating the loader (round 3 - 5) ---------------------------------------------------------------------------
+    def _iter_serial(self):
         q = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
         use_gpu = self.device is not None and self.device.type == "cuda"
@@ -51,6 +166,8 @@ class Prefetcher:
                 q.put((e, None))
 
         th = threading.Thread(target=produce, name="scl-prefetch", daemon=True)
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 5e-4))      # see _iter_parallel: the launch thread must not wait 5 ms for the interpreter lock
         th.start()
         try:
             while True:
@@ -69,6 +186,7 @@ class Prefetcher:
         finally:
             stop.set()
             th.join(timeout=5.0)
+            sys.setswitchinterval(old_switch)
 
 
 class _null:

@@ -53,6 +53,11 @@ def check_grads(case, grads, tol=TOL):
                 scale = np.abs(G[key.replace("conv_k.bias", "conv_q.bias")]).max()
                 assert np.abs(G[key]).max() < 1e-4 * max(scale, 1e-6) or scale == 0, k
                 assert np.abs(np.asarray(grads[k])).max() <= max(20 * tol * scale, 1e-30) or scale == 0, k
+            elif k.endswith("conv_k.weight") and np.abs(G[key]).max() < 1e-2 * floor:
+                # a ONE-token sequence: the soft-max over a single key is 1 whatever the key is — this gradient is exactly zero in exact
+                # arithmetic, and what both sides hold is round-off of sums that cancel (1e-6 of the floor's scale): bounded, not compared
+                # (round 6: the comparison had passed by luck until the MLP beside it moved to the exact-f32 kernel and the last bits changed)
+                assert np.abs(np.asarray(grads[k])).max() < 1e-2 * floor, (k, np.abs(np.asarray(grads[k])).max(), floor)
             elif k.endswith("conv_k.weight"):
                 # the key projection's gradient is what survives the same cancellation (only the DIFFERENCES between keys matter to a
                 # soft-max): 100x smaller than the query / value gradients of its layer, so fp32 round-off is 5x larger relative to it

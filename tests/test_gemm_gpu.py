@@ -280,14 +280,17 @@ def test_gemm_speed_report(dev, capsys):
 @pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K,splitk", [(12736, 1024, 1024, 1), (5128, 1288, 256, 1), (2184, 3072, 1024, 1), (1024, 4096, 12736, 4),
                                           (520, 776, 4096, 3), (200, 256, 64, 1), (1000, 200, 512, 1)])
-@pytest.mark.parametrize("loop", ["1", "0"])
+@pytest.mark.parametrize("loop", ["1", "0", "1-no112"])
 def test_wide_tile_kernel_equals_128_tile_kernel(dev, monkeypatch, a_t, b_t, M, N, K, splitk, loop):
     """The wide-tile kernels (gemm_w8.hip: runtime row pitch, 7+6 / 8+8 row blocks per wave row, scalar-offset K advance), both K
     loops (SCL_W8_MODE 1 = single barrier with counted LDS waits, the default for every layout; 0 = two-barrier ping-pong): same K
     order per output element as the 128x128 kernels => bit-identical, on ragged M / N edges, row pitches that are not multiples of
     16, split-K slabs with an uneven last slab, repeated to give a mis-ordered LDS read a chance to show.
     Memory behind the operands is NaN: a fetch past a row limit that is not range-checked to zero would poison the output."""
-    monkeypatch.setenv("SCL_W8_MODE", loop)
+    # round 6: with K-contiguous A the plan may take 112-row tiles (4 + 3 row blocks) for shapes that fill the CUs better that way
+    # ((2184, 3072), (200, 256), (1000, 200) here); "1-no112" keeps those shapes on the 208- / 256-row tiles they were written for
+    monkeypatch.setenv("SCL_W8_MODE", loop[0])
+    monkeypatch.setenv("SCL_W8_TILE112", "0" if loop.endswith("no112") else "1")
     A = _rand((M, K), dev, 51, 0.3); B = _rand((N, K), dev, 52, 0.3)
     def nanpad(mat):
         buf = torch.full((mat.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=dev)
@@ -719,15 +722,22 @@ def test_wide_tile_kernel_utterance_batched_reduction_rows(dev, splitk):
     _close(outs[1].sum(0), want, 2e-3, "conv wgrad")
 
 
-@pytest.mark.parametrize("M,N", [(3 * 208 + 57, 1024), (2 * 208 + 1, 2 * 256 + 72), (12736, 1024)])
-def test_wide_tile_epilogue_kinds_equal_the_128_tile_kernel(dev, monkeypatch, M, N):
+@pytest.mark.parametrize("t112", ["1", "0"])
+@pytest.mark.parametrize("M,N", [(3 * 208 + 57, 1024), (2 * 208 + 1, 2 * 256 + 72), (12736, 1024), (6368, 1024)])
+def test_wide_tile_epilogue_kinds_equal_the_128_tile_kernel(dev, monkeypatch, M, N, t112):
     """The compile-time epilogue kinds of the 208-row single-barrier kernels (gemm_w8_epi.h: 1 bf16 [+ bias], 2 fc1 forward with the
     stored gelu', 3 fc2 data gradient x stored derivative [+ column sums], 4 f32 [+ bias] + f32 residual) against the 128 x 128
     kernel and against the generic run-time-flag loop of the same kernel (SCL_W8_EPI_GENERIC is read once per process, so the
     generic arm is reached through a flag combination no kind matches: dropout with p = 0), bit for bit — ragged last row tile,
     a column edge inside a tile (the element-wise path inside a kind), both weight layouts."""
+    # t112 (round 6): the two ragged shapes and the batch-32 shape (6368 rows: 57 x 4 tiles) plan 112-row tiles (4 + 3 row blocks, the second
+    # wave row's single 3-block epilogue pass) when allowed; "0" keeps them on the 208-row tiles
+    monkeypatch.setenv("SCL_W8_TILE112", t112)
     K = 512
     A = _rand((M, K), dev, 401, 0.3); W = _rand((N, K), dev, 402, 0.05); Wt = W.t().contiguous()
+    if M == 6368:
+        d0 = ops._gemm_desc(ops.Op(A, K), ops.Op(W, K), torch.empty(M, N, dtype=torch.bfloat16, device=dev), M, N, K)
+        assert ops.L.load().scl_gemm_uses_wide_tiles(ops.ctypes.byref(d0)) == (4 if t112 == "1" else 0)      # the AUTOMATIC choice at batch 32
     bias = torch.randn(N, device=dev); Rb = _rand((M, N), dev, 403, 1.0); Rf = torch.randn(M, N, device=dev)
     cases = [
         (dict(), torch.bfloat16, False), (dict(bias=bias), torch.bfloat16, False),                                   # kind 1

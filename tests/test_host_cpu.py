@@ -179,6 +179,57 @@ def test_prefetcher_preserves_order_and_propagates_errors():
     it.close()
 
 
+def test_parallel_prefetcher_builds_on_several_threads_and_hands_over_in_order():
+    """Round 6: `workers` builder threads take the DataLoader's own index batches one sequence number each; whatever order they finish in,
+    the consumer sees the batches in the sampler's order, each exactly once; an exception surfaces at ITS batch; early exit stops the
+    builders; a loader that is not a plain in-process DataLoader falls back to the single-thread path."""
+    import threading
+    import time as _time
+    import pytest as _pt
+    from torch.utils.data import DataLoader, Dataset, Subset
+    from scl_amd.prefetch import Prefetcher
+    seen_threads = set()
+
+    class DS(Dataset):
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at = n, fail_at
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            seen_threads.add(threading.current_thread().name)
+            _time.sleep(0.002 * ((i * 7) % 5))          # uneven build times: later batches finish first
+            if i == self.fail_at:
+                raise ValueError("decode failed at %d" % i)
+            return "u%d" % i, torch.full((4, 2), float(i)), torch.tensor([float(i)])
+
+    ld = DataLoader(DS(41), batch_size=3, shuffle=False, drop_last=False, num_workers=0)
+    got = list(Prefetcher(ld, depth=2, workers=4))
+    ref = list(ld)
+    assert len(got) == len(ref) == 14
+    for a, b in zip(got, ref):
+        assert list(a[0]) == list(b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert len([t for t in seen_threads if t.startswith("scl-prefetch-")]) >= 2
+    # shuffle + drop_last + Subset: the sampler's own semantics — every index of the epoch exactly once
+    ld2 = DataLoader(Subset(DS(50), list(range(5, 45))), batch_size=4, shuffle=True, drop_last=True, num_workers=0)
+    ids = sorted(int(u[1:]) for b in Prefetcher(ld2, workers=3) for u in b[0])
+    assert ids == list(range(5, 45))
+    # an exception surfaces at its batch, after the batches before it
+    it = iter(Prefetcher(DataLoader(DS(30, fail_at=13), batch_size=2, num_workers=0), workers=4))
+    heads = []
+    with _pt.raises(ValueError, match="decode failed at 13"):
+        for b in it:
+            heads.append(b[0][0])
+    assert heads == ["u%d" % i for i in range(0, 12, 2)]
+    # early exit does not hang; one worker / a non-DataLoader iterable use the serial path
+    it = iter(Prefetcher(DataLoader(DS(1000), batch_size=1, num_workers=0), workers=4))
+    assert next(it)[0] == ["u0"] or list(next(it)[0]) == ["u1"]
+    it.close()
+    assert [b[0][0] for b in Prefetcher(DataLoader(DS(5), batch_size=1, num_workers=0), workers=1)] == ["u%d" % i for i in range(5)]
+    assert list(Prefetcher(range(5), workers=4)) == list(range(5))
+
+
 def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
     from scl_amd import pack
     pack.set_audio_loader(None)

@@ -67,4 +67,4 @@ def test_default_path_kernels_have_no_private_segment(asm):
         seen += 1
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
-    assert seen == 17      # ping-pong + single barrier, 4 layouts, 208- and 256-row tiles; the grouped weight-gradient kernel
+    assert seen == 19      # ping-pong + single barrier, 4 layouts, 208- and 256-row tiles; the grouped weight-gradient kernel; round 6: the two 112-row single-barrier kernels (NN, NT)
