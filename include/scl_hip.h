@@ -593,6 +593,10 @@ int scl_multiview_crop_f32(const float* src, const int64_t* off, const int* len,
  * decoded audio.  total_samples == 0 in STREAMINFO (unknown length): decode with a capacity of the caller's choosing. */
 int scl_flac_info(const void* data, int64_t nbytes, int* sample_rate, int* channels, int* bits_per_sample, int64_t* total_samples);
 int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* out, int64_t capacity_samples, int64_t* decoded_samples, int check_md5);
+/* The same stream as what librosa.load(path, sr=None, mono=True) returns: float32 [total], every sample / 2^(bits-1), channels averaged
+ * (sequential float32 sum, then the division, as numpy's mean over the channel axis) — one pass, no int32 image (round 6: the
+ * pack builder's and the scoring loop's reader). */
+int scl_flac_decode_mono_f32(const void* data, int64_t nbytes, float* out, int64_t capacity_samples, int64_t* decoded_samples, int check_md5);
 
 /* ---- conf-5 augmenters (csrc/speedpitch.hip) ----------------------------------------------------------------------------------
  * speed: datautils/audio_augmentor/speed.py:29-33 -> pydub 0.25.1 AudioSegment.speedup(speed_factor).  scl_i16_append_xfade is

@@ -154,7 +154,9 @@ def _score_loop(dataset, model, device, batch_size, fn, workers=None):
             while nxt < n and len(futs) < ahead:
                 futs.append(pool.submit(dataset.__getitem__, nxt))
                 nxt += 1
-        top_up()
+        direct = hasattr(dataset, "load_into") and hasattr(dataset, "cut")      # scl_amd.pack.EvalDataset: decode straight into the batch's pinned rows
+        if not direct:
+            top_up()
         pending = None                                   # (host copies of the previous batch's results, their event, its ids)
 
         def to_host(res):
@@ -172,12 +174,31 @@ def _score_loop(dataset, model, device, batch_size, fn, workers=None):
             if ev is not None:
                 ev.record()
             return out, ev
-        while futs:
-            items = [futs.popleft().result() for _ in range(min(batch_size, len(futs)))]
-            top_up()
-            xs, ids = [it[0] for it in items], [it[1] for it in items]
-            host = torch.empty((len(xs),) + tuple(xs[0].shape), dtype=xs[0].dtype, pin_memory=use_gpu)
-            torch.stack(xs, out=host)
+        if direct:
+            batches = deque()
+
+            def submit_batch():
+                nonlocal nxt
+                cnt = min(batch_size, n - nxt)
+                host = torch.empty((cnt, dataset.cut), dtype=torch.float32, pin_memory=use_gpu)
+                hv = host.numpy()
+                fs = [pool.submit(dataset.load_into, nxt + j, hv[j]) for j in range(cnt)]
+                nxt += cnt
+                batches.append((host, fs))
+            while nxt < n and len(batches) < 4:          # three batches being decoded beyond the one in flight
+                submit_batch()
+        while (batches if direct else futs):
+            if direct:
+                host, fs = batches.popleft()
+                ids = [f.result() for f in fs]
+                if nxt < n:
+                    submit_batch()
+            else:
+                items = [futs.popleft().result() for _ in range(min(batch_size, len(futs)))]
+                top_up()
+                xs, ids = [it[0] for it in items], [it[1] for it in items]
+                host = torch.empty((len(xs),) + tuple(xs[0].shape), dtype=xs[0].dtype, pin_memory=use_gpu)
+                torch.stack(xs, out=host)
             res, ev = to_host(model(host.to(device, non_blocking=True)))
             if pending is not None:
                 if pending[1] is not None:

@@ -611,8 +611,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(const bf16_t* __restr
     // ---- column sums of this (utterance, head)'s dQ / dK / dV block -> bias_part[b][3E]: the q/k/v bias gradient is the column sum
     // of dqkv (autograd of F.linear), summed here from the f32 accumulators instead of by a pass over the 78 MB tensor.
     // Fixed order: butterfly over the 16 key / query lanes, then waves in index order => deterministic.
-    ATT_LDS_BARRIER();                     // the dS image is free
-    float* red = reinterpret_cast<float*>(QO + 32768);      // [8 waves][16 (dq) + 64 (dk) + 64 (dv)] f32 = 4.5 KiB (first dS image)
+    // [8 waves][16 (dq) + 64 (dk) + 64 (dv)] f32 = 4.5 KiB in the query-tile buffer the LAST step did not use: its readers (main phase of
+    // step NT2 - 2) finished before that step's barrier, and the last step staged nothing into it — no barrier needed before the partials
+    // are written (round 6; rounds 3 - 5 waited for the dS image here: one block-wide barrier of the tail gone)
+    float* red = reinterpret_cast<float*>(QO + (((NT2 - 1) & 1) ^ 1) * 16384);
     {
         float v[4] = {dqsum[0] * scale, dqsum[1] * scale, dqsum[2] * scale, dqsum[3] * scale};
 #pragma unroll

@@ -381,57 +381,87 @@ extern "C" int scl_flac_info(const void* data, int64_t nbytes, int* sample_rate,
     return SCL_OK;
 }
 
-extern "C" int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* out, int64_t capacity_samples, int64_t* decoded_samples,
-                                   int check_md5) {
-    SCL_REQUIRE(data && nbytes > 42 && out && decoded_samples && capacity_samples > 0, "flac_decode: bad args");
+// Shared body of the two decode entry points: frames are decoded one at a time; `sink_i` (interleaved int32 [capacity][channels]) or
+// `sink_f` (mono float [capacity]: channel mean of sample / 2^(bits-1), the arithmetic of librosa.load(mono=True) on soundfile's float
+// samples — what scl_amd/pack.py did with two numpy passes over the int32 image) receives them, and the MD5 runs over the frames as they come.
+static int flac_decode_any(const void* data, int64_t nbytes, int32_t* sink_i, float* sink_f, int64_t capacity_samples, int64_t* decoded_samples,
+                           int check_md5) {
     const uint8_t* p = (const uint8_t*)data;
     const size_t n = (size_t)nbytes;
     StreamInfo si;
     SCL_REQUIRE(parse_header(p, n, &si), "flac_decode: not a FLAC stream (no fLaC marker / STREAMINFO)");
     SCL_REQUIRE(si.channels >= 1 && si.channels <= 8 && si.bps >= 4 && si.bps <= 32, "flac_decode: %d channels, %d bits", si.channels, si.bps);
-    std::vector<int32_t> ch;
+    std::vector<int32_t> ch, frame;
     size_t pos = si.first_frame;
     int64_t written = 0;
     int bps = si.bps;
+    bool all0 = true;
+    for (int i = 0; i < 16; ++i) all0 = all0 && si.md5[i] == 0;
+    const bool md5_on = check_md5 && !all0;      // an all-zero signature means the encoder did not compute one
+    Md5 md;
+    const int bytes = (si.bps + 7) / 8, nch = si.channels;
+    std::vector<uint8_t> tmp;
+    const float inv = 1.0f / (float)(1ull << (si.bps - 1));
     while (pos + 2 <= n && (si.total == 0 || written < si.total)) {
         if (!(p[pos] == 0xFF && (p[pos + 1] & 0xFE) == 0xF8)) break;      // trailing bytes that are not a frame (e.g. an ID3v1 tag)
-        const int rc = decode_frame(p, n, &pos, si, ch, out, capacity_samples, &written, &bps);
-        if (rc == FLAC_ENOSPC) {      // told apart from a corrupt frame: a caller that could not size the output (STREAMINFO total = 0) grows it and retries
-            scl_set_error("flac_decode: output too small (%lld samples per channel hold the stream only up to byte %zu)", (long long)capacity_samples, pos);
-            return SCL_EINVAL;
-        }
+        // one frame into `frame` (interleaved), then into the sink
+        int64_t fw = 0;
+        const size_t frame_cap = 65536;      // the largest block a frame header can declare
+        if (frame.size() < frame_cap * (size_t)nch) frame.resize(frame_cap * (size_t)nch);
+        const int rc = decode_frame(p, n, &pos, si, ch, frame.data(), (int64_t)frame_cap, &fw, &bps);
         if (rc != SCL_OK) {
             scl_set_error("flac_decode: corrupt frame at byte %zu (sample %lld): sync / CRC / reserved-field check failed", pos, (long long)written);
             return rc;
         }
+        if (written + fw > capacity_samples) {      // told apart from a corrupt frame: a caller that could not size the output (STREAMINFO total = 0) grows it and retries
+            scl_set_error("flac_decode: output too small (%lld samples per channel hold the stream only up to byte %zu)", (long long)capacity_samples, pos);
+            return SCL_EINVAL;
+        }
+        const int32_t* f = frame.data();
+        if (sink_i) memcpy(sink_i + written * nch, f, (size_t)fw * nch * sizeof(int32_t));
+        if (sink_f) {
+            float* o = sink_f + written;
+            if (nch == 1) for (int64_t i = 0; i < fw; ++i) o[i] = (float)f[i] * inv;      // exact: a power-of-two scale
+            else for (int64_t i = 0; i < fw; ++i) {
+                float a = 0.f;
+                for (int c = 0; c < nch; ++c) a += (float)f[i * nch + c] * inv;         // numpy's mean over the channel axis: sequential float32 sum, then / channels
+                o[i] = a / (float)nch;
+            }
+        }
+        if (md5_on) {
+            const int64_t m = fw * nch;
+            if (tmp.size() < (size_t)m * bytes) tmp.resize((size_t)m * bytes);
+            if (bytes == 2) {
+                int16_t* t16 = reinterpret_cast<int16_t*>(tmp.data());
+                for (int64_t i = 0; i < m; ++i) t16[i] = (int16_t)f[i];
+            } else {
+                for (int64_t i = 0; i < m; ++i) {
+                    const uint32_t v = (uint32_t)f[i];
+                    for (int b = 0; b < bytes; ++b) tmp[(size_t)i * bytes + b] = (uint8_t)(v >> (8 * b));
+                }
+            }
+            md.update(tmp.data(), (size_t)m * bytes);
+        }
+        written += fw;
     }
     SCL_REQUIRE(si.total == 0 || written == si.total, "flac_decode: stream ends after %lld of %lld samples", (long long)written, (long long)si.total);
     *decoded_samples = written;
-    if (check_md5) {
-        bool all0 = true;
-        for (int i = 0; i < 16; ++i) all0 = all0 && si.md5[i] == 0;
-        if (!all0) {       // an all-zero signature means the encoder did not compute one
-            Md5 md;
-            const int bytes = (si.bps + 7) / 8;
-            std::vector<uint8_t> tmp(65536 * (size_t)bytes);
-            const int64_t total = written * si.channels;
-            for (int64_t i0 = 0; i0 < total; i0 += 65536) {
-                const int64_t m = total - i0 < 65536 ? total - i0 : 65536;
-                if (bytes == 2) {
-                    int16_t* t16 = reinterpret_cast<int16_t*>(tmp.data());
-                    for (int64_t i = 0; i < m; ++i) t16[i] = (int16_t)out[i0 + i];
-                } else {
-                    for (int64_t i = 0; i < m; ++i) {
-                        const uint32_t v = (uint32_t)out[i0 + i];
-                        for (int b = 0; b < bytes; ++b) tmp[(size_t)i * bytes + b] = (uint8_t)(v >> (8 * b));
-                    }
-                }
-                md.update(tmp.data(), (size_t)m * bytes);
-            }
-            uint8_t dig[16];
-            md.final(dig);
-            SCL_REQUIRE(!memcmp(dig, si.md5, 16), "flac_decode: MD5 of the decoded audio differs from the signature in STREAMINFO");
-        }
+    if (md5_on) {
+        uint8_t dig[16];
+        md.final(dig);
+        SCL_REQUIRE(!memcmp(dig, si.md5, 16), "flac_decode: MD5 of the decoded audio differs from the signature in STREAMINFO");
     }
     return SCL_OK;
+}
+
+extern "C" int scl_flac_decode_i32(const void* data, int64_t nbytes, int32_t* out, int64_t capacity_samples, int64_t* decoded_samples,
+                                   int check_md5) {
+    SCL_REQUIRE(data && nbytes > 42 && out && decoded_samples && capacity_samples > 0, "flac_decode: bad args");
+    return flac_decode_any(data, nbytes, out, nullptr, capacity_samples, decoded_samples, check_md5);
+}
+
+extern "C" int scl_flac_decode_mono_f32(const void* data, int64_t nbytes, float* out, int64_t capacity_samples, int64_t* decoded_samples,
+                                        int check_md5) {
+    SCL_REQUIRE(data && nbytes > 42 && out && decoded_samples && capacity_samples > 0, "flac_decode: bad args");
+    return flac_decode_any(data, nbytes, nullptr, out, capacity_samples, decoded_samples, check_md5);
 }

@@ -227,6 +227,7 @@ def _protos():
         "scl_stream_wait_stream": ([_vp, _vp], _i32),
         "scl_flac_info": ([_vp, _i64, _vp, _vp, _vp, _vp], _i32),
         "scl_flac_decode_i32": ([_vp, _i64, _vp, _i64, _vp, _i32], _i32),
+        "scl_flac_decode_mono_f32": ([_vp, _i64, _vp, _i64, _vp, _i32], _i32),
         "scl_gemm_splitk_finish": ([P(SclGemmDesc), _vp, _i32, _i64, _vp], _i32),
         "scl_i16_append_xfade": ([_vp, _i32, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _i32, _i32, _f64, _f64, _i32, _i32, _i32, _vp], _i32),
         "scl_stft_nframes": ([_i32], _i32),

@@ -69,8 +69,12 @@ def _read_flac(path):
     L.check(lib.scl_flac_info(buf, len(raw), ctypes.byref(fs), ctypes.byref(ch), ctypes.byref(bits), ctypes.byref(total)), "scl_flac_info(%s)" % path)
     # STREAMINFO without a length (streamed encoders): a CONSTANT / silence frame expands without bound per byte, so the output
     # grows until the decoder stops reporting "too small" (it writes nothing past the capacity it is given)
-    cap = total.value if total.value > 0 else max(len(raw) * 16, 1 << 16)
     got = ctypes.c_int64(0)
+    if total.value > 0:      # the usual case: one pass straight to mono float32 (scl_flac_decode_mono_f32 = the arithmetic of the numpy lines below)
+        x = np.empty(total.value, dtype=np.float32)
+        L.check(lib.scl_flac_decode_mono_f32(buf, len(raw), x.ctypes.data_as(ctypes.c_void_p), total.value, ctypes.byref(got), 1), "scl_flac_decode_mono_f32(%s)" % path)
+        return x[: got.value], fs.value
+    cap = max(len(raw) * 16, 1 << 16)
     while True:
         out = np.empty((cap, ch.value), dtype=np.int32)
         rc = lib.scl_flac_decode_i32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got), 1)
@@ -404,3 +408,18 @@ class EvalDataset(Dataset):
         utt_id = self.list_IDs[index]
         x = load_audio(os.path.join(self.base_dir, utt_id), 16000)
         return torch.from_numpy(np.ascontiguousarray(pad_eval(x, self.padding_type, self.cut), dtype=np.float32)), utt_id
+
+    def load_into(self, index, out):
+        """Decode + pad utterance `index` straight into `out` (a float32 numpy row of length self.cut — a row of the scoring loop's pinned
+        batch buffer: no per-item tensor, no stacking copy); returns the utterance id.  Same samples as __getitem__."""
+        utt_id = self.list_IDs[index]
+        x = load_audio(os.path.join(self.base_dir, utt_id), 16000)
+        n = x.shape[0]
+        if n >= self.cut:
+            out[:] = x[: self.cut]
+        elif self.padding_type == "repeat":
+            out[:] = pad_eval(x, "repeat", self.cut)
+        else:
+            out[:n] = x
+            out[n:] = 0.0
+        return utt_id

@@ -5,10 +5,12 @@ forked workers are out (the parent has initialised the GPU) — THREADS build th
 behind ctypes), numpy filter design and the C-ABI launches all release the GIL, and every builder thread issues its kernels on its OWN
 HIP stream, so they overlap the training step's kernels instead of queueing behind them.
 
-Round 6: one builder thread made 98 packs/s = 1078 utterances/s against a GPU that trains 1500+ — `workers` threads now take the
-DataLoader's own index batches (its batch_sampler: shuffle / drop_last / Subset semantics unchanged) one sequence number each, build them
-concurrently and hand them over IN ORDER.  With one worker (or a loader that is not a plain in-process DataLoader) the loader is simply
-iterated on one thread, as before.  Hand-over is an event: the consumer's stream waits for it and the tensors are marked as used on that
+Round 6: one builder thread made 98 packs/s = 1078 utterances/s against a GPU that trains 1500+.  What fixed it was the builder's own cost
+(fast sampler without a 64000-element permutation per clip, a 1.3 - 1.5 x faster FLAC decoder that writes mono float32 in one pass: 158
+packs/s on ONE thread); `workers` > 1 threads can take the DataLoader's own index batches (its batch_sampler: shuffle / drop_last / Subset
+semantics unchanged) one sequence number each, build them concurrently and hand them over IN ORDER — measured, that raises the builder
+alone to 186 packs/s and LOWERS the training rate (the builders and the launch thread share one interpreter lock), so it is opt-in
+(SCL_PREFETCH_THREADS).  With one worker (or a loader that is not a plain in-process DataLoader) the loader is iterated on one thread.  Hand-over is an event: the consumer's stream waits for it and the tensors are marked as used on that
 stream (allocator safety).  Exceptions of a producer surface in the consumer.  Like the reference's workers, concurrent builders draw
 from the process-wide `random` / `np.random` streams in whatever order they run: every draw has the right distribution, the assignment of
 draws to packs is not reproducible (SCL_PREFETCH_THREADS=1 restores one sequential stream).
@@ -22,13 +24,15 @@ import torch
 
 
 def default_workers():
-    """Two builders by default: measured on an MI355X box (profiles/r6_pack_builder.txt) the builder alone peaks at 2 threads (186 packs/s
-    of 11 views; more threads only fight for the interpreter lock), and inside a training run every builder thread competes with the
-    LAUNCH thread for that lock — at PACKS=6 four builders cost the step 31 %, one 8 %."""
+    """ONE builder thread by default.  Measured on MI355X boxes (profiles/r6_pack_builder.txt): with the fast RawBoost sampler and the
+    round-6 FLAC decoder one thread builds 158 packs/s of 11 views = 1730 utterances/s — more than the 1580 - 1600 the GPU trains at 6 packs per
+    step — and end to end main.run_epoch then runs at 1.04 - 1.07 x the resident-batch step.  Two threads raise the builder ALONE to
+    181 - 186 packs/s, but inside a training run every builder shares the interpreter lock with the launch thread (~760 C calls per
+    step): 2 - 3 builders cost the step 11 - 57 %.  SCL_PREFETCH_THREADS=<n> for hosts / corpora where decoding dominates."""
     try:
-        return max(1, int(os.environ.get("SCL_PREFETCH_THREADS", "2")))
+        return max(1, int(os.environ.get("SCL_PREFETCH_THREADS", "1")))
     except ValueError:
-        return 2
+        return 1
 
 
 class Prefetcher:

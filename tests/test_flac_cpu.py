@@ -191,3 +191,28 @@ def test_second_and_third_streams_from_the_format_specification():
     pcm, fs, bits = decode(d3, check_md5=1)
     assert (fs, bits) == (32000, 8) and pcm.shape == (24, 1)
     assert pcm[:, 0].tolist() == [0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5, 0]
+
+
+@pytest.mark.parametrize("nch,bps,mode", [(1, 16, "independent"), (2, 16, "mid_side"), (2, 24, "left_side"), (3, 12, "independent"), (1, 20, "independent")])
+def test_one_pass_mono_float_decode_equals_the_numpy_formulation(nch, bps, mode):
+    """scl_flac_decode_mono_f32 (round 6: the reader of the pack builder and of the scoring loop) against the two numpy passes it replaces —
+    int32 image -> float32 / 2^(bits-1) -> mean over the channel axis, i.e. librosa.load(mono=True) on soundfile's floats — bit for bit,
+    with the MD5 of STREAMINFO checked on the way (computed over the frames as they are decoded) and a capacity that is too small refused."""
+    n = 10000
+    amp = (1 << (bps - 1)) // 3
+    x = np.stack([speechlike(n, 30 + c, amp=amp) * (1 if c % 2 == 0 else -1) // (c + 1) for c in range(nch)], axis=1)
+    raw = write_flac(x if nch > 1 else x[:, 0], 16000, bps, 1152, stereo_mode=mode)
+    ints, fs, bits = decode(raw)
+    ref = ints.astype(np.float32) / np.float32(1 << (bits - 1))
+    ref = ref.mean(axis=1) if nch > 1 else ref[:, 0]
+    lib = L.load()
+    buf = ctypes.create_string_buffer(raw, len(raw))
+    out = np.full(n + 7, np.nan, dtype=np.float32)
+    got = ctypes.c_int64(0)
+    L.check(lib.scl_flac_decode_mono_f32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), n + 7, ctypes.byref(got), 1), "decode f32")
+    assert got.value == n and np.array_equal(out[:n], ref) and np.isnan(out[n:]).all()
+    assert lib.scl_flac_decode_mono_f32(buf, len(raw), out.ctypes.data_as(ctypes.c_void_p), n - 1, ctypes.byref(got), 1) != 0
+    assert b"output too small" in lib.scl_last_error()
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 0x10
+    cb = ctypes.create_string_buffer(bytes(bad), len(bad))
+    assert lib.scl_flac_decode_mono_f32(cb, len(bad), out.ctypes.data_as(ctypes.c_void_p), n + 7, ctypes.byref(got), 1) != 0

@@ -230,6 +230,50 @@ def test_parallel_prefetcher_builds_on_several_threads_and_hands_over_in_order()
     assert list(Prefetcher(range(5), workers=4)) == list(range(5))
 
 
+def test_threaded_scoring_loop_writes_the_same_lines_in_protocol_order(tmp_path):
+    """main._score_loop (round 6): decoder threads + results read back one batch late must produce exactly the score file of the plain
+    DataLoader loop — both through per-item __getitem__ futures and through EvalDataset-style load_into rows (a ragged last batch included)."""
+    import time as _time
+    import main as M
+    from torch.utils.data import Dataset
+
+    class Items(Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            _time.sleep(0.001 * ((i * 5) % 4))
+            return torch.full((16,), float(i)), "utt%04d" % i
+
+    class Rows(Items):
+        cut = 16
+
+        def load_into(self, i, out):
+            _time.sleep(0.001 * ((i * 3) % 4))
+            out[:] = float(i)
+            return "utt%04d" % i
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            s = x.mean(dim=1, keepdim=True)
+            return torch.cat([s, -2.0 * s], dim=1), x, s          # (output, feats, emb) as the plugins' training-mode forward (is_train)
+
+    net = Net()
+    outs = {}
+    for name, ds, thr in (("plain", Items(37), "1"), ("futures", Items(37), "4"), ("rows", Rows(37), "4")):
+        os.environ["SCL_EVAL_THREADS"] = thr
+        path = str(tmp_path / (name + ".txt"))
+        M.produce_evaluation_file(ds, net, torch.device("cpu"), path, batch_size=5)
+        outs[name] = open(path).read()
+    os.environ.pop("SCL_EVAL_THREADS")
+    lines = outs["plain"].splitlines()
+    assert len(lines) == 37 and lines[0].split()[0] == "utt0000" and lines[-1] == "utt0036 36.0 -72.0"
+    assert outs["futures"] == outs["plain"] and outs["rows"] == outs["plain"]
+
+
 def test_non_wav_corpus_is_refused_at_start_up_without_a_decoder():
     from scl_amd import pack
     pack.set_audio_loader(None)
