@@ -103,6 +103,9 @@ typedef struct SclOperand {
 #define SCL_GEMM_FORCE_X2 0x08000000  /* pick the two-blocks-per-CU 208 x 128 kernel of gemm_x2.hip whenever it can address the operands */
 #define SCL_GEMM_NO_X2    0x10000000  /* never that kernel (testing / A-B comparison) */
 #define SCL_GEMM_AB_F32   0x40000000  /* A and B are f32 (strides in f32 elements, multiples of 4): exact-fp32 MFMA kernel (gemm_f32.hip) */
+#define SCL_GEMM_C_SPLIT3 0x80000000u /* bf16 C, wide tiles only: the stored value v leaves as the row image [hi | hi | lo] of three N-wide planes (ldc = 3 N, hi = bf16(v),
+                                         lo = bf16(v - hi)) — the left operand of the NEXT triple-plane GEMM (scl_split3_f32_bf16) without an f32 round trip; refused
+                                         (SCL_EUNSUPPORTED) when the launch would not run on the wide-tile kernel */
 #define SCL_GEMM_STAMPS   0x20000000  /* diagnostic: the wide kernels record per-block time stamps (scl_debug_gemm_stamps) */
 #define SCL_GEMM_ACT_SHIFT   8        /* 0 none, 1 gelu(erf), 2 relu, 3 leaky_relu(0.01), 5 gelu(erf) with C2 = gelu'(pre-activation) instead
                                        * of the pre-activation (the backward multiplies by it: RACT 4) */
@@ -246,8 +249,9 @@ int scl_avgpool_bwd(const float* dy, int B, int R, int C, float* dx, void* strea
 /* LayerNorm (+GELU), column reductions                                                        */
 /* ------------------------------------------------------------------------------------------ */
 /* y = act(LN(x) * gamma + beta) per row of [M, C]; x f32 or bf16; y to bf16 and/or f32; saves mean / rstd.
- * act: 0 none, 1 gelu.  Replaces fairseq Fp32LayerNorm / nn.LayerNorm (+ nn.GELU in the conv stack)
- * inside Wav2Vec2Model.forward (model/xlsr.py:41). */
+ * act: 0 none, 1 gelu; | 0x100: y_bf16 receives the row as [hi | hi | lo] with pitch 3 C (hi = bf16(y), lo = bf16(y - hi): the left
+ * operand of the scoring path's triple-plane GEMMs, see scl_split3_f32_bf16).  Replaces fairseq Fp32LayerNorm / nn.LayerNorm
+ * (+ nn.GELU in the conv stack) inside Wav2Vec2Model.forward (model/xlsr.py:41). */
 int scl_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                       float* mean, float* rstd, int M, int C, int64_t ldx, int64_t ldy, float eps, int act, void* stream);
 /* number of row-slab partials scl_layernorm_bwd writes for M rows */
@@ -301,6 +305,11 @@ int scl_colsum_reduce(const void* x, int x_f32, float* part, int* counters, floa
 /* element-wise glue                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 int scl_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* f32 [rows][K] (pitch ldx) -> bf16 [rows][3 K]: per row [hi | hi | lo] (order 0, left operand) or [hi | lo | hi] (order 1, right operand),
+ * hi = bf16(x), lo = bf16(x - hi): one bf16 GEMM over 3 K then yields hi.hi + hi.lo + lo.hi = the f32 product to ~2^-17 relative.  The
+ * scoring path's linears (encoder.forward_f32: main.py --eval / --predict / --emb, reference main.py:161-214) run that way on the wide
+ * bf16 kernel. */
+int scl_split3_f32_bf16(const float* x, int64_t rows, int K, int64_t ldx, void* out, int order, void* stream);
 int scl_add_f32(const float* a, const float* b, float* out, void* out_bf16, int64_t n, void* stream);
 /* dst[b][r][:] = src[b][r - pad_before][:] (* act'(pre)), zero outside [0,T): zero-padded operand of the
  * grouped positional conv (fairseq encoder.pos_conv, padding = k/2) and of its dgrad. */

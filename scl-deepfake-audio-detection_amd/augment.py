@@ -60,6 +60,7 @@ def _draw_notch_params(nBands, minF, maxF, minBW, maxBW, minCoeff, maxCoeff, min
 # same draws in the same order, the filters of a clip designed at once in closed form (design_notch_filters: tests/test_host_cpu.py pins
 # it to the scipy chain at 1e-12; the RawBoost goldens hold at their 3e-5 bar either way).
 _SCIPY_DESIGN = __import__("os").environ.get("SCL_RAWBOOST_SCIPY", "0") == "1"
+RIR_GEMM = __import__("os").environ.get("SCL_RIR_GEMM", "1") != "0"      # RIR convolution (>= 1024 taps) on the f32 matrix cores (below); 0: fir_kernel
 
 
 def _draw_lnl(a, fs):
@@ -347,16 +348,77 @@ def rawboost_batch(x, args, algo, sr=16000, sampler="reference"):
     return y
 
 
+# ---- RIR convolution on the f32 matrix cores (round 6) -----------------------------------------------------------------------------------
+# SURVEY.md 8(d) asks for a formulation of the 8000-tap RIR convolution in which the matrix cores do the products.  Taking the outputs 64 at a
+# time makes it a GEMM without a band of wasted products:
+#     y[64 a + b] = sum_k A[a][k] * B[b][k],   A[a][k] = xpad[64 a + k]            (rows of the SIGNAL that overlap: row pitch 64 < K = R + 63)
+#                                              B[b][k] = h[b + R - 1 - k] or 0     (the taps as a 64-row Toeplitz image, built once per RIR)
+# i.e. M = Lout / 64 rows, N = 64, K = R + 63 (0.8 % extra products at R = 8000) on the library's exact-f32 MFMA kernel (an fmaf chain per
+# output: v_mfma_f32_16x16x4_f32; bf16 operands would break the +-1-LSB property of A7), the overlapping-row operand being the same
+# descriptor the conv stack uses; split-K (the output is only 18 tiles) with the slabs summed in index order.  Measured on MI355X
+# (profiles/r6_fir_toeplitz_probe.txt): ONE clip x 8000 taps — what reverb_wrapper runs — 296 us on fir_kernel (one clip is a handful of
+# workgroups: 3.5 TFLOP/s) -> 26 us; 16 clips 339 -> 176 us (93 TFLOP/s of useful work).  RawBoost's 121 - 411-tap filters stay on
+# fir_kernel: the GEMM form measured 235 vs 202 us there (24 % band waste, and five powered / shifted signal copies to lay out).
+_RIR_GEMM_MIN_TAPS = 1024
+_TOEPLITZ = {}      # (data_ptr, R, device) -> (weak reference to the RIR tensor, image [64, Kp], Kp)
+
+
+def _toeplitz_image(rir):
+    import weakref
+    R = rir.numel()
+    key = (rir.data_ptr(), R, str(rir.device))
+    ent = _TOEPLITZ.get(key)
+    if ent is not None and ent[0]() is rir:
+        return ent[1], ent[2]
+    Kp = (R + 63 + 15) // 16 * 16
+    b = torch.arange(64, device=rir.device)[:, None]
+    k = torch.arange(Kp, device=rir.device)[None, :]
+    t = b + (R - 1) - k
+    img = torch.where((t >= 0) & (t < R), rir.float()[t.clamp(0, R - 1)], torch.zeros((), device=rir.device)).contiguous()
+    if len(_TOEPLITZ) > 256:
+        _TOEPLITZ.clear()
+    _TOEPLITZ[key] = (weakref.ref(rir), img, Kp)      # RIR tensors live in the audio bank (scl_amd/pack.py): the image is built once per file
+    return img, Kp
+
+
+def _rir_full_conv_gemm(x, rir):
+    """y[m] = sum_t rir[t] x[m - t], m in [0, L + R - 1): numpy.convolve(x, rir) (reverb.py:37) as the GEMM above.  Returns y and the
+    partial statistics clip_affine needs."""
+    L, R = x.numel(), rir.numel()
+    Lout = L + R - 1
+    dev = x.device
+    img, Kp = _toeplitz_image(rir)
+    M = (Lout + 63) // 64
+    Lp = 64 * (M - 1) + Kp + 64
+    xpad = torch.zeros(Lp, device=dev)
+    xpad[R - 1: R - 1 + L] = x
+    nk = Kp // 16
+    splitk = max(1, min(32, nk // 8, (4 * 256) // max(1, ((M + 63) // 64))))
+    y = torch.empty(M * 64, device=dev)
+    if splitk > 1:
+        slabs = torch.empty(splitk * M * 64, device=dev)
+        ops.gemm(ops.Op(xpad, 64), ops.Op(img, Kp), slabs, M, 64, Kp, splitk=splitk, c_split_stride=M * 64, x3=False)
+        ops.reduce_slabs(slabs, y, M * 64, splitk, M * 64)
+    else:
+        ops.gemm(ops.Op(xpad, 64), ops.Op(img, Kp), y, M, 64, Kp, x3=False)
+    part = torch.empty(ops.fir_nblocks(Lout) * 4, device=dev)
+    ops.clip_stats(y, Lout, Lout, 1, part)
+    return y, part, Lout
+
+
 def reverb(x, rir):
     """ReverbAugmentor.transform (reverb.py:33-44): full convolution, peak normalise, int16 C cast;
     returns the int16 VALUES as fp32 (pydub_to_librosa keeps them unscaled, utils.py:20-22)."""
     L, R = x.numel(), rir.numel()
     Lout = L + R - 1
     dev = x.device
-    i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)
-    y = torch.empty(Lout, device=dev)
-    part = torch.empty(ops.fir_nblocks(Lout) * 4, device=dev)
-    ops.fir_multi(x.contiguous(), L, L, rir.contiguous().float(), i32(0), i32(R), i32(0), 1, 1, False, y, Lout, Lout, part)
+    if R >= _RIR_GEMM_MIN_TAPS and RIR_GEMM:
+        y, part, _ = _rir_full_conv_gemm(x.contiguous().float(), rir)
+    else:
+        i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)
+        y = torch.empty(Lout, device=dev)
+        part = torch.empty(ops.fir_nblocks(Lout) * 4, device=dev)
+        ops.fir_multi(x.contiguous(), L, L, rir.contiguous().float(), i32(0), i32(R), i32(0), 1, 1, False, y, Lout, Lout, part)
     out = torch.empty(Lout, device=dev)
     ops.clip_affine(ops.AFF_PEAK_QUANT_I16, y, Lout, part, out, Lout, Lout, 1)
     return out

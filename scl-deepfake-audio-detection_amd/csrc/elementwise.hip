@@ -22,6 +22,39 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     }
 }
 
+// f32 [rows][K] (row pitch ldx) -> bf16 [rows][3 K]: every value as hi = bf16(x) and lo = bf16(x - hi), laid out per row as
+// [hi | hi | lo] (order 0: the left operand) or [hi | lo | hi] (order 1: the right operand), so that ONE bf16 GEMM over 3 K computes
+// hi.hi + hi.lo + lo.hi — the f32 product to ~2^-17 relative (the lo.lo term is dropped), accumulated in f32.  Round 6: the scoring
+// path's linears on the wide bf16 kernel (operands by LDS-DMA, no conversion in the K loop) instead of the f32-pair kernel that splits
+// inside its loop at 26 % matrix-pipe occupancy.
+__global__ void split3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t rows, int K, int64_t ldx, int order) {
+    const int kv = K >> 3;
+    const int64_t total = rows * kv;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int64_t r = i / kv;
+        const int c = (int)(i - r * kv) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 b = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float lo[8];
+        uint4 h, l;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hw[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+            lo[2 * j] = v[2 * j] - __uint_as_float(hw[j] << 16);
+            lo[2 * j + 1] = v[2 * j + 1] - __uint_as_float(hw[j] & 0xFFFF0000u);
+            lw[j] = pack_bf2(lo[2 * j], lo[2 * j + 1]);
+        }
+        h = make_uint4(hw[0], hw[1], hw[2], hw[3]); l = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        bf16_t* o = out + r * 3 * (int64_t)K + c;
+        *reinterpret_cast<uint4*>(o) = h;
+        *reinterpret_cast<uint4*>(o + K) = order ? l : h;
+        *reinterpret_cast<uint4*>(o + 2 * (int64_t)K) = order ? h : l;
+    }
+}
+
 // dst[b][r][c] (bf16, rows_out per item) = src[b][r - pad_before][c] (f32 or bf16), zero outside; optional
 // multiply by act'(pre[b][r-pad][c]) (positional-conv backward: dc = d_out * gelu'(pre)).
 template <bool SRC_F32>
@@ -330,6 +363,13 @@ extern "C" int scl_cast_f32_bf16(const float* src, void* dst, int64_t n, void* s
     SCL_REQUIRE(src && dst && n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "cast: bad args");
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 8)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     return scl_check_launch("scl_cast_f32_bf16");
+}
+
+extern "C" int scl_split3_f32_bf16(const float* x, int64_t rows, int K, int64_t ldx, void* out, int order, void* stream) {
+    SCL_REQUIRE(x && out && rows > 0 && K >= 8 && (K & 7) == 0 && ldx >= K && (ldx & 3) == 0 && (order == 0 || order == 1), "split3: bad args (K a multiple of 8)");
+    SCL_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "split3: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (K >> 3))), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, rows, K, ldx, order);
+    return scl_check_launch("scl_split3_f32_bf16");
 }
 
 extern "C" int scl_pad_rows_bf16(const void* src, int src_f32, void* dst, const void* pre, int ract, int B, int T, int C,

@@ -802,6 +802,9 @@ static int gemm_fill_k(const SclGemmDesc& d, GemmK& k) {
                al(d.R, (d.flags & SCL_GEMM_R_F32) ? 16 : 8) && al(d.bias, 16);
     // the wide epilogue writes its column-sum partial rows from the 8-column vector path only: without it the rows would stay unwritten
     SCL_REQUIRE(!d.colsum_part || k.vec_ok, "gemm: colsum_part needs 16-byte aligned C / C2 / R / bias and strides that are multiples of 4");
+    SCL_REQUIRE(!((unsigned)d.flags & SCL_GEMM_C_SPLIT3) || (!(d.flags & (SCL_GEMM_C_F32 | SCL_GEMM_HAS_C2 | SCL_GEMM_AB_F32)) && d.splitk == 1 && d.nb1 == 1 && d.nb2 == 1 &&
+                                                             (d.N & 7) == 0 && d.ldc == 3 * d.N && d.c_rpb >= d.M && k.vec_ok && ((uintptr_t)d.C & 15) == 0 && !d.colsum_part),
+                "gemm: C_SPLIT3 needs one un-batched problem, bf16 C with ldc = 3 N, N %% 8 == 0, 16-byte aligned C and no second output");
     return SCL_OK;
 }
 
@@ -909,6 +912,10 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
         const bool x2 = false;
 #endif
         const bool w8 = !x2 && dma && gemm_pick_w8(k, at, bt, d, zdim, &plan);
+        if (((unsigned)d.flags & SCL_GEMM_C_SPLIT3) && !w8) {
+            scl_set_error("gemm: C_SPLIT3 is served by the wide-tile kernel only, and this launch (M %d, N %d, K %d) does not qualify for it", d.M, d.N, d.K);
+            return SCL_EUNSUPPORTED;
+        }
         prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? (plan.variant == 2 ? 6 : 1 + plan.variant) : 0));
         if (x2) {
 #ifdef SCL_EXPERIMENTS

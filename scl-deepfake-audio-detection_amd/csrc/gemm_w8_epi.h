@@ -191,6 +191,21 @@ static __device__ __forceinline__ void w8_epilogue_pass_k(const GemmK& d, f32x4 
                 float* p = reinterpret_cast<float*>(d.C) + off;
                 *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else if (!KN && ((unsigned)flags & SCL_GEMM_C_SPLIT3)) {
+                // triple-plane row image [hi | hi | lo] (planes N apart, ldc = 3 N; the host checked alignment and N % 8 == 0): the scoring
+                // path's fc1 hands fc2 its left operand without an f32 copy and a split pass (scl_split3_f32_bf16's arithmetic)
+                bf16_t* p = reinterpret_cast<bf16_t*>(d.C) + off;
+                const uint4 h = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+                float l8[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    l8[2 * j] = v[2 * j] - __uint_as_float(hw[j] << 16);
+                    l8[2 * j + 1] = v[2 * j + 1] - __uint_as_float(hw[j] & 0xFFFF0000u);
+                }
+                *reinterpret_cast<uint4*>(p) = h;
+                *reinterpret_cast<uint4*>(p + d.N) = h;
+                *reinterpret_cast<uint4*>(p + 2 * (long long)d.N) = make_uint4(pack_bf2(l8[0], l8[1]), pack_bf2(l8[2], l8[3]), pack_bf2(l8[4], l8[5]), pack_bf2(l8[6], l8[7]));
             } else {
                 bf16_t* p = reinterpret_cast<bf16_t*>(d.C) + off;
                 if (KN || (off & 7) == 0) *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
@@ -231,7 +246,7 @@ static __device__ __forceinline__ void w8_epilogue_pass(const GemmK& d, f32x4 (&
     constexpr int KEY = SCL_GEMM_C_F32 | SCL_GEMM_C2_F32 | SCL_GEMM_R_F32 | SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | SCL_GEMM_DROPOUT |
                         (0xF << SCL_GEMM_ACT_SHIFT) | (0xF << SCL_GEMM_RMODE_SHIFT) | (0xF << SCL_GEMM_RACT_SHIFT);
     const int f = d.flags & KEY, fb = f & ~SCL_GEMM_HAS_BIAS;
-    if (SPEC != 0 && !(d.debug & 16) && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B)
+    if (SPEC != 0 && !(d.debug & 16) && !((unsigned)d.flags & SCL_GEMM_C_SPLIT3) && d.vec_ok && !(d.ldc & 7) && !(d.c_rbstride & 7) && !(cbase & 7)) {      // debug bit 4: SCL_W8_EPI_GENERIC=1 (A/B); the triple-plane store lives in the generic loop only
         if ((SPEC & 2) && fb == 0) return w8_epilogue_pass_k<NMT, 1>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);
         if ((SPEC & 4) && f == (SCL_GEMM_HAS_BIAS | SCL_GEMM_HAS_C2 | (5 << SCL_GEMM_ACT_SHIFT)))
             return w8_epilogue_pass_k<NMT, 2>(d, acc, nmt, wlds, wextra, mbase, nbase, mlimit, cbase, bias, lane, csum_row, cs_carry, blk_stride);

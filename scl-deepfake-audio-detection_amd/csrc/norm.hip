@@ -102,11 +102,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
                     float o[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = (v[r][ch][i] - mean[r]) * rstd[r] * g[i] + b[i];
-                    if (act == 1) {
+                    if ((act & 0xFF) == 1) {
 #pragma unroll
                         for (int i = 0; i < 8; i += 2) gelu2(o[i], o[i + 1]);      // packed-f32 form, same bits as gelu_f
                     }
-                    if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
+                    if (y_bf && (act & 0x100)) {
+                        // triple-plane output (round 6, scoring path): row = [hi | hi | lo], hi = bf16(o), lo = bf16(o - hi), pitch 3 C —
+                        // the left operand of the bf16 GEMM over 3 K that stands in for the f32 product (elementwise.hip split3_kernel)
+                        float lo[8];
+                        uint4 h;
+                        h.x = pack_bf2(o[0], o[1]); h.y = pack_bf2(o[2], o[3]); h.z = pack_bf2(o[4], o[5]); h.w = pack_bf2(o[6], o[7]);
+                        const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lo[2 * i] = o[2 * i] - __uint_as_float(hw[i] << 16);
+                            lo[2 * i + 1] = o[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u);
+                        }
+                        bf16_t* dst = y_bf + (int64_t)row * 3 * C + c;
+                        *reinterpret_cast<uint4*>(dst) = h;
+                        *reinterpret_cast<uint4*>(dst + C) = h;
+                        store8_bf16(dst, 2 * (int64_t)C, lo);
+                    } else if (y_bf) store8_bf16(y_bf, (int64_t)row * ldy + c, o);
                     if (y_f32) store8_f32(y_f32, (int64_t)row * ldy + c, o);
                 }
             }

@@ -47,6 +47,7 @@ GELU_DC2 = True      # decided by the A/Bs of rounds 2-4; 
 # BASELINE.json configs[4] names fp8 attention: csrc/attention_fp8.hip (e4m3 operands, fp32 accumulation) for the no-grad bf16 forward.  Opt-in:
 # the reference is fp32 and the fused forward is bound by its soft-max VALU work, not by the matrix pipe (profiles/r4_attn_fp8_probe.txt).
 ATTN_FP8 = os.environ.get("SCL_ATTN_FP8", "0") == "1"
+SCORE_X3PLANES = os.environ.get("SCL_SCORE_X3PLANES", "1") != "0"      # fp32 scoring path: plain linears as one bf16 GEMM over [hi | hi | lo] x [hi | lo | hi] (forward_f32)
 CONV_WGRAD_WIDE = True      # decided by the A/Bs of rounds 2-4; the environment switch is gone
 
 
@@ -534,8 +535,18 @@ class Encoder:
         v, g = P.f32(self.n("encoder.pos_conv.0.weight_v")), P.f32(self.n("encoder.pos_conv.0.weight_g"))
         w = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())                              # weight_norm(dim=2)
         pos = w.view(G, Cg, Cg, K).permute(0, 1, 3, 2).reshape(G, Cg, K * Cg).contiguous()       # k index = (tap, channel in group)
-        self._f32w, self._f32w_version = {"wk": wk, "pos": pos}, P.version
+        self._f32w, self._f32w_version = {"wk": wk, "pos": pos, "w3": {}}, P.version
         return self._f32w
+
+    def _w3(self, fw, name, N, K):
+        """[N, 3 K] bf16 image [hi | lo | hi] of a Linear's fp32 master weight (ops.split3, order 1): the right operand of the scoring
+        path's triple-plane GEMMs; built on first use, dropped with the rest of the fp32 re-layouts when the masters change."""
+        w3 = fw["w3"].get(name)
+        if w3 is None:
+            w3 = torch.empty(N * 3 * K, dtype=torch.bfloat16, device=self.dev)
+            ops.split3(self.P.flat, N, K, w3, 1, x_offset=self.P.off(self.n(name)))
+            fw["w3"][name] = w3
+        return w3
 
     def forward_f32(self, x):
         """The encoder forward with fp32 activations and the fp32 master weights, every contraction on the exact-fp32 matrix-core
@@ -556,10 +567,39 @@ class Encoder:
             self._bufs[key] = dict(z=[f32(B * t * C + slack) for t in Ts], y=f32(B * Ts[1] * C), stat=f32(2 * B * Ts[1]), h=f32(M * max(C, E) + slack),
                                    x0=f32(M * E), xpad=torch.zeros(B * (T + K) * E + slack, device=self.dev), xa=f32(M * E), xb=f32(M * E),
                                    x1=f32(M * E), qkv=f32(M * 3 * E + slack), S=f32(B * H * T * Tp), Pm=torch.zeros(B * H * T * Tp + 1024, device=self.dev),
-                                   ctx=f32(M * E + slack), a=f32(M * Fd + slack), out=f32(M * E))
+                                   ctx=f32(M * E + slack), a=f32(M * Fd + slack), out=f32(M * E),
+                                   a3=torch.empty(M * 3 * max(C, E, Fd) + 2 * slack, dtype=torch.bfloat16, device=self.dev),
+                                   a3b=torch.empty(M * 3 * Fd + 2 * slack, dtype=torch.bfloat16, device=self.dev))
         d = self._bufs[key]
         fw = self._f32_weights()
         Wf = lambda name, ld: Op(P.flat, ld, offset=P.off(self.n(name)))
+        # Round 6: the plain linears (flat K) as ONE bf16 GEMM over 3 K on the wide-tile kernel — left operand [hi | hi | lo] written by a
+        # streaming split pass, right operand [hi | lo | hi] cached per weight: hi.hi + hi.lo + lo.hi with f32 accumulation, the same three
+        # products the f32-pair kernel forms inside its K loop (4 - 6e-6 of float64), at the bf16 kernel's operand feed (LDS-DMA, no
+        # conversion in the loop).  SCL_SCORE_X3PLANES=0 / shapes with K % 64 != 0: the f32-operand kernel as before.
+        use3 = SCORE_X3PLANES and ops.F32X3
+        # fc1 -> fc2 without an f32 activation: needs the wide-tile kernel for fc1 (it alone writes the triple-plane image), i.e. K, N
+        # multiples of 64 / 8 and enough tiles — asked of the library once per shape
+        ffn3 = bool(use3 and E % 64 == 0 and Fd % 64 == 0 and
+                    ops.gemm_wide_kind(Op(d["a3"], 3 * E), Op(d["a3"], 3 * E), d["a3b"], M, Fd, 3 * E, ldc=3 * Fd))
+
+        LN3 = 0x100      # scl_layernorm_fwd: write [hi | hi | lo] rows straight into a3 (no f32 copy, no split pass)
+
+        def ln_then_lin(xsrc, lnw, lnb, Kin, wname, N, out, **epi):
+            """LayerNorm(xsrc) -> Linear: the LayerNorm kernel writes the triple-plane operand itself when that path is on."""
+            if use3 and Kin % 64 == 0 and N % 8 == 0:
+                ops.layernorm_fwd(xsrc, self.b(lnw), self.b(lnb), d["a3"], None, mean, rstd, M, Kin, act=LN3)
+                ops.gemm(Op(d["a3"], 3 * Kin), Op(self._w3(fw, wname, N, Kin), 3 * Kin), out, M, N, 3 * Kin, **epi)
+            else:
+                ops.layernorm_fwd(xsrc, self.b(lnw), self.b(lnb), None, d["h"], mean, rstd, M, Kin)
+                ops.gemm(Op(d["h"], Kin), Wf(wname, Kin), out, M, N, Kin, **epi)
+
+        def lin(A, Kin, wname, N, out, **epi):
+            if use3 and Kin % 64 == 0 and N % 8 == 0:
+                ops.split3(A, M, Kin, d["a3"], 0)
+                ops.gemm(Op(d["a3"], 3 * Kin), Op(self._w3(fw, wname, N, Kin), 3 * Kin), out, M, N, 3 * Kin, **epi)
+            else:
+                ops.gemm(Op(A, Kin), Wf(wname, Kin), out, M, N, Kin, **epi)
         fe = "feature_extractor.conv_layers.%d."
         mean, rstd = d["stat"][: B * Ts[1]], d["stat"][B * Ts[1]:]
         ops.conv0_fwd_f32(x, self.b(fe % 0 + "0.weight"), self.b(fe % 0 + "0.bias"), self.b(fe % 0 + "2.1.weight"), self.b(fe % 0 + "2.1.bias"),
@@ -568,8 +608,7 @@ class Encoder:
             k, s, Tin, Tout = cfg.conv_kernels[i], cfg.conv_strides[i], Ts[i - 1], Ts[i]
             ops.gemm(Op(d["z"][i - 1], s * C, rpb=Tout, rbstride=Tin * C), Op(fw["wk"][i], k * C), d["y"], B * Tout, C, k * C, bias=self.b(fe % i + "0.bias"))
             ops.layernorm_fwd(d["y"], self.b(fe % i + "2.1.weight"), self.b(fe % i + "2.1.bias"), None, d["z"][i], mean, rstd, B * Tout, C, act=1)
-        ops.layernorm_fwd(d["z"][-1], self.b("layer_norm.weight"), self.b("layer_norm.bias"), None, d["h"], mean, rstd, M, C)
-        ops.gemm(Op(d["h"], C), Wf("post_extract_proj.weight", C), d["x0"], M, E, C, bias=self.b("post_extract_proj.bias"))
+        ln_then_lin(d["z"][-1], "layer_norm.weight", "layer_norm.bias", C, "post_extract_proj.weight", E, d["x0"], bias=self.b("post_extract_proj.bias"))
         # positional conv: zero-padded rows (the pad rows of xpad are never written), GELU, residual
         d["xpad"][: B * (T + K) * E].view(B, T + K, E)[:, K // 2: K // 2 + T].copy_(d["x0"].view(B, T, E))
         xin, xout = d["xa"], d["xb"]
@@ -578,17 +617,24 @@ class Encoder:
         qkv, S, Pm = d["qkv"], d["S"], d["Pm"]
         for n in range(cfg.layers):
             pn = "encoder.layers.%d." % n
-            ops.layernorm_fwd(xin, self.b(pn + "self_attn_layer_norm.weight"), self.b(pn + "self_attn_layer_norm.bias"), None, d["h"], mean, rstd, M, E)
-            ops.gemm(Op(d["h"], E), Wf(pn + "self_attn.q_proj.weight", E), qkv, M, 3 * E, E, bias=self.b(pn + "self_attn.q_proj.bias"))
+            ln_then_lin(xin, pn + "self_attn_layer_norm.weight", pn + "self_attn_layer_norm.bias", E, pn + "self_attn.q_proj.weight", 3 * E, qkv,
+                        bias=self.b(pn + "self_attn.q_proj.bias"))
             ops.gemm(Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=E), S, T, T, D, nb1=B, nb2=H, alpha=D ** -0.5,
                      ldc=Tp, c_bs1=H * T * Tp, c_bs2=T * Tp)
             ops.softmax_fwd_f32(S, Pm, B * H * T, T, Tp, Tp)                                               # fp32 soft-max, as fairseq (one wave per row)
             ops.gemm(Op(Pm, Tp, bs1=H * T * Tp, bs2=T * Tp), Op(qkv, 3 * E, bs1=T * 3 * E, bs2=D, offset=2 * E), d["ctx"], T, D, T, b_t=True,
                      nb1=B, nb2=H, ldc=E, c_bs1=T * E, c_bs2=D)
-            ops.gemm(Op(d["ctx"], E), Wf(pn + "self_attn.out_proj.weight", E), d["x1"], M, E, E, bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
-            ops.layernorm_fwd(d["x1"], self.b(pn + "final_layer_norm.weight"), self.b(pn + "final_layer_norm.bias"), None, d["h"], mean, rstd, M, E)
-            ops.gemm(Op(d["h"], E), Wf(pn + "fc1.weight", E), d["a"], M, Fd, E, bias=self.b(pn + "fc1.bias"), act=ACT_GELU)
-            ops.gemm(Op(d["a"], Fd), Wf(pn + "fc2.weight", Fd), xout, M, E, Fd, bias=self.b(pn + "fc2.bias"), R=d["x1"], rmode=1)
+            lin(d["ctx"], E, pn + "self_attn.out_proj.weight", E, d["x1"], bias=self.b(pn + "self_attn.out_proj.bias"), R=xin, rmode=1)
+            if use3 and ffn3:
+                # fc1 writes gelu(.) as the triple-plane image itself (SCL_GEMM_C_SPLIT3: no f32 activation, no split pass) and fc2 reads it
+                ln_then_lin(d["x1"], pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", E, pn + "fc1.weight", Fd, d["a3b"],
+                            bias=self.b(pn + "fc1.bias"), act=ACT_GELU, ldc=3 * Fd, split3=True)
+                ops.gemm(Op(d["a3b"], 3 * Fd), Op(self._w3(fw, pn + "fc2.weight", E, Fd), 3 * Fd), xout, M, E, 3 * Fd, bias=self.b(pn + "fc2.bias"),
+                         R=d["x1"], rmode=1)
+            else:
+                ln_then_lin(d["x1"], pn + "final_layer_norm.weight", pn + "final_layer_norm.bias", E, pn + "fc1.weight", Fd, d["a"],
+                            bias=self.b(pn + "fc1.bias"), act=ACT_GELU)
+                lin(d["a"], Fd, pn + "fc2.weight", E, xout, bias=self.b(pn + "fc2.bias"), R=d["x1"], rmode=1)
             xin, xout = xout, xin
         ops.layernorm_fwd(xin, self.b("encoder.layer_norm.weight"), self.b("encoder.layer_norm.bias"), None, d["out"], mean, rstd, M, E)
         return d["out"], T

@@ -88,6 +88,7 @@ GEMM_FORCE_W8 = 0x02000000
 GEMM_FORCE_X2 = 0x08000000
 GEMM_NO_X2 = 0x10000000
 GEMM_AB_F32 = 0x40000000
+GEMM_C_SPLIT3 = -0x80000000      # bit 31 of the int32 flag word: bf16 C as [hi | hi | lo] planes (wide tiles only)
 GEMM_F32X3 = 0x20000000
 ACT_SHIFT, RMODE_SHIFT, RACT_SHIFT = 8, 12, 16
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
@@ -154,6 +155,7 @@ def _protos():
         "scl_colsum_reduce": ([_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp], _i32),
         # elementwise.hip
         "scl_cast_f32_bf16": ([_vp, _vp, _i64, _vp], _i32),
+        "scl_split3_f32_bf16": ([_vp, _i64, _i32, _i64, _vp, _i32, _vp], _i32),
         "scl_add_f32": ([_vp, _vp, _vp, _vp, _i64, _vp], _i32),
         "scl_pad_rows_bf16": ([_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
         "scl_col2im_bf16": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),

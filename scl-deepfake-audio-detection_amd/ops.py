@@ -124,15 +124,18 @@ def _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, f32):
 
 def gemm(A, B, C, M, N, K, *, a_t=False, b_t=False, bias=None, act=0, c2=None, R=None, rmode=0, ract=0,
          alpha=1.0, nb1=1, nb2=1, splitk=1, ldc=None, c_rpb=FLAT, c_rbstride=0, c_bs1=0, c_bs2=0,
-         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None, x3=None):
+         c_offset=0, bias_bs2=0, bias_offset=0, drop_p=0.0, drop_seed=0, c_split_stride=0, no_dma=False, no_big=False, no_p8=False, force_p8=False, force_big=False, no_w8=False, force_w8=False, force_x2=False, no_x2=False, colsum_part=None, x3=None, split3=False):
     """C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] B[z][n][k]) — see include/scl_hip.h.
-    x3 (f32 operands only): the bf16-pair form of the f32 kernel (SCL_GEMM_F32X3); None = the module default F32X3, False = the exact kernel."""
+    x3 (f32 operands only): the bf16-pair form of the f32 kernel (SCL_GEMM_F32X3); None = the module default F32X3, False = the exact kernel.
+    split3: C (bf16, ldc = 3 N) receives the triple-plane row image of the result (see scl_split3_f32_bf16)."""
     d = _gemm_desc(A, B, C, M, N, K, a_t=a_t, b_t=b_t, bias=bias, act=act, c2=c2, R=R, rmode=rmode, ract=ract, alpha=alpha, nb1=nb1,
                    nb2=nb2, splitk=splitk, ldc=ldc, c_rpb=c_rpb, c_rbstride=c_rbstride, c_bs1=c_bs1, c_bs2=c_bs2, c_offset=c_offset,
                    bias_bs2=bias_bs2, bias_offset=bias_offset, drop_p=drop_p, drop_seed=drop_seed, c_split_stride=c_split_stride,
                    no_dma=no_dma, no_big=no_big, no_p8=no_p8, force_p8=force_p8, force_big=force_big, no_w8=no_w8, force_w8=force_w8,
                    force_x2=force_x2, no_x2=no_x2, colsum_part=colsum_part, x3=x3)
-    sk = _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, A.t.dtype == torch.float32)
+    if split3:      # bf16 C as [hi | hi | lo] planes of N columns (ldc = 3 N): SCL_GEMM_C_SPLIT3, wide tiles only (SclError otherwise)
+        d.flags |= L.GEMM_C_SPLIT3
+    sk = 1 if split3 else _auto_splitk(M, N, K, a_t, nb1, nb2, splitk, A.t.dtype == torch.float32)
     if sk > 1 and not (force_w8 or force_p8 or force_big or force_x2):
         key = (C.device.index, torch.cuda.current_stream(C.device).cuda_stream)
         ws = _SPLITK_WS.get(key)
@@ -382,6 +385,11 @@ def colsum_reduce(x, part, out, M, N, ld=None):
 
 def cast_bf16(src, dst, n=None):
     _call("scl_cast_f32_bf16", _p(src), _p(dst), n or src.numel(), _stream())
+
+
+def split3(x, rows, K, out, order, ldx=None, x_offset=0):
+    """f32 [rows][K] -> bf16 [rows][3 K] as [hi | hi | lo] (order 0) / [hi | lo | hi] (order 1): csrc/elementwise.hip split3_kernel."""
+    _call("scl_split3_f32_bf16", _ptr(x, x_offset), rows, K, ldx or K, _p(out), order, _stream())
 
 
 def add_f32(a, b, out, out_bf16, n):

@@ -250,7 +250,7 @@ def test_hip_backend_matches_the_reference_golden(dev, case, tag):
     BASELINE map ("199:": 42 x 66, 66 nodes — 33 kept by the first pools, the fused kernels' 256-position tiles) and an odd width ("202:":
     67 nodes); at the two big sizes EVERY parameter gradient is checked and the fused kernels (resstack.hip, graph.hip) must be the path
     that ran.  Top-k ties: the fused pool orders equal scores by index, torch.topk by its own rule; the random inputs hold none.
-    Bounds: outputs 2e-5 at every size (measured 2e-6).  Gradients 2e-4 on the small map; on the big maps 5e-3 of the tensor's largest
+    Bounds: outputs 2e-5 at every size (measured 2e-6).  Gradients 2e-4 on the small map; on the big maps 2e-3 (round 6; was 5e-3) of the tensor's largest
     magnitude: SELU's derivative jumps 1.758 -> 1.051 at zero, and among the 5 M pre-activations of a 4 x 42 x 66 stack one can land within
     fp32 rounding of zero on the other side of where the reference's own rounding put it — a sparse O(1) difference in ONE element's
     derivative that spreads into the tensors upstream of it (measured with tools/aasist_golden_probe.py: every tensor of `199:train` and
@@ -287,7 +287,7 @@ def test_hip_backend_matches_the_reference_golden(dev, case, tag):
         err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
         assert err < tol, "%s: rel err %.3e" % (name, err)
     pre = tag + case
-    gtol = 2e-4 if not tag else 5e-3
+    gtol = 2e-4 if not tag else 2e-3      # round 6: 5e-3 -> 2e-3 (measured <= 1.4e-3: a regression of 40 % is now caught)
     close(logits, G[pre + ":logits"], "logits", 2e-5); close(hidden, G[pre + ":hidden"], "hidden", 2e-5); close(x.grad, G[pre + ":grad_x"], "grad_x", gtol)
     n = check_grads(dict(m.named_parameters()), pre, lambda a, b, name: close(a, b, name, gtol), gtol)
     assert n == (12 if not tag else sum(1 for p in m.parameters() if p.grad is not None)), n

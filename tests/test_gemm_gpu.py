@@ -848,3 +848,79 @@ def test_grouped_launch_over_tile_ranges_covers_every_tile_once(dev):
         assert torch.equal(p[2], S)
     with pytest.raises(ops.L.SclError, match="covers tiles"):
         ops.gemm_group_part([(probs[0], 1, 2)])
+
+
+def test_triple_plane_bf16_gemm_reproduces_the_f32_product(dev):
+    """Round 6, the scoring path's linears: scl_split3_f32_bf16 writes [hi | hi | lo] / [hi | lo | hi] rows (hi = bf16(x), lo = bf16(x - hi)),
+    and ONE bf16 GEMM over 3 K then returns hi.hi + hi.lo + lo.hi.  Checked: the planes themselves (hi + lo reproduces x to 2^-16 relative, hi
+    duplicated where the layout says so), the product against float64 (the f32-pair kernel's 4 - 6e-6 class) and against the f32-pair kernel
+    on the same operands."""
+    M, N, K = 1000, 520, 256
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    a3 = torch.empty(M * 3 * K, dtype=torch.bfloat16, device=dev)
+    w3 = torch.empty(N * 3 * K, dtype=torch.bfloat16, device=dev)
+    ops.split3(A, M, K, a3, 0)
+    ops.split3(W, N, K, w3, 1)
+    av, wv = a3.view(M, 3, K).float(), w3.view(N, 3, K).float()
+    assert torch.equal(av[:, 0], av[:, 1]) and torch.equal(wv[:, 0], wv[:, 2])
+    assert torch.equal(av[:, 0], A.to(torch.bfloat16).float()) and torch.equal(wv[:, 0], W.to(torch.bfloat16).float())
+    for x, hi, lo in ((A, av[:, 0], av[:, 2]), (W, wv[:, 0], wv[:, 1])):
+        assert ((hi + lo - x).abs() <= x.abs() * 2.0 ** -16 + 1e-30).all()
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ops.Op(a3, 3 * K), ops.Op(w3, 3 * K), C, M, N, 3 * K)
+    ref = A.double() @ W.double().t()
+    err = ((C.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+    C2 = torch.empty(M, N, device=dev)
+    ops.gemm(ops.Op(A, K), ops.Op(W, K), C2, M, N, K, x3=True)
+    assert ((C - C2).abs().max() / ref.abs().max()).item() < 2e-5
+    # a row pitch larger than K (a view into a wider buffer) and the refusals
+    wide = torch.randn(64, 320, generator=g).to(dev)
+    o = torch.empty(64 * 3 * 256, dtype=torch.bfloat16, device=dev)
+    ops.split3(wide, 64, 256, o, 0, ldx=320)
+    assert torch.equal(o.view(64, 3, 256)[:, 0].float(), wide[:, :256].to(torch.bfloat16).float())
+    with pytest.raises(ops.L.SclError):
+        ops.split3(wide, 64, 100, o, 0, ldx=320)          # K not a multiple of 8
+
+
+def test_layernorm_writes_the_triple_plane_operand_itself(dev):
+    """scl_layernorm_fwd with act | 0x100: the [hi | hi | lo] row image must equal the split pass applied to the kernel's own f32 output."""
+    M, C = 403, 1024
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, C, generator=g) * 3 + 0.7).to(dev)
+    gam, bet = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    y = torch.empty(M, C, device=dev)
+    ops.layernorm_fwd(x, gam, bet, None, y, mean, rstd, M, C)
+    want = torch.empty(M * 3 * C, dtype=torch.bfloat16, device=dev)
+    ops.split3(y, M, C, want, 0)
+    got = torch.full((M * 3 * C,), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.layernorm_fwd(x, gam, bet, got, None, mean, rstd, M, C, act=0x100)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), gam.double(), bet.double())
+    v = got.view(M, 3, C).float()
+    assert (((v[:, 0] + v[:, 2]).double() - ref).abs() <= ref.abs() * 2.0 ** -15 + 1e-5).all()      # hi + lo carries 16 mantissa bits
+
+
+def test_wide_tile_epilogue_writes_the_triple_plane_image(dev):
+    """SCL_GEMM_C_SPLIT3 (round 6: the scoring path's fc1 -> fc2 hand-over): the wide-tile epilogue stores bias + GELU of the product as the
+    row image [hi | hi | lo] (ldc = 3 N) — bit for bit what scl_split3_f32_bf16 makes of the same launch's f32 output — on 208- and 112-row
+    tiles; a launch that would not run on the wide tiles is refused, not served wrongly."""
+    for M, N, K in ((12864, 4096, 3072), (6368, 1024, 512)):      # 208-row tiles; 112-row tiles (57 x 4)
+        g = torch.Generator().manual_seed(M)
+        A = _rand((M, K), dev, 61, 0.3); W = _rand((N, K), dev, 62, 0.05)
+        bias = torch.randn(N, generator=g).to(dev)
+        Cf = torch.empty(M, N, device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(W, K), Cf, M, N, K, bias=bias, act=1, force_w8=True)
+        want = torch.empty(M * 3 * N, dtype=torch.bfloat16, device=dev)
+        ops.split3(Cf, M, N, want, 0)
+        got = torch.full((M * 3 * N,), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.Op(A, K), ops.Op(W, K), got, M, N, K, bias=bias, act=1, ldc=3 * N, split3=True)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (M, N, K)
+    small = torch.empty(64 * 3 * 64, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ops.L.SclError, match="wide-tile kernel only"):
+        ops.gemm(ops.Op(_rand((64, 64), dev, 1, 0.3), 64), ops.Op(_rand((64, 64), dev, 2, 0.3), 64), small, 64, 64, 64, ldc=192, split3=True)
+    with pytest.raises(ops.L.SclError, match="ldc = 3 N"):
+        ops.gemm(ops.Op(A, K), ops.Op(W, K), got, M, N, K, ldc=N, split3=True)

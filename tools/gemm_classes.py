@@ -57,8 +57,18 @@ def classify(meta, H):
 
 def alg_bytes(meta, H):
     M, N, K, flags, z, variant = meta[:6]
-    if variant >= 4:
-        return None
+    if variant == 4:
+        # grouped weight gradients: `flags` tiles of 256 x 256 out of the 192 a transformer layer has (fc2 64, fc1 64, out 16, qkv 48); a
+        # layer's eight operand matrices are 16384 columns of bf16 over K rows, its four outputs 12.6 M f32
+        tiles = flags
+        return tiles / 192.0 * 16384 * K * 2, tiles * 256 * 256 * 4
+    if variant == 5:
+        # pos-conv (16 groups x 64 channels, 128 taps): M = B T rows (fwd / dgrad) or K = B T (wgrad); padded slab rows ~ M (1 + 128 / 199)
+        if flags == 2:
+            return 2 * K * N * 2 * 1.64, M * N * 4 / 1.0
+        return M * N * 2 * 1.64 + K * N // 16 * 2 + M * N * 4, M * N * 4 + (M * N * 2 if flags == 1 else 0)
+    if variant == 6:
+        variant = 2
     zz = max(1, z)
     out = M * N * (4 if flags & H["C_F32"] else 2) * zz
     rd = (M * K + N * K) * 2 * (zz if zz > 1 and not (flags & H["C_F32"]) else 1)
@@ -128,6 +138,7 @@ def main():
                 cls[k][name].append(v * 1024.0 * (2.0 if name == "fetch" else 1.0))      # KiB -> bytes; FETCH_SIZE doubled (gfx950)
     tot_ms = sum(e["ms"] for e in cls.values())
     tot_fl = 0.0
+    fam_meas = fam_alg = 0.0
     print("# GEMM family of `python bench.py` (batch %d x %d, %s), %d profiled steps, sources %s" % (d["batch"], d["samples"], d["model"], nstep, d["gemm_src_sha"]))
     print("# us = mean launch duration from the launch's own dispatch time stamps (what roofline.frac sums); FETCH = FETCH_SIZE x 2 (gfx950), "
           "WRITE = WRITE_SIZE, from separate --pmc passes joined by dispatch order; alg = unique operand bytes read / output bytes written")
@@ -137,7 +148,7 @@ def main():
         (M, N, K), lay, epi = k
         meta = e["meta"]
         if meta[5] == 4:
-            fl = None
+            fl = 2.0 * 256 * 256 * K * meta[3]      # `flags` = tiles of the launch
         else:
             fl = 2.0 * M * N * K * (max(1, meta[4]) if meta[5] < 4 and not (meta[3] & H["C_F32"] and meta[4] > 1) else 1)
             if meta[5] < 4 and (meta[3] & H["C_F32"]) and meta[4] > 1:
@@ -153,7 +164,14 @@ def main():
             fmt(fe), fmt(ab[0] / 1e6 if ab else None), fmt(wr), fmt(ab[1] / 1e6 if ab else None), fmt(ratio, "%6.2f")))
         if fl:
             tot_fl += fl * e["n"]
+        if ab and fe is not None and wr is not None:
+            fam_meas += (fe + wr) * e["n"] / nstep
+            fam_alg += (ab[0] + ab[1]) / 1e6 * e["n"] / nstep
     print("# total %.3f ms of GEMM-family launches per step, %d launches per step" % (tot_ms / nstep, len(L) // nstep))
+    if fam_alg > 0:
+        nl = len(L) // nstep
+        print("# family traffic per step: measured (FETCH x 2 + WRITE) %.1f GB vs algorithmic %.1f GB = %.2f x; per launch %.0f MB vs %.0f MB"
+              % (fam_meas / 1e3, fam_alg / 1e3, fam_meas / fam_alg, fam_meas / nl, fam_alg / nl))
 
 
 if __name__ == "__main__":

@@ -1,12 +1,12 @@
 # Kernel summary of the STEADY-STATE steps of a bench.py run (the last 3 optimizer steps of the rocprofv3 kernel trace: warm-up, model
 # construction and plan building are left out — rocprofv3's own --stats table sums the whole process).
-#   bash tools/steady_state_profile.sh <tag> <bench.py arguments...>     ->  gpurun_out/r5_<tag>_steady_state.txt
+#   bash tools/steady_state_profile.sh <tag> <bench.py arguments...>     ->  gpurun_out/${ROUND:-r6}_<tag>_steady_state.txt
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 rm -rf gpurun_out/prof_ss
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_ss -o bench -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 "$@" > gpurun_out/prof_ss_$tag.log 2>&1
-python3 - "$tag" "$*" <<'PY' > gpurun_out/r5_${tag}_steady_state.txt
+python3 - "$tag" "$*" <<'PY' > gpurun_out/${ROUND:-r6}_${tag}_steady_state.txt
 import csv, glob, collections, sys
 tag, args = sys.argv[1], sys.argv[2]
 f = glob.glob('gpurun_out/prof_ss/**/*kernel_trace.csv', recursive=True)[0]
@@ -30,6 +30,6 @@ print("--- every at::native / rocclr row")
 for k, v in sorted(nat, key=lambda kv: -kv[1][0]):
     print("%-98s %6.1f calls %8.1f us %7.3f ms/step %5.3f%%" % (k, v[1] / n, v[0] / 1e3 / v[1], v[0] / 1e6 / n, 100 * v[0] / tot))
 PY
-head -3 gpurun_out/r5_${tag}_steady_state.txt | cut -c1-300
-sed -n '/--- every/,$p' gpurun_out/r5_${tag}_steady_state.txt | cut -c1-180
+head -3 gpurun_out/${ROUND:-r6}_${tag}_steady_state.txt | cut -c1-300
+sed -n '/--- every/,$p' gpurun_out/${ROUND:-r6}_${tag}_steady_state.txt | cut -c1-180
 rm -rf gpurun_out/prof_ss
