@@ -591,14 +591,20 @@ __global__ __launch_bounds__(512, 2) void scl_gemm_w8s_group_kernel(const GemmGr
     W8GArg gp = (W8GArg)__builtin_amdgcn_kernarg_segment_ptr();
     const int total = g.first[W8_GROUP_MAX];
     const int x = blockIdx.x & 7, idx = blockIdx.x >> 3, q = total >> 3, r = total & 7;
+#ifdef SCL_EXPERIMENTS      // the experiment build keeps round 5's per-member XCD runs selectable (SCL_WGRAD_XCD_MAJOR=0: profiles/r6_group_xcd_major.txt)
     const int pos = (g.xcd_major ? ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx) : (int)blockIdx.x);
+#else
+    const int pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+#endif
     int mem = 0;
 #pragma unroll
     for (int i = 1; i < W8_GROUP_MAX; ++i) mem += (i < g.n && pos >= g.first[i]) ? 1 : 0;
     mem = __builtin_amdgcn_readfirstlane(mem);
     const int t = __builtin_amdgcn_readfirstlane(pos - gp->first[mem] + gp->tile0[mem]);
-    if (g.xcd_major) w8s_tile<AT, BT, RB0, RB1, true>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0);
-    else w8s_tile<AT, BT, RB0, RB1, false>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0);
+#ifdef SCL_EXPERIMENTS
+    if (!g.xcd_major) { w8s_tile<AT, BT, RB0, RB1, false>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0); return; }
+#endif
+    w8s_tile<AT, BT, RB0, RB1, true>(*(const GemmK*)&gp->k[mem], smem, t, gp->ntiles[mem], 0);      // (one instantiation in the shipped library: the tile body is 120 KB of code)
 }
 
 #ifdef SCL_EXPERIMENTS      // opt-in experiment, not part of the shipped library (see gemm.hip)
@@ -909,8 +915,12 @@ int scl_gemm_w8_group_launch(GemmK* ks, int n, const int* tile0, const int* ntil
     }
     for (int i = n; i <= W8_GROUP_MAX; ++i) g.first[i] = total;
     g.n = n;
+#ifdef SCL_EXPERIMENTS
     static const int xcd_major = [] { const char* e = getenv("SCL_WGRAD_XCD_MAJOR"); return e ? atoi(e) : 1; }();      // 0: round 5's per-member XCD runs (A/B)
     g.xcd_major = xcd_major;
+#else
+    g.xcd_major = 1;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)scl_gemm_w8s_group_kernel<true, true, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);

@@ -56,3 +56,5 @@ timeout 1500 python3 tools/data_path_probe.py 2>&1 | grep -v "amdgpu.ids\|Scores
 for f in gpurun_out/r6_bench_default.json gpurun_out/r6_bench_b32_norawboost.json gpurun_out/r6_bench_pack11.json gpurun_out/r6_bench_eval_b64.json gpurun_out/r6_bench_wav2vec2_aasist_b64.json gpurun_out/r6_bench_wav2vec2_aasist_b32.json gpurun_out/r6_bench_wav2vec2_resnet_nll_b32.json gpurun_out/r6_bench_wav2vec2_btse_b64.json gpurun_out/r6_bench_wav2vec2_btse_b128.json; do echo $f; cut -c1-330 $f; echo; done
 head -4 gpurun_out/r6_bench_default_steady_state.txt | cut -c1-250
 tail -4 gpurun_out/r6_gemm_classes.txt
+timeout 2400 python3 -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/r6_full_gpu_tests.log
+cat gpurun_out/r6_full_gpu_tests.log
