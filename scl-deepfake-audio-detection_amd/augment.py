@@ -435,16 +435,30 @@ def _dbfs(sumsq, n):
     return -float("inf") if rms == 0 else 20 * math.log(rms / 32768.0, 10)      # pydub.utils.ratio_to_db spells log10 this way
 
 
-def background_noise(x, noise_i16, snr_db):
+def host_i16_sumsq(x):
+    """sum of squares of librosa_to_pydub(x) (utils.py:24-30: int16(x * 32768) by C cast — truncation toward zero, +1.0 wraps to -32768),
+    evaluated on the host from the float32 samples: the exact integer scl_f32_to_i16_wrap + scl_i16_sumsq produce on the device.  Lets
+    background_noise() run without its host <- device round trip (round 6: that `.tolist()` was the pack builder's one synchronisation per
+    pack — the builder thread sat out the queueing delay of every kernel it had issued before it, on a GPU saturated by the training step)."""
+    v = np.trunc(np.asarray(x, dtype=np.float32) * np.float32(32768.0)).astype(np.int64)
+    v = ((v + 32768) % 65536) - 32768
+    return int((v * v).sum())
+
+
+def background_noise(x, noise_i16, snr_db, sumsq=None):
     """BackgroundNoiseAugmentor.transform (background_noise.py:40-56) with the noise file and
-    SNR_dB = random.randint(5, 15) given; pydub / audioop integer semantics, bit-exact."""
+    SNR_dB = random.randint(5, 15) given; pydub / audioop integer semantics, bit-exact.
+    sumsq = (speech, noise) sums of squares of the two int16 signals when the caller already has them (host_i16_sumsq: no device sync)."""
     dev = x.device
     sp = to_int16(x)
     n, nn = sp.numel(), noise_i16.numel()
-    parts = torch.zeros(2, 64, dtype=torch.int64, device=dev)
-    ops.i16_sumsq(sp, n, parts[0], 64)
-    ops.i16_sumsq(noise_i16.contiguous(), nn, parts[1], 64)
-    sums = parts.sum(1).tolist()                      # host sync: two integers per clip
+    if sumsq is not None:
+        sums = [int(sumsq[0]), int(sumsq[1])]
+    else:
+        parts = torch.zeros(2, 64, dtype=torch.int64, device=dev)
+        ops.i16_sumsq(sp, n, parts[0], 64)
+        ops.i16_sumsq(noise_i16.contiguous(), nn, parts[1], 64)
+        sums = parts.sum(1).tolist()                      # host sync: two integers per clip
     sig_db, noi_db = _dbfs(sums[0], n), _dbfs(sums[1], nn)
     gain = snr_db * noi_db / sig_db                   # (sic) background_noise.py:52
     factor = 10.0 ** (gain / 20.0)

@@ -15,6 +15,7 @@ stream (allocator safety).  Exceptions of a producer surface in the consumer.  L
 from the process-wide `random` / `np.random` streams in whatever order they run: every draw has the right distribution, the assignment of
 draws to packs is not reproducible (SCL_PREFETCH_THREADS=1 restores one sequential stream).
 """
+import collections
 import os
 import queue
 import sys
@@ -45,8 +46,10 @@ class Prefetcher:
         return len(self.loader)
 
     def _parallel_ok(self):
+        # a plain in-process DataLoader is driven from its batch_sampler (also with ONE builder: the index batches are then known two
+        # ahead, which is what lets the dataset decode the next items' files on its decoder threads: PackDataset.decode_ahead)
         ld = self.loader
-        return (self.workers > 1 and isinstance(ld, torch.utils.data.DataLoader) and ld.num_workers == 0 and ld.batch_sampler is not None
+        return (isinstance(ld, torch.utils.data.DataLoader) and ld.num_workers == 0 and ld.batch_sampler is not None
                 and not isinstance(ld.dataset, torch.utils.data.IterableDataset))
 
     def __iter__(self):
@@ -62,7 +65,9 @@ class Prefetcher:
         slots = threading.Semaphore(self.depth + self.workers)      # batches built or being built but not yet consumed
         stop = threading.Event()
         done = {}                    # sequence number -> (item | exception, event)
-        state = {"next": 0, "end": None}
+        state = {"next": 0, "end": None, "drained": False}
+        ahead = collections.deque()
+        hint = _decode_hint(dataset)
 
         def build(wid):
             side = torch.cuda.Stream(device=self.device) if use_gpu else None
@@ -75,15 +80,23 @@ class Prefetcher:
                         if not slots.acquire(timeout=0.1):
                             continue
                         with lock:                      # the sampler is not thread-safe; the sequence number fixes the hand-over order
-                            try:
-                                idxs = next(batches)
-                            except StopIteration:
+                            while len(ahead) < self.workers + 2 and not state["drained"]:      # index batches drawn (and hinted) ahead of their build
+                                try:
+                                    nb = next(batches)
+                                except StopIteration:
+                                    state["drained"] = True
+                                    break
+                                ahead.append(nb)
+                                if hint is not None:
+                                    hint(nb)
+                            if not ahead:
                                 if state["end"] is None:
                                     state["end"] = state["next"]
                                 slots.release()
                                 with cv:
                                     cv.notify_all()
                                 return
+                            idxs = ahead.popleft()
                             seq = state["next"]
                             state["next"] += 1
                         try:
@@ -191,6 +204,21 @@ class Prefetcher:
             stop.set()
             th.join(timeout=5.0)
             sys.setswitchinterval(old_switch)
+
+
+def _decode_hint(dataset):
+    """dataset.decode_ahead(indices) if the dataset (or the dataset under a Subset) offers it: the prefetcher tells it which items come next."""
+    idx_map = None
+    while isinstance(dataset, torch.utils.data.Subset):
+        inner = dataset.indices
+        idx_map = inner if idx_map is None else [inner[i] for i in idx_map]
+        dataset = dataset.dataset
+    fn = getattr(dataset, "decode_ahead", None)
+    if fn is None:
+        return None
+    if idx_map is None:
+        return lambda idxs: fn(list(idxs))
+    return lambda idxs: fn([idx_map[i] for i in idxs])
 
 
 class _null:

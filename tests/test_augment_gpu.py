@@ -83,6 +83,13 @@ def test_background_noise_and_int16_conversion(dev):
         got = AUG.background_noise(torch.from_numpy(sp).to(dev), torch.from_numpy(noise).to(dev), snr).cpu().numpy()
         ref, _ = AI.background_noise(sp, noise, snr)
         assert np.array_equal(got, ref.astype(np.float32))
+        # round 6: the two integer powers handed in from the host (no host <- device round trip in the pack builder): same result
+        nsq = int((noise.astype(np.int64) ** 2).sum())
+        got2 = AUG.background_noise(torch.from_numpy(sp).to(dev), torch.from_numpy(noise).to(dev), snr, sumsq=(AUG.host_i16_sumsq(sp), nsq)).cpu().numpy()
+        assert np.array_equal(got2, got)
+    edge = np.array([1.0, -1.0, 0.99999, -0.00002, 0.5, 0.999985, -0.999985], dtype=np.float32)      # the +1.0 wrap and truncation toward zero
+    i16 = AUG.to_int16(torch.from_numpy(edge).to(dev)).cpu().numpy().astype(np.int64)
+    assert AUG.host_i16_sumsq(edge) == int((i16 * i16).sum())
     g = np.load(os.path.join(G, "audio_int16.npz"))      # librosa_to_pydub -> pydub_to_librosa executed by the reference
     assert AUG.to_int16(torch.from_numpy(g["conv:in"]).to(dev)).cpu().numpy().tolist() == g["conv:out"].tolist()
 

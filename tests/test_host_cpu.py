@@ -230,6 +230,38 @@ def test_parallel_prefetcher_builds_on_several_threads_and_hands_over_in_order()
     assert list(Prefetcher(range(5), workers=4)) == list(range(5))
 
 
+def test_prefetcher_hints_the_dataset_which_items_come_next():
+    """Round 6: a dataset with decode_ahead(indices) (scl_amd.pack.PackDataset: decode the next packs' files on decoder threads) is told the
+    index batches ahead of their build — every item is hinted before it is built, through a Subset with the base dataset's indices."""
+    from torch.utils.data import DataLoader, Dataset, Subset
+    from scl_amd.prefetch import Prefetcher
+    log = []
+
+    class DS(Dataset):
+        def __len__(self):
+            return 40
+
+        def decode_ahead(self, idxs):
+            log.append(("hint", tuple(idxs)))
+
+        def __getitem__(self, i):
+            log.append(("build", i))
+            return torch.tensor([float(i)])
+
+    sub = Subset(DS(), list(range(39, 9, -1)))          # 30 items, base indices 39 .. 10
+    got = [int(b[0, 0]) for b in Prefetcher(DataLoader(sub, batch_size=1, shuffle=False, num_workers=0), workers=1)]
+    assert got == list(range(39, 9, -1))
+    hinted = set()
+    for kind, v in log:
+        if kind == "hint":
+            hinted.update(v)
+        else:
+            assert v in hinted, (v, sorted(hinted))     # hinted (with the BASE index) before it was built
+    assert hinted == set(range(10, 40))
+    first_build = next(i for i, (k, _) in enumerate(log) if k == "build")
+    assert sum(1 for k, _ in log[:first_build] if k == "hint") >= 2          # at least two batches ahead when the first build starts
+
+
 def test_threaded_scoring_loop_writes_the_same_lines_in_protocol_order(tmp_path):
     """main._score_loop (round 6): decoder threads + results read back one batch late must produce exactly the score file of the plain
     DataLoader loop — both through per-item __getitem__ futures and through EvalDataset-style load_into rows (a ragged last batch included)."""

@@ -96,6 +96,9 @@ class Rep(torch.utils.data.Dataset):
     def __getitem__(self, i):
         return self.ds[i % len(ids)]
 
+    def decode_ahead(self, idxs):
+        self.ds.decode_ahead([i % len(ids) for i in idxs])
+
 
 print("== 1. pack builder alone (11-view conf-3 packs from FLAC; builder threads of scl_amd.prefetch, each on its own HIP stream)")
 for sampler in (("reference", "fast") if "1" in PARTS else ()):
