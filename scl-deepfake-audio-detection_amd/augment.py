@@ -415,10 +415,10 @@ def reverb(x, rir):
     if R >= _RIR_GEMM_MIN_TAPS and RIR_GEMM:
         y, part, _ = _rir_full_conv_gemm(x.contiguous().float(), rir)
     else:
-        i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)
+        z0, zr = _h2d_pack([np.zeros(1, dtype=np.int32), np.array([R], dtype=np.int32)], dev)
         y = torch.empty(Lout, device=dev)
         part = torch.empty(ops.fir_nblocks(Lout) * 4, device=dev)
-        ops.fir_multi(x.contiguous(), L, L, rir.contiguous().float(), i32(0), i32(R), i32(0), 1, 1, False, y, Lout, Lout, part)
+        ops.fir_multi(x.contiguous(), L, L, rir.contiguous().float(), z0, zr, z0, 1, 1, False, y, Lout, Lout, part)
     out = torch.empty(Lout, device=dev)
     ops.clip_affine(ops.AFF_PEAK_QUANT_I16, y, Lout, part, out, Lout, Lout, 1)
     return out
@@ -583,8 +583,8 @@ def multiview_crop(views, length, repeat_pad, random_trim=True):
     else:
         start, out_len = 0, length
     src = torch.cat([v.reshape(-1).float() for v in views])
-    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64), device=dev)
+    # offsets and lengths through one pinned, asynchronous copy (a torch.tensor(..., device=) is a blocking copy behind the whole pack's chain)
+    off, lens_d = _h2d_pack([np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64), np.asarray(lens, dtype=np.int32)], dev)
     out = torch.empty(len(views), out_len, device=dev)
-    ops.multiview_crop(src, off, torch.tensor(lens, dtype=torch.int32, device=dev), len(views), firstlen, start, out_len,
-                       repeat_pad, out, out_len)
+    ops.multiview_crop(src, off, lens_d, len(views), firstlen, start, out_len, repeat_pad, out, out_len)
     return out

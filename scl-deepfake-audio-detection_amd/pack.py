@@ -205,9 +205,20 @@ def bank_tensor(path, sr, args, kind):
 
 
 def _to_dev(x, args):
+    """Host samples -> device.  Through pinned staging + an ASYNCHRONOUS copy (round 6): a plain `.to(device)` of pageable memory is a
+    blocking copy that first waits for everything queued on the builder's stream — eleven times per conf-3 pack, each time behind the
+    whole augmentation chain of the previous view, on a GPU the training step keeps saturated: the builder then runs at the pace of its
+    kernels' queueing delays (the bimodal 1.05 x / 1.9 x steps of profiles/r6_pack_builder.txt).  The caching host allocator hands a
+    pinned block out again only after the copy that reads it has completed."""
+    dev = _dev(args)
     if torch.is_tensor(x):
-        return x.to(_dev(args), dtype=torch.float32)
-    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_dev(args))
+        return x.to(dev, dtype=torch.float32)
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if dev.type != "cuda":
+        return torch.from_numpy(a).to(dev)
+    host = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)
+    host.numpy()[...] = a
+    return host.to(dev, non_blocking=True)
 
 
 # ---- augmenters, resolved by name (augall_3:271-374) ---------------------------------------------
@@ -434,7 +445,14 @@ class PackDataset(Dataset):
             views, n_pos = [real] + aug_real + add_real + voc + aug_voc + add_spoof, 1 + len(aug_real) + len(add_real)
         dev_views = [_to_dev(v, self.args).reshape(-1) for v in views]
         pack = augment.multiview_crop(dev_views, self.trim_length, self.repeat_pad, random_trim=True)   # [V, L]
-        label = torch.tensor([1.0] * n_pos + [0.0] * (len(views) - n_pos))
+        lab = np.asarray([1.0] * n_pos + [0.0] * (len(views) - n_pos), dtype=np.float32)
+        if pack.is_cuda:
+            # the labels travel with the pack (pinned + asynchronous, on the builder's stream): as a host tensor they cost the TRAINING loop a
+            # blocking `.to(device)` per step (main.run_epoch / the reference's train_epoch: batch_y.to(device)), i.e. one full
+            # synchronisation of the launch thread with the GPU per optimizer step
+            label = augment._h2d_pack([lab], pack.device)[0]
+        else:
+            label = torch.from_numpy(lab)
         return uid, pack.t(), label
 
 

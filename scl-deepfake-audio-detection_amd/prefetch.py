@@ -5,12 +5,13 @@ forked workers are out (the parent has initialised the GPU) — THREADS build th
 behind ctypes), numpy filter design and the C-ABI launches all release the GIL, and every builder thread issues its kernels on its OWN
 HIP stream, so they overlap the training step's kernels instead of queueing behind them.
 
-Round 6: one builder thread made 98 packs/s = 1078 utterances/s against a GPU that trains 1500+.  What fixed it was the builder's own cost
-(fast sampler without a 64000-element permutation per clip, a 1.3 - 1.5 x faster FLAC decoder that writes mono float32 in one pass: 158
-packs/s on ONE thread); `workers` > 1 threads can take the DataLoader's own index batches (its batch_sampler: shuffle / drop_last / Subset
-semantics unchanged) one sequence number each, build them concurrently and hand them over IN ORDER — measured, that raises the builder
-alone to 186 packs/s and LOWERS the training rate (the builders and the launch thread share one interpreter lock), so it is opt-in
-(SCL_PREFETCH_THREADS).  With one worker (or a loader that is not a plain in-process DataLoader) the loader is iterated on one thread.  Hand-over is an event: the consumer's stream waits for it and the tensors are marked as used on that
+Round 6: one builder thread made 98 packs/s = 1078 utterances/s against a GPU that trains 1500+.  What fixed it: the builder no longer
+synchronises with the GPU (scl_amd/pack.py, augment.py: pinned asynchronous uploads, host-side integer powers), costs less (fast sampler, a
+1.3 - 1.5 x faster one-pass FLAC decoder) and finds its files decoded AHEAD: a plain in-process DataLoader is driven from its batch_sampler
+(shuffle / drop_last / Subset semantics unchanged), so the index batches are known two ahead and the dataset is hinted
+(`decode_ahead(indices)`, decoder threads in C).  `workers` > 1 builder threads take one sequence number each and hand over IN ORDER —
+measured, they never beat one builder inside a training run (they share the interpreter lock with the launch thread): opt-in
+(SCL_PREFETCH_THREADS).  Any other iterable is simply iterated on one thread.  Hand-over is an event: the consumer's stream waits for it and the tensors are marked as used on that
 stream (allocator safety).  Exceptions of a producer surface in the consumer.  Like the reference's workers, concurrent builders draw
 from the process-wide `random` / `np.random` streams in whatever order they run: every draw has the right distribution, the assignment of
 draws to packs is not reproducible (SCL_PREFETCH_THREADS=1 restores one sequential stream).
@@ -25,11 +26,11 @@ import torch
 
 
 def default_workers():
-    """ONE builder thread by default.  Measured on MI355X boxes (profiles/r6_pack_builder.txt): with the fast RawBoost sampler and the
-    round-6 FLAC decoder one thread builds 158 packs/s of 11 views = 1730 utterances/s — more than the 1580 - 1600 the GPU trains at 6 packs per
-    step — and end to end main.run_epoch then runs at 1.04 - 1.07 x the resident-batch step.  Two threads raise the builder ALONE to
-    181 - 186 packs/s, but inside a training run every builder shares the interpreter lock with the launch thread (~760 C calls per
-    step): 2 - 3 builders cost the step 11 - 57 %.  SCL_PREFETCH_THREADS=<n> for hosts / corpora where decoding dominates."""
+    """ONE builder thread by default.  Measured on MI355X boxes (profiles/r6_pack_builder.txt): with no host <-> device synchronisation
+    left in the builder, the fast RawBoost sampler, the round-6 FLAC decoder and the files decoded ahead on decoder threads, one thread
+    builds 227 - 256 packs/s of 11 views = 2500 - 2800 utterances/s — the GPU trains 1580 - 1640 at 6 packs per step — and end to end
+    main.run_epoch runs at 1.03 - 1.13 x the resident-batch step.  More builder threads share the interpreter lock with the launch thread
+    (~760 C calls per step) and never beat one inside a training run (1.05 - 1.27 x).  SCL_PREFETCH_THREADS=<n> to try it anyway."""
     try:
         return max(1, int(os.environ.get("SCL_PREFETCH_THREADS", "1")))
     except ValueError:
