@@ -153,8 +153,8 @@ for packs in (() if "2" not in PARTS else ((3,) if QUICK else (1, 3, 6))):
         step()
     torch.cuda.synchronize()
     t_res = (time.time() - t0) / nsteps * 1e3
-    print("PACKS=%d (%2d utterances per step): resident batch %.1f ms/step = %5.0f utt/s | end to end with 1 / 2 / 3 builder threads: %.1f ms (%.2f x) / %.1f ms (%.2f x) / %.1f ms (%.2f x); 2 threads (the default) = %5.0f utt/s"
-          % (packs, nutt, t_res, nutt / t_res * 1e3, res[1], res[1] / t_res, res[2], res[2] / t_res, res[3], res[3] / t_res, nutt / res[2] * 1e3), flush=True)
+    print("PACKS=%d (%2d utterances per step): resident batch %.1f ms/step = %5.0f utt/s | end to end with 1 / 2 / 3 builder threads: %.1f ms (%.2f x) / %.1f ms (%.2f x) / %.1f ms (%.2f x); 1 thread (the default) = %5.0f utt/s"
+          % (packs, nutt, t_res, nutt / t_res * 1e3, res[1], res[1] / t_res, res[2], res[2] / t_res, res[3], res[3] / t_res, nutt / res[1] * 1e3), flush=True)
 
 if "3" not in PARTS:
     shutil.rmtree(tmp, ignore_errors=True)
