@@ -224,8 +224,44 @@ def _h2d_pack(arrays, dev):
     hv = host.numpy()
     for a, o in zip(arrays, offs):
         hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
-    d = host.to(dev, non_blocking=True)
+    d = upload_async(host, dev)
     return [d[o:o + a.nbytes].view(_TORCH_DT[a.dtype.type]).view(a.shape) for a, o in zip(arrays, offs)]
+
+
+# Host -> device copies made by a thread that runs far AHEAD of the GPU (the trainer's launch thread: ~3 steps ahead, round 6,
+# profiles/r6_bench_default_phase_gaps.txt) go out on an UPLOAD STREAM of their own; the stream that will use the data waits for the copy's
+# event.  A copy queued on the compute stream sits behind 100+ ms of kernels and then costs its own latency there (the switch to the copy
+# path and back); on its own stream it runs when it is issued — steps before its consumer gets there — and the consumer's wait is already
+# satisfied.  Measured (profiles/r6_upload_stream_ab.txt): default step -0.3 ms, pack-11 step -0.18 ms.  A thread whose stream is nearly
+# EMPTY gains nothing and pays the extra stream switch + event per copy (the pack builder alone: 234 -> 198 packs/s), so the prefetcher's
+# builder threads opt out with `use_upload_stream(False)`.
+_UPLOAD = {}
+_UPLOAD_LOCAL = threading.local()
+UPLOAD_STREAM = __import__("os").environ.get("SCL_UPLOAD_STREAM", "1") != "0"
+
+
+def use_upload_stream(on):
+    """per-thread switch (default: on, unless SCL_UPLOAD_STREAM=0)"""
+    _UPLOAD_LOCAL.on = bool(on)
+
+
+def upload_async(host, dev):
+    """pinned host tensor -> device tensor, asynchronously; safe to use on the CURRENT stream of the calling thread."""
+    dev = torch.device(dev)
+    if dev.type != "cuda" or not UPLOAD_STREAM or not getattr(_UPLOAD_LOCAL, "on", True):
+        return host.to(dev, non_blocking=True)
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), threading.get_ident())
+    up = _UPLOAD.get(key)
+    if up is None:
+        up = _UPLOAD[key] = torch.cuda.Stream(device=dev)      # one per launching thread: the pack builder's copies do not queue behind the trainer's
+    with torch.cuda.stream(up):
+        d = host.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(up)
+    cur.wait_event(ev)
+    d.record_stream(cur)      # allocated on the upload stream's pool, consumed (and eventually freed) on `cur`
+    return d
 
 
 _TORCH_DT = {np.float32: torch.float32, np.int32: torch.int32, np.int64: torch.int64, np.float64: torch.float64}

@@ -218,7 +218,7 @@ def _to_dev(x, args):
         return torch.from_numpy(a).to(dev)
     host = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)
     host.numpy()[...] = a
-    return host.to(dev, non_blocking=True)
+    return augment.upload_async(host, dev)      # plain non_blocking copy in a builder thread, upload stream when the trainer's thread builds
 
 
 # ---- augmenters, resolved by name (augall_3:271-374) ---------------------------------------------

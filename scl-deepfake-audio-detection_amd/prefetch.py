@@ -25,6 +25,11 @@ import threading
 import torch
 
 
+def _augment():
+    from . import augment      # imported on first use: the prefetcher itself needs neither scipy nor the HIP library
+    return augment
+
+
 def default_workers():
     """ONE builder thread by default.  Measured on MI355X boxes (profiles/r6_pack_builder.txt): with no host <-> device synchronisation
     left in the builder, the fast RawBoost sampler, the round-6 FLAC decoder and the files decoded ahead on decoder threads, one thread
@@ -75,6 +80,8 @@ class Prefetcher:
             try:
                 if use_gpu:
                     torch.cuda.set_device(self.device)
+                if use_gpu:
+                    _augment().use_upload_stream(False)      # this thread's stream is nearly empty: copies go straight onto it
                 ctx = torch.cuda.stream(side) if use_gpu else _null()
                 with ctx:
                     while not stop.is_set():
@@ -164,6 +171,8 @@ class Prefetcher:
             try:
                 if use_gpu:
                     torch.cuda.set_device(self.device)
+                if use_gpu:
+                    _augment().use_upload_stream(False)      # this thread's stream is nearly empty: copies go straight onto it
                 ctx = torch.cuda.stream(side) if use_gpu else _null()
                 with ctx:
                     for item in self.loader:
