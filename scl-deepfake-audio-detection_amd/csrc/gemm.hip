@@ -348,6 +348,101 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
 }
 
 
+#ifdef SCL_EXPERIMENTS
+// ---- deep-ring variant of the LDS-DMA kernel: the same tile, images, fragment reads and epilogue behind a ring of S stages ------------
+// Round 6 (profiles/r6_pack11_gemm_classes.txt): at M = 11 x 199 rows an N = 1024 linear is 144 tiles — at most one 4-wave workgroup per
+// CU on 144 of the 256 CUs — and the two-stage loop above then runs at the LATENCY of one stage per K step (~1.5 us: 21 - 29 us for a
+// 4.6-GFLOP product, 160 - 220 TFLOP/s).  When the whole grid fits one workgroup per CU nothing else wants the CU's LDS, so this variant
+// spends it on bytes in flight: S - 1 stages of 32 KiB outstanding behind a counted vmcnt and raw barriers (a __syncthreads() would drain
+// the queue).  Loads past the last K tile are issued out of range (no fetch) so that the count is the same in every iteration.
+// Accumulation order is k ascending as above: results are bit-identical to the two-stage kernel's.
+// MEASURED (profiles/r6_small_m_probe.txt, rings of 3 / 4 / 5 stages): no gain — 18.8 vs 20.3 us at K = 1024, 51 vs 54 us at K = 4096, equal
+// under split-K.  The K step of a lone 4-wave workgroup is not waiting for memory: with ONE wave per SIMD its 16 fragment reads (64 KiB of
+// LDS traffic per step and CU = 512 cycles) and its 32 MFMAs (512 cycles) run one after the other, whatever is in flight.  What the small-M
+// launches lack is a second wave per SIMD, not bytes in flight.  Kept for the record behind SCL_EXPERIMENTS (SCL_GEMM_DEEP=1 selects it).
+#ifndef SCL_DEEP_STAGES
+#define SCL_DEEP_STAGES 5
+#endif
+constexpr int DEEP_S = SCL_DEEP_STAGES;
+constexpr int DEEP_LDS = DEEP_S * 2 * TILE_BYTES;      // 5 stages = all 160 KiB
+
+template <bool AT, bool BT, int S>
+__global__ __launch_bounds__(256, 1) void scl_gemm_deep_kernel(const GemmK d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, (d.M + BM - 1) / BM, tiles_n, tm, tn, d.group_m);
+    const int m0 = tm * BM, n0 = tn * BN;
+    int z = blockIdx.z;
+    const int ksplit = __builtin_amdgcn_readfirstlane(z % d.splitk); z /= d.splitk;
+    const int z1 = __builtin_amdgcn_readfirstlane(z / d.nb2), z2 = z - z1 * d.nb2;
+    const int nk_total = (d.K + BK - 1) / BK;
+    const int nk_per = __builtin_amdgcn_readfirstlane((nk_total + d.splitk - 1) / d.splitk);
+    const int kbegin = ksplit * nk_per * BK;
+    int kend = kbegin + nk_per * BK; if (kend > d.K) kend = d.K;
+    const int nk = kend > kbegin ? (kend - kbegin + BK - 1) / BK : 0;
+    const char* Ab = reinterpret_cast<const char*>(d.A.ptr) + z1 * d.A.bs1 + z2 * d.A.bs2;
+    const char* Bb = reinterpret_cast<const char*>(d.B.ptr) + z1 * d.B.bs1 + z2 * d.B.bs2;
+
+    typename DmaSel<AT>::type sa;
+    typename DmaSel<BT>::type sb;
+    sa.init(d.A, Ab, m0, d.M, kbegin, kend, lane, wave);
+    sb.init(d.B, Bb, n0, d.N, kbegin, kend, lane, wave);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int STAGE = 2 * TILE_BYTES;
+    // prologue: tiles 0 .. S-2 (out-of-range no-ops past the last one)
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) {
+        if (s) { sa.advance(); sb.advance(); }
+        sa.issue(d.A, smem + s * STAGE, wave); sb.issue(d.B, smem + s * STAGE + TILE_BYTES, wave);
+    }
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's 8 pieces of tile kt have landed; the S - 2 younger tiles stay in flight
+        if (S == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (S == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... for every wave, and every wave is done reading the stage of tile kt - 1
+        {
+            sa.advance(); sb.advance();
+            int ns = stage + (S - 1); if (ns >= S) ns -= S;
+            char* nb = smem + ns * STAGE;
+            sa.issue(d.A, nb, wave); sb.issue(d.B, nb + TILE_BYTES, wave);
+        }
+        const char* tA = smem + stage * STAGE;
+        const char* tB = tA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = AT ? frag_t_raw(tA, wr * 4 + i, ks, lane) : frag_k(tA, wr * 4 + i, ks, lane);
+                fb[i] = BT ? frag_t_raw(tB, wc * 4 + i, ks, lane) : frag_k(tB, wc * 4 + i, ks, lane);
+            }
+            if (AT || BT) lds_wait_frags(fa, fb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1 == S ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may still target this block's LDS when it retires
+    gemm_epilogue(d, acc, m0, n0, z1, z2, ksplit, lane, wr, wc);
+}
+#endif
+
+
 // (A 128x128 / BK = 32 / 5-stage variant that doubles the bytes in flight per CU was measured 4-19 % SLOWER than the kernel
 // above on every encoder shape — the extra barrier per 16 MFMAs costs more than the deeper prefetch returns — and removed.)
 
@@ -916,7 +1011,14 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
             scl_set_error("gemm: C_SPLIT3 is served by the wide-tile kernel only, and this launch (M %d, N %d, K %d) does not qualify for it", d.M, d.N, d.K);
             return SCL_EUNSUPPORTED;
         }
-        prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? (plan.variant == 2 ? 6 : 1 + plan.variant) : 0));
+#ifdef SCL_EXPERIMENTS
+        // one workgroup per CU at most and a K loop long enough to fill the ring: the deep-ring variant of the 128 x 128 kernel (opt-in)
+        const char* deep_env = getenv("SCL_GEMM_DEEP");
+        const bool deep = !x2 && !w8 && dma && deep_env && atoi(deep_env) != 0 && (long long)tiles * zdim <= 256 && (d.K + BK - 1) / BK / d.splitk >= 4;
+#else
+        const bool deep = false;
+#endif
+        prof.note(d.M, d.N, d.K, d.flags, (int)zdim, x2 ? 3 : (w8 ? (plan.variant == 2 ? 6 : 1 + plan.variant) : (deep ? 7 : 0)));
         if (x2) {
 #ifdef SCL_EXPERIMENTS
             scl_gemm_x2_launch(k, at, bt, plan, zdim, s);
@@ -952,6 +1054,21 @@ extern "C" int scl_gemm_bf16(const SclGemmDesc* dp, void* stream) {
             else if (!at && bt) SCL_LAUNCH((scl_gemm_big_kernel<false, true>), bgrid, bblock, BIG_LDS, s, k);
             else if (at && !bt) SCL_LAUNCH((scl_gemm_big_kernel<true, false>), bgrid, bblock, BIG_LDS, s, k);
             else SCL_LAUNCH((scl_gemm_big_kernel<true, true>), bgrid, bblock, BIG_LDS, s, k);
+#endif
+#ifdef SCL_EXPERIMENTS
+        } else if (deep) {
+            static bool deep_attr_set = false;
+            if (!deep_attr_set) {
+                hipFuncSetAttribute((const void*)scl_gemm_deep_kernel<false, false, DEEP_S>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_deep_kernel<false, true, DEEP_S>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_deep_kernel<true, false, DEEP_S>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
+                hipFuncSetAttribute((const void*)scl_gemm_deep_kernel<true, true, DEEP_S>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
+                deep_attr_set = true;
+            }
+            if (!at && !bt) SCL_LAUNCH((scl_gemm_deep_kernel<false, false, DEEP_S>), grid, block, DEEP_LDS, s, k);
+            else if (!at && bt) SCL_LAUNCH((scl_gemm_deep_kernel<false, true, DEEP_S>), grid, block, DEEP_LDS, s, k);
+            else if (at && !bt) SCL_LAUNCH((scl_gemm_deep_kernel<true, false, DEEP_S>), grid, block, DEEP_LDS, s, k);
+            else SCL_LAUNCH((scl_gemm_deep_kernel<true, true, DEEP_S>), grid, block, DEEP_LDS, s, k);
 #endif
         } else if (dma) {
             if (!at && !bt) SCL_LAUNCH((scl_gemm_dma_kernel<false, false>), grid, block, lds, s, k);

@@ -87,6 +87,89 @@ def test_two_rank_step_equals_single_process_mean_gradient_step(dev, mode):
     assert err < 2e-6, err
 
 
+TRAJ_LR = (4e-4, 1e-4)      # max / base rate of tests/golden/trajectory.npz (the reference's AdamW + CyclicLR, main.py:339-341)
+
+
+def _traj_data(step, rank):
+    g = torch.Generator().manual_seed(1000 + 10 * step + rank)
+    return 0.1 * torch.randn(4, 4000, generator=g), torch.tensor([1, 1, 0, 0])
+
+
+def _traj_sched(opt):
+    return torch.optim.lr_scheduler.CyclicLR(opt, base_lr=TRAJ_LR[1], max_lr=TRAJ_LR[0], step_size_up=3, mode="exp_range", gamma=0.85,
+                                             cycle_momentum=False)
+
+
+def _worker_traj(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scl_amd.model_linear import Model
+    from scl_amd.optim import FusedAdamW
+    from scl_amd.parallel import GradSync
+    dev = torch.device("cuda:0")
+    m = Model(ARGS, dev, seed=0)
+    m.eval()
+    sync = GradSync(m.P.grad[: m.P.n_train], bucket_elems=40000)
+    opt = FusedAdamW(m, lr=TRAJ_LR[0], weight_decay=1e-4, grad_sync=sync)
+    sched = _traj_sched(opt)
+    lrs, step = [], 0
+    for ep in range(2):
+        for i in range(3):
+            x, y = _traj_data(step, rank)
+            lrs.append(opt.param_groups[0]["lr"])
+            _step(m, opt, x.to(dev), y.to(dev), sync)
+            step += 1
+        sched.step()                                           # main.py:416: once per epoch
+    torch.cuda.synchronize()
+    q.put((rank, m.P.flat[: m.P.n_train].cpu().numpy(), lrs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_six_step_trajectory_with_the_epoch_scheduler_equals_the_mean_gradient_trajectory(dev):
+    """The trajectory of tests/test_model_gpu.py (six steps, AdamW, CyclicLR stepped between step 3 and 4) under data parallelism: two
+    ranks on different packs, bucketed all-reduce from the backward's callbacks, steps 2..6 replayed from the recorded launch plan while
+    the scheduler changes the rate the fused AdamW kernel reads.  Equal to one process stepping on the mean of the two gradients."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_traj, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (torch.from_numpy(w), lrs)) for r, w, lrs in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][0], res[1][0])
+    from scl_amd.model_linear import Model
+    from scl_amd.optim import FusedAdamW
+    m = Model(ARGS, dev, seed=0)
+    m.eval()
+    opt = FusedAdamW(m, lr=TRAJ_LR[0], weight_decay=1e-4, overlap=False)
+    sched = _traj_sched(opt)
+    w0 = m.P.flat[: m.P.n_train].cpu().clone()
+    lrs, step = [], 0
+    for ep in range(2):
+        for i in range(3):
+            lrs.append(opt.param_groups[0]["lr"])
+            grads = []
+            for r in range(world):
+                x, y = _traj_data(step, r)
+                out, feats, emb = m(x.to(dev))
+                opt.zero_grad()
+                sum(m.loss(out, feats, emb, y.to(dev), CONF).values()).backward()
+                grads.append(m.P.grad.clone())
+            m.P.grad.copy_((grads[0] + grads[1]) / world)
+            opt.step()
+            step += 1
+        sched.step()
+    assert lrs == res[0][1] == res[1][1] and len(set(lrs)) == 2, (lrs, res[0][1])          # the rate changed once, identically everywhere
+    ref = m.P.flat[: m.P.n_train].cpu()
+    err = (res[0][0] - ref).abs().max().item()
+    upd = (ref - w0).abs().max().item()
+    assert upd > 5e-4 and err < 2e-5, (err, upd)      # six Adam steps move weights by up to ~6 lr = 2e-3; round-off sign flips are bounded by lr each
+
+
 def _worker_aasist(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
