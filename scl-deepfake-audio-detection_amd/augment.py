@@ -103,8 +103,9 @@ def _draw_ssi(a, L, fs):
 # ---- fast parameter sampling (throughput mode) ----------------------------------------------------
 # Same distributions as above, but (a) drawn from a private numpy Generator instead of the global legacy stream, so it
 # is NOT draw-for-draw reproducible against the reference, and (b) all notch filters of a batch are designed at once:
-# firwin in closed form, the five band-stop sections multiplied in the frequency domain, freqz = the first 512 bins of a
-# 1024-point FFT.  ~25x less host time per clip than the per-filter scipy calls of the reference-compatible sampler.
+# firwin in closed form, the five band-stop sections multiplied in the frequency domain (zero-phase: real spectra from one matrix
+# product with a cosine table, design_notch_filters below), freqz = the first 512 bins of the 1024-point response.  ~50x less host time
+# per clip than the per-filter scipy calls of the reference-compatible sampler.
 # A numpy Generator is not safe under concurrent draws, and the pack builder runs on several threads (scl_amd/prefetch.py): every thread
 # gets its own generator, spawned from one seed sequence in the order the threads first ask (the launch thread of bench.py is always the
 # first: its stream is np.random.default_rng(seed)'s own, as before).
@@ -131,33 +132,123 @@ def seed_fast_sampler(seed):
         _FAST_ROOT.update(seq=np.random.SeedSequence(seed), epoch=_FAST_ROOT["epoch"] + 1, first=True)
 
 
+_COS_TABLES = {}      # (kmax, nfft) -> [kmax + 1, nfft / 2 + 1] float64: cos(2 pi i k / nfft), row 0 halved ... see _cos_table
+_HAMMING = {}         # c -> right half (centre first) of the symmetric Hamming window of length c
+
+
+try:      # numpy's BLAS threads sleep between calls and take tens of ms to wake for a 2-ms product (measured: 0.4 ms warm, 26 - 190 ms after a
+    # pause, 2.3 ms on the calling thread alone): the one matrix product of the filter design runs single-threaded
+    from threadpoolctl import ThreadpoolController as _TPC
+    _BLAS_CTL = _TPC()
+except Exception:      # noqa: BLE001 - optional
+    _BLAS_CTL = None
+
+
+def _matmul_1thread(a, b):
+    if _BLAS_CTL is None:
+        return a @ b
+    with _BLAS_CTL.limit(limits=1, user_api="blas"):
+        return a @ b
+
+
+def _cos_table(kmax, nfft):
+    t = _COS_TABLES.get((kmax, nfft))
+    if t is None:
+        k = np.arange(kmax + 1)[:, None]
+        i = np.arange(nfft // 2 + 1)[None, :]
+        t = 2.0 * np.cos((2.0 * np.pi / nfft) * ((k * i) % nfft))      # A(w_i) = h[0] + 2 sum_{k >= 1} h[k] cos(w_i k)
+        t[0] = 1.0
+        if len(_COS_TABLES) > 8:
+            _COS_TABLES.clear()
+        _COS_TABLES[(kmax, nfft)] = t
+    return t
+
+
+def _hamming_half(c, kmax):
+    """[..., kmax + 1]: w[k] of the symmetric Hamming window of odd length c at distance k from its centre (0 beyond (c - 1) / 2)."""
+    out = np.zeros(c.shape + (kmax + 1,))
+    for cv in np.unique(c):
+        w = _HAMMING.get(int(cv))
+        if w is None:
+            a = (int(cv) - 1) // 2
+            w = 0.54 - 0.46 * np.cos(2.0 * np.pi * (a + np.arange(a + 1)) / max(int(cv) - 1, 1)) if cv > 1 else np.ones(1)
+            _HAMMING[int(cv)] = w
+        out[c == cv, :len(w)] = w
+    return out
+
+
+_DESIGN_CHUNK = 64
+
+
 def design_notch_filters(fc, bw, c, G, fs):
-    """Vectorised genNotchCoeffs for n filters: fc, bw [n, nBands] (Hz), c [n, nBands] odd tap counts, G [n] (dB).
-    Returns a list of n float64 tap vectors (length sum(c) - nBands + 1)."""
+    """Vectorised genNotchCoeffs for n filters: fc, bw [n, nBands] (Hz), c [n, nBands] tap counts, G [n] (dB).
+    Returns a list of n float64 tap vectors (length sum(c) - nBands + 1).
+
+    Odd tap counts (what genNotchCoeffs draws, RawBoost.py:33-36) take the zero-phase route: every section is symmetric about its centre
+    tap, so h[-k] = h[k] and its spectrum is REAL, A(w) = h[0] + 2 sum_k h[k] cos(w k) — one [sections, half taps] x [half taps, bins] matrix
+    product with a cached cosine table instead of 1024-point FFTs of 101-tap sequences, half the sines of the closed-form firwin, the
+    window from a table per length, a real product over the sections and one inverse transform per filter: 20 -> 8 ms per 320 filters."""
     n, nb = fc.shape
+    c = np.asarray(c)
+    if n > _DESIGN_CHUNK:      # [filters, sections, bins] float64 intermediates of one chunk stay cache-resident: 35 vs 56 us per filter
+        out = []
+        for i in range(0, n, _DESIGN_CHUNK):
+            j = i + _DESIGN_CHUNK
+            out += design_notch_filters(fc[i:j], bw[i:j], c[i:j], G[i:j], fs)
+        return out
     nyq = fs / 2.0
     f1 = fc - bw / 2.0
     f2 = fc + bw / 2.0
     f1 = np.where(f1 <= 0, 1 / 1000, f1) / nyq
     f2 = np.where(f2 >= nyq, nyq - 1 / 1000, f2) / nyq
+    if not bool((c % 2 == 1).all()):
+        return _design_notch_filters_general(f1, f2, c, G)
+    lens = c.sum(axis=1) - nb + 1
+    nfft = 1024
+    while nfft < int(lens.max()):                               # non-default --nBands / --maxCoeff: the circular product must not alias
+        nfft *= 2
+    alpha = (c - 1) // 2                                        # centre tap of every section
+    kmax = int(alpha.max())
+    k = np.arange(1, kmax + 1)[None, None, :]
+    pik = np.pi * k
+    # scipy.signal.firwin, pass_zero band-stop with cut-offs f1 < f2 (normalised to Nyquist): h[m] = f1 sinc(f1 m) + sinc(m) - f2 sinc(f2 m)
+    # at distance m from the centre; for integer m != 0 that is (sin(pi f1 m) - sin(pi f2 m)) / (pi m), and f1 + 1 - f2 at the centre
+    half = np.empty((n, nb, kmax + 1))
+    half[..., 0] = f1 - f2 + 1.0
+    half[..., 1:] = (np.sin(f1[..., None] * pik) - np.sin(f2[..., None] * pik)) / pik
+    half *= _hamming_half(c, kmax)                              # zero beyond the section's own half length
+    half /= (half[..., :1] + 2.0 * half[..., 1:].sum(axis=-1, keepdims=True))      # unity gain at DC
+    A = _matmul_1thread(half.reshape(n * nb, kmax + 1), _cos_table(kmax, nfft)).reshape(n, nb, nfft // 2 + 1)
+    spec = A.prod(axis=1)                                       # zero-phase response of the nBands sections in series
+    bz = np.fft.irfft(spec, nfft, axis=-1)                      # zero-phase taps: bz[k] = bz[-k], k <= (lens - 1) / 2 < nfft / 2
+    # freqz(b, 1, fs): 512 points on [0, fs/2) = every (nfft / 1024)-th bin; |H| = |A| (the linear phase has unit modulus)
+    Hmag = np.abs(spec[:, ::nfft // 1024][:, :512]).max(axis=-1)
+    bz *= (10.0 ** (G / 20.0) / Hmag)[:, None]
+    htot = (lens - 1) // 2
+    lmax = int(lens.max())
+    taps = np.take_along_axis(bz, np.abs(np.arange(lmax)[None, :] - htot[:, None]) % nfft, axis=1)      # causal: b[t] = bz[|t - htot|]
+    return [taps[i, :lens[i]].copy() for i in range(n)]
+
+
+def _design_notch_filters_general(f1, f2, c, G):
+    """any tap counts (even ones have no centre tap): closed-form firwin, the sections multiplied in the frequency domain by FFT"""
+    n, nb = f1.shape
     cmax = int(c.max())
     idx = np.arange(cmax)[None, None, :]                        # [1,1,cmax]
     alpha = 0.5 * (c[..., None] - 1)
     m = idx - alpha
     valid = idx < c[..., None]
-    # pass_zero band-stop: pass bands [0, f1] and [f2, 1] (cut-offs normalised to Nyquist), scipy.signal.firwin
     h = f1[..., None] * np.sinc(f1[..., None] * m) + (np.sinc(m) - f2[..., None] * np.sinc(f2[..., None] * m))
     win = 0.54 - 0.46 * np.cos(2.0 * np.pi * idx / np.maximum(c[..., None] - 1, 1))   # symmetric Hamming of length c
     h = np.where(valid, h * win, 0.0)
     h = h / h.sum(axis=-1, keepdims=True)                       # unity gain at DC
     lens = c.sum(axis=1) - nb + 1
     nfft = 1024
-    while nfft < int(lens.max()):                               # non-default --nBands / --maxCoeff: the circular product must not alias
+    while nfft < int(lens.max()):
         nfft *= 2
     spec = np.fft.rfft(h, nfft, axis=-1).prod(axis=1)           # product of the nBands sections
-    b = np.fft.irfft(spec, nfft, axis=-1)                       # [n, nfft]; exact linear convolution (total length <= nfft; 501 by default)
-    # freqz(b, 1, fs): 512 points on [0, fs/2) = every (nfft / 1024)-th bin of the nfft-point transform
-    Hmag = np.abs(np.fft.rfft(b, nfft, axis=-1)[:, ::nfft // 1024][:, :512]).max(axis=-1)
+    b = np.fft.irfft(spec, nfft, axis=-1)                       # [n, nfft]; exact linear convolution (total length <= nfft)
+    Hmag = np.abs(spec[:, ::nfft // 1024][:, :512]).max(axis=-1)      # freqz(b, 1, fs): the transform of b IS spec
     b = (10.0 ** (G / 20.0) / Hmag)[:, None] * b
     return [b[i, :lens[i]].copy() for i in range(n)]
 
@@ -228,13 +319,13 @@ def _h2d_pack(arrays, dev):
     return [d[o:o + a.nbytes].view(_TORCH_DT[a.dtype.type]).view(a.shape) for a, o in zip(arrays, offs)]
 
 
-# Host -> device copies made by a thread that runs far AHEAD of the GPU (the trainer's launch thread: ~3 steps ahead, round 6,
-# profiles/r6_bench_default_phase_gaps.txt) go out on an UPLOAD STREAM of their own; the stream that will use the data waits for the copy's
-# event.  A copy queued on the compute stream sits behind 100+ ms of kernels and then costs its own latency there (the switch to the copy
-# path and back); on its own stream it runs when it is issued — steps before its consumer gets there — and the consumer's wait is already
-# satisfied.  Measured (profiles/r6_upload_stream_ab.txt): default step -0.3 ms, pack-11 step -0.18 ms.  A thread whose stream is nearly
-# EMPTY gains nothing and pays the extra stream switch + event per copy (the pack builder alone: 234 -> 198 packs/s), so the prefetcher's
-# builder threads opt out with `use_upload_stream(False)`.
+# Host -> device copies made by a thread that runs AHEAD of the GPU (the trainer's launch thread) go out on an UPLOAD STREAM of their own;
+# the stream that will use the data waits for the copy's event.  A copy queued on the compute stream runs only when the GPU gets there
+# and the consumer then waits for the host-memory read; on its own stream it runs when it is issued and the consumer's wait is long
+# satisfied.  Measured with events inside the un-profiled default step (tools/augment_gaps.py, profiles/r6_augment_gaps.txt): the ISD
+# upload + scatter 59 -> 20 us, the RawBoost chain 328 -> 273 us per step (its kernels: ~250); profiles/r6_upload_stream_ab.txt: default
+# step -0.3 ms, pack-11 step -0.18 ms.  A thread whose stream is nearly EMPTY gains nothing and pays the extra stream switch + event per
+# copy (the pack builder alone: 234 -> 198 packs/s), so the prefetcher's builder threads opt out with `use_upload_stream(False)`.
 _UPLOAD = {}
 _UPLOAD_LOCAL = threading.local()
 UPLOAD_STREAM = __import__("os").environ.get("SCL_UPLOAD_STREAM", "1") != "0"

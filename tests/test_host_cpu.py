@@ -82,7 +82,7 @@ def test_batched_notch_design_matches_scipy_per_filter_design(nb, cmax):
     from scipy import signal
     from scl_amd import augment
     rs = np.random.RandomState(0)
-    n, fs = 12, 16000
+    n, fs = (12 if nb > 5 else 150), 16000          # 150: more than one design chunk
     fc = rs.uniform(20, 8000, (n, nb)); bw = rs.uniform(100, 1000, (n, nb))
     c = rs.uniform(10, cmax, (n, nb)).astype(np.int64); c = np.where(c % 2 == 0, c + 1, c)
     if nb > 5:
@@ -100,6 +100,11 @@ def test_batched_notch_design_matches_scipy_per_filter_design(nb, cmax):
         ref = 10 ** (G[i] / 20) * b / np.amax(np.abs(h))
         assert got[i].shape == ref.shape
         np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-12)
+    # the FFT route (any tap counts; what the zero-phase route replaced for the odd counts genNotchCoeffs draws) agrees as well
+    f1 = np.where(fc - bw / 2 <= 0, 1 / 1000, fc - bw / 2) / (fs / 2)
+    f2 = np.where(fc + bw / 2 >= fs / 2, fs / 2 - 1 / 1000, fc + bw / 2) / (fs / 2)
+    for g, o in zip(got, augment._design_notch_filters_general(f1, f2, c, G)):
+        np.testing.assert_allclose(o, g, rtol=0, atol=1e-12)
 
 
 def test_fast_sampler_statistics():

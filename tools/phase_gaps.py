@@ -68,9 +68,13 @@ def run_events(steps=12, warmup=5):
     res = {"ms_per_step_wall": wall, "steps": steps}
     if marks:
         spans = [[m[i].elapsed_time(m[i + 1]) for i in range(5)] for m in marks]
-        # the loss events bracket the FORWARD part of the losses; their backward runs inside total.backward() — reported with "backward"
-        res["spans_ms"] = {PHASES[i]: sum(s[i] for s in spans) / len(spans) for i in range(5)}
-        res["step_span_ms"] = sum(m[0].elapsed_time(m[5]) for m in marks) / len(marks)
+        # the loss events bracket the FORWARD part of the losses; their backward runs inside total.backward() — reported with "backward".
+        # The FIRST step after the synchronize is kept apart: the GPU is idle while the launch thread draws and designs that step's
+        # RawBoost parameters (in every later step that host work runs while the GPU is still busy with the step before).
+        res["first_step_spans_ms"] = {PHASES[i]: spans[0][i] for i in range(5)}
+        rest = spans[1:]
+        res["spans_ms"] = {PHASES[i]: sum(s[i] for s in rest) / len(rest) for i in range(5)}
+        res["step_span_ms"] = sum(m[0].elapsed_time(m[5]) for m in marks[1:]) / len(rest)
         res["between_steps_ms"] = sum(marks[i][5].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)) / max(1, len(marks) - 1)
     print(json.dumps(res))
 
@@ -124,8 +128,11 @@ def run_trace(path, events_json=None, n=3):
         tk += k; ts += sp; te += es or 0.0
     print("%-10s %9.1f %12.3f %14.3f %16s %22s" % ("sum", sum(a["n"] for a in agg.values()) / n, tk, ts, "%.3f" % te if evs else "-", "%.3f" % (te - tk) if evs else "-"))
     if evs:
-        print("# un-profiled: %.3f ms per step on the host clock, %.3f ms from the first to the last event of a step, %.3f ms between the last event of a step and the first of the next"
-              % (evs["ms_per_step_wall"], evs.get("step_span_ms", 0.0), evs.get("between_steps_ms", 0.0)))
+        print("# un-profiled: %.3f ms per step on the host clock (all %d steps after a synchronize), %.3f ms from the first to the last event of a step (steps 2..), %.3f ms between the last event of a step and the first of the next"
+              % (evs["ms_per_step_wall"], evs.get("steps", 0), evs.get("step_span_ms", 0.0), evs.get("between_steps_ms", 0.0)))
+        if "first_step_spans_ms" in evs:
+            print("# the FIRST step after the synchronize (GPU idle while the launch thread prepares the step; not in the table): "
+                  + ", ".join("%s %.3f" % (p, evs["first_step_spans_ms"][p]) for p in PHASES))
     print("# idle time under the profiler by the kernel that PRECEDES the gap (per step):")
     for nm, (c, us) in sorted(gaps_after.items(), key=lambda kv: -kv[1][1])[:14]:
         print("  %-62s %6.1f gaps %8.1f us" % (nm[:62], c / n, us / n))
