@@ -292,7 +292,8 @@ def test_plugin_forward_and_train_step_against_the_cpu_chain(dev):
     sum(losses.values()).backward()
     torch.cuda.synchronize()
     for k in rloss:
-        assert abs(float(losses[k]) - float(rloss[k])) <= 1e-2 * max(abs(float(rloss[k])), 1e-3), (k, float(losses[k]), float(rloss[k]))
+        got, ref = losses[k].item(), rloss[k].item()
+        assert abs(got - ref) <= 1e-2 * max(abs(ref), 1e-3), (k, got, ref)
     for k in ("fc2.weight", "bioScoring.bio_scoring.weight", "bioScoring.encoder.attn_layers.0.conv_v.weight", "bioScoring.encoder.ffn_layers.2.conv_1.weight",
               "backend.mlp.m_frame_level.linear_1.weight", "backend.LL.weight"):
         name = k[len("backend."):] if k.startswith("backend.LL.") else k
