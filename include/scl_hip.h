@@ -553,9 +553,14 @@ int scl_graph_reduce(const SclGraphReduceJob* jobs, int njobs, void* stream);
 /* ------------------------------------------------------------------------------------------ */
 /* losses: supervised contrastive (model/loss_metrics.py:85-209) and NLL (linear_nll.py:167)   */
 /* ------------------------------------------------------------------------------------------ */
-/* Buffers: ws = scl_supcon_nchunks(K) * bz * bz floats; G = 2 * bz * bz floats — [0, bz*bz) receives dL/dS from the forward and is
- * read by the backward, [bz*bz, 2*bz*bz) is the backward's scratch (the symmetrised, scaled coefficient matrix of its GEMM form). */
+/* Any batch size 1 <= bz <= SCL_SUPCON_MAX_BZ (the reference has no limit: under nn.DataParallel Model.loss sees the gathered batch of all
+ * GPUs, main.py:62-66).  Up to 128 utterances the loss and dL/dS come from one workgroup with S in LDS; larger batches take a wave per row.
+ * Buffers: ws = scl_supcon_ws_floats(bz, K) floats (= scl_supcon_nchunks(K) * bz * bz partial sums + bz row losses); G = 2 * bz * bz
+ * floats — [0, bz*bz) receives dL/dS from the forward and is read by the backward, [bz*bz, 2*bz*bz) is scratch (S of a batch of more than
+ * 128 in the forward when S_out is null; the symmetrised, scaled coefficient matrix of the backward's GEMM form). */
+#define SCL_SUPCON_MAX_BZ 1024
 int scl_supcon_nchunks(int64_t K);
+long long scl_supcon_ws_floats(int bz, int64_t K);
 int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int64_t K, int64_t ldF, int Tprime, float temperature,
                    float* ws, float* G, float* loss_out, float* S_out, void* stream);
 int scl_supcon_bwd(const float* F, const float* G, const float* upstream, float coef, int bz, int64_t K, int64_t ldF,

@@ -105,16 +105,89 @@ __global__ __launch_bounds__(1024) void supcon_loss_kernel(const float* __restri
     }
 }
 
+// ---- batches of more than 128 utterances (the reference has no limit: nn.DataParallel computes Model.loss on the gathered batch of all
+// GPUs, 8 x 64 = 512 rows at BASELINE configs[2] / [3] — SCL_GLOBAL_SUPCON=1) --------------------------------------------------------
+// Gram fallback for shapes the GEMM form does not take: one thread per pair over its K chunk, straight from global memory.
+__global__ __launch_bounds__(256) void supcon_gram_any_kernel(const float* __restrict__ F, float* __restrict__ part, int bz,
+                                                              int64_t K, int64_t ldF, int64_t kchunk) {
+    const int64_t k0 = (int64_t)blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
+    const int64_t npairs = (int64_t)bz * bz;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npairs) return;
+    const int i = (int)(p / bz), j = (int)(p % bz);
+    const float* fi = F + (int64_t)i * ldF;
+    const float* fj = F + (int64_t)j * ldF;
+    float acc = 0.f;
+    for (int64_t kb = k0; kb < k1; kb += KC) {      // the same chunking of the sum as supcon_gram_kernel: KC terms, then the running total
+        const int64_t ke = min(k1, kb + KC);
+        float s = 0.f;
+        for (int64_t k = kb; k < ke; ++k) s += fi[k] * fj[k];
+        acc += s;
+    }
+    part[(int64_t)blockIdx.y * npairs + p] = acc;
+}
+
+// The loss for any bz: one WAVE per row i (the rows are independent); S stays in global memory (S_buf, bz x bz), nothing in LDS.
+// Same arithmetic per row as supcon_loss_kernel; rowloss[i] to global, summed in index order by supcon_loss_finish_kernel.
+__global__ __launch_bounds__(256) void supcon_loss_rows_kernel(const float* __restrict__ part, int nparts, const int64_t* __restrict__ labels,
+                                                               int bz, float scale, float* __restrict__ rowloss, float* __restrict__ G,
+                                                               float* __restrict__ S_buf) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= bz) return;
+    const int64_t npairs = (int64_t)bz * bz;
+    float* Si = S_buf + (int64_t)i * bz;
+    const int64_t yi = labels[i];
+    float mx = -INFINITY;
+    for (int j = lane; j < bz; j += 64) {
+        float s = 0.f;
+        for (int c = 0; c < nparts; ++c) s += part[(int64_t)c * npairs + (int64_t)i * bz + j];
+        s *= scale;
+        Si[j] = s;
+        mx = fmaxf(mx, j == i ? 0.f : s);      // logits * self_mask
+    }
+    mx = wave_max(mx);
+    float se = 0.f, npos = 0.f, spos = 0.f;
+    for (int j = lane; j < bz; j += 64) {      // this lane re-reads the values it wrote itself
+        if (j == i) continue;
+        const float l = Si[j] - mx;
+        se += expf(l);
+        if (labels[j] == yi) { npos += 1.f; spos += l; }
+    }
+    se = wave_sum(se); npos = wave_sum(npos); spos = wave_sum(spos);
+    const float lse = logf(se);
+    const float mlpp = (spos - npos * lse) / npos;  // 0/0 -> NaN as the reference
+    if (lane == 0) rowloss[i] = -mlpp;
+    for (int j = lane; j < bz; j += 64) {
+        float g = 0.f;
+        if (j != i) {
+            const float l = Si[j] - mx;
+            g = -((labels[j] == yi ? 1.f / npos : 0.f) - expf(l) / se) / (float)bz;
+        }
+        G[(int64_t)i * bz + j] = g;
+    }
+}
+__global__ void supcon_loss_finish_kernel(const float* __restrict__ rowloss, int bz, float* __restrict__ loss_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < bz; ++i) s += rowloss[i];
+        *loss_out = s / (float)bz;
+    }
+}
+
 // dF[i][k] (+)= upstream * scale * sum_j (G[i][j] + G[j][i]) F[j][k]
 __global__ __launch_bounds__(256) void supcon_bwd_kernel(const float* __restrict__ F, const float* __restrict__ G,
                                                          const float* __restrict__ upstream, float coef, float* __restrict__ dF,
                                                          bf16_t* __restrict__ dF_bf, int bz, int64_t K, int64_t ldF, int accumulate) {
-    extern __shared__ float sm[];  // Gs [bz*bz]
-    for (int p = threadIdx.x; p < bz * bz; p += 256) {
-        const int i = p / bz, j = p % bz;
-        sm[p] = G[i * bz + j] + G[j * bz + i];
+    extern __shared__ float sm[];  // Gs [bz*bz] (bz <= 128; larger batches read G + G^T from global memory: block-uniform addresses)
+    const bool in_lds = bz <= 128;
+    if (in_lds) {
+        for (int p = threadIdx.x; p < bz * bz; p += 256) {
+            const int i = p / bz, j = p % bz;
+            sm[p] = G[i * bz + j] + G[j * bz + i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const float c = coef * (upstream ? *upstream : 1.f);
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
@@ -125,7 +198,8 @@ __global__ __launch_bounds__(256) void supcon_bwd_kernel(const float* __restrict
             const float f = F[(int64_t)j * ldF + k];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (i0 + q < bz) acc[q] += sm[(i0 + q) * bz + j] * f;
+                if (i0 + q < bz)
+                    acc[q] += (in_lds ? sm[(i0 + q) * bz + j] : G[(int64_t)(i0 + q) * bz + j] + G[(int64_t)j * bz + i0 + q]) * f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -202,13 +276,34 @@ extern "C" int scl_supcon_nchunks(int64_t K) {
     return (int)n;
 }
 
-// F f32 [bz, K] (row stride ldF); labels int64 [bz]; ws: nchunks*bz*bz floats; G: bz*bz floats.
+// floats the forward's workspace needs: the partial Gram matrices + one row of per-utterance losses (batches of more than 128)
+extern "C" long long scl_supcon_ws_floats(int bz, int64_t K) {
+    return (long long)scl_supcon_nchunks(K) * bz * bz + bz;
+}
+
+// F f32 [bz, K] (row stride ldF); labels int64 [bz]; ws: scl_supcon_ws_floats(bz, K) floats; G: 2*bz*bz floats.
 // loss_out = supcon_loss(feats) exactly as the reference returns it (before Model.loss's extra 1/bz).
 extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int64_t K, int64_t ldF, int Tprime, float temperature,
                               float* ws, float* G, float* loss_out, float* S_out, void* stream) {
     SCL_REQUIRE(F && labels && ws && G && loss_out, "supcon_fwd: null pointer");
-    SCL_REQUIRE(bz >= 1 && bz <= 128 && K >= 1 && Tprime >= 1 && temperature > 0.f, "supcon_fwd: need 1 <= bz <= 128");
+    SCL_REQUIRE(bz >= 1 && bz <= SCL_SUPCON_MAX_BZ && K >= 1 && Tprime >= 1 && temperature > 0.f, "supcon_fwd: need 1 <= bz <= %d", SCL_SUPCON_MAX_BZ);
     hipStream_t s = (hipStream_t)stream;
+    // bz <= 128: S, the loss and dL/dS in ONE workgroup (S in LDS).  Larger batches: a wave per row, S in global memory — the caller's G
+    // buffer (2 bz^2 floats) holds dL/dS in its first half and S in its second (the backward overwrites that half with its own scratch),
+    // the row losses go behind the partial sums (ws holds one extra row of bz floats: scl_supcon_ws_floats)
+    const bool small = bz <= 128;
+    auto finish = [&](int nparts) {
+        const float scale = 1.0f / ((float)Tprime * temperature);
+        if (small) {
+            hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(1024), (size_t)(bz * bz + bz) * sizeof(float), s, ws, nparts, labels, bz, scale,
+                               loss_out, G, S_out);
+        } else {
+            float* rowloss = ws + (size_t)scl_supcon_nchunks(K) * bz * bz;
+            float* S_buf = S_out ? S_out : G + (size_t)bz * bz;
+            hipLaunchKernelGGL(supcon_loss_rows_kernel, dim3((bz + 3) / 4), dim3(256), 0, s, ws, nparts, labels, bz, scale, rowloss, G, S_buf);
+            hipLaunchKernelGGL(supcon_loss_finish_kernel, dim3(1), dim3(64), 0, s, rowloss, bz, loss_out);
+        }
+    };
     if (supcon_as_gemm(bz, K, ldF, F)) {
         SclGemmDesc d;
         memset(&d, 0, sizeof(d));
@@ -218,24 +313,23 @@ extern "C" int scl_supcon_fwd(const float* F, const int64_t* labels, int bz, int
         d.splitk = sk; d.c_split_stride = sk > 1 ? (int64_t)bz * bz : 0; d.flags = SCL_GEMM_C_F32 | SCL_GEMM_AB_F32; d.alpha = 1.0f;
         const int rc = scl_gemm_bf16(&d, stream);
         if (rc != SCL_OK) return rc;
-        hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(1024), (size_t)(bz * bz + bz) * sizeof(float), s, ws, sk, labels, bz,
-                           1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
+        finish(sk);
         return scl_check_launch("scl_supcon_fwd");
     }
     const int nch = (int)((K + 1023) / 1024 < 1 ? 1 : ((K + 1023) / 1024 > 512 ? 512 : (K + 1023) / 1024));
     int64_t kchunk = (K + nch - 1) / nch;
     kchunk = (kchunk + KC - 1) / KC * KC;
     const int nch_eff = (int)((K + kchunk - 1) / kchunk);
-    hipLaunchKernelGGL(supcon_gram_kernel, dim3(nch_eff), dim3(256), (size_t)bz * (KC + 1) * sizeof(float), s, F, ws, bz, K, ldF, kchunk);
-    hipLaunchKernelGGL(supcon_loss_kernel, dim3(1), dim3(1024), (size_t)(bz * bz + bz) * sizeof(float), s, ws, nch_eff, labels, bz,
-                       1.0f / ((float)Tprime * temperature), loss_out, G, S_out);
+    if (small) hipLaunchKernelGGL(supcon_gram_kernel, dim3(nch_eff), dim3(256), (size_t)bz * (KC + 1) * sizeof(float), s, F, ws, bz, K, ldF, kchunk);
+    else hipLaunchKernelGGL(supcon_gram_any_kernel, dim3((unsigned)(((int64_t)bz * bz + 255) / 256), nch_eff), dim3(256), 0, s, F, ws, bz, K, ldF, kchunk);
+    finish(nch_eff);
     return scl_check_launch("scl_supcon_fwd");
 }
 
 // dF (+)= (*upstream) * coef / (T' t) * (G + G^T) F      (coef carries Model.loss's 1/bz)
 extern "C" int scl_supcon_bwd(const float* F, const float* G, const float* upstream, float coef, int bz, int64_t K, int64_t ldF,
                               int Tprime, float temperature, float* dF, void* dF_bf16, int accumulate, void* stream) {
-    SCL_REQUIRE(F && G && dF && bz >= 1 && bz <= 128 && K >= 1, "supcon_bwd: bad args");
+    SCL_REQUIRE(F && G && dF && bz >= 1 && bz <= SCL_SUPCON_MAX_BZ && K >= 1, "supcon_bwd: bad args (1 <= bz <= %d)", SCL_SUPCON_MAX_BZ);
     if (supcon_as_gemm(bz, K, ldF, F) && ((uintptr_t)dF & 15) == 0 && (dF_bf16 == nullptr || ((uintptr_t)dF_bf16 & 7) == 0)) {
         // dF[i][k] (+)= sum_j Gs[i][j] F[j][k]:  A = Gs [bz, bz4] (reduction padded to a multiple of 4 with zero columns),
         // B = F read as [j rows][k contiguous] (transposed operand), C = dF f32 (+ R = dF when accumulating), C2 = the bf16 copy
@@ -258,7 +352,7 @@ extern "C" int scl_supcon_bwd(const float* F, const float* G, const float* upstr
         if (rc != SCL_OK) return rc;
         return scl_check_launch("scl_supcon_bwd");
     }
-    hipLaunchKernelGGL(supcon_bwd_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), (size_t)bz * bz * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(supcon_bwd_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), bz <= 128 ? (size_t)bz * bz * sizeof(float) : 0, (hipStream_t)stream,
                        F, G, upstream, coef / ((float)Tprime * temperature), dF, (bf16_t*)dF_bf16, bz, K, ldF, accumulate);
     return scl_check_launch("scl_supcon_bwd");
 }

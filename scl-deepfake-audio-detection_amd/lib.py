@@ -211,6 +211,7 @@ def _protos():
         "scl_graph_reduce": ([_vp, _i32, _vp], _i32),
         # loss.hip
         "scl_supcon_nchunks": ([_i64], _i32),
+        "scl_supcon_ws_floats": ([_i32, _i64], _i64),
         "scl_supcon_fwd": ([_vp, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
         "scl_supcon_bwd": ([_vp, _vp, _vp, _f32, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp], _i32),
         "scl_nll_fwd": ([_vp, _vp, _i32, _i32, _vp, _vp, _vp], _i32),

@@ -376,7 +376,7 @@ class _LossFn(torch.autograd.Function):
         outc, F1, F2 = output.contiguous(), feats.contiguous().view(bz, -1), emb.contiguous()
         ops.nll_fwd(outc, labels, bz, output.shape[1], res[0:1], coef)
         K1, K2 = Tq * dq, emb.shape[1]
-        ws = torch.empty(max(ops.supcon_nchunks(K1), ops.supcon_nchunks(K2)) * bz * bz, device=dev)
+        ws = torch.empty(max(ops.supcon_ws_floats(bz, K1), ops.supcon_ws_floats(bz, K2)), device=dev)
         G1, G2 = torch.empty(2 * bz * bz, device=dev), torch.empty(2 * bz * bz, device=dev)      # dL/dS + the backward's scratch
         ops.supcon_fwd(F1, labels, bz, K1, K1, Tq, 0.07, ws, G1, res[1:2])
         ops.supcon_fwd(F2, labels, bz, K2, K2, K2, 0.07, ws, G2, res[2:3])   # emb as [bz,1,128,1]: T' = 128, d = 1

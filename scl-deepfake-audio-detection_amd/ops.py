@@ -517,8 +517,14 @@ def supcon_nchunks(K):
     return L.load().scl_supcon_nchunks(K)
 
 
+def supcon_ws_floats(bz, K):
+    """floats of scl_supcon_fwd's workspace: partial Gram matrices + one row of per-utterance losses (used by batches of more than 128)"""
+    return int(L.load().scl_supcon_ws_floats(bz, K))
+
+
 def supcon_fwd(F, labels, bz, K, ldF, Tprime, temperature, ws, G, loss_out, S_out=None):
-    assert G.numel() >= 2 * bz * bz and ws.numel() >= supcon_nchunks(K) * bz * bz, "supcon: G holds 2 bz^2 floats (dL/dS + backward scratch)"
+    assert G.numel() >= 2 * bz * bz and ws.numel() >= supcon_nchunks(K) * bz * bz + (bz if bz > 128 else 0), \
+        "supcon: G holds 2 bz^2 floats (dL/dS + backward scratch), ws supcon_ws_floats(bz, K)"
     _call("scl_supcon_fwd", _p(F), _p(labels), bz, K, ldF, Tprime, temperature, _p(ws), _p(G), _p(loss_out), _p(S_out),
                                     _stream())
 

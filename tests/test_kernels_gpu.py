@@ -9,6 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from scl_amd import ops  # noqa: E402
+from scl_amd.lib import SclError  # noqa: E402
 
 
 def rel(got, ref):
@@ -258,6 +259,40 @@ def test_conv0_fwd_bwd(dev, C, L, B, saved):
         y = F.conv1d(x[:, None], w, b, stride=s).transpose(1, 2).reshape(B * T0, C)
         assert rel(stats[:, 0], y.mean(1)) < 1e-4 and rel(stats[:, 1], (y.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
     assert rel(dW, wr.grad) < 2e-4 and rel(db, br_.grad) < 2e-4 and rel(dg, gr.grad) < 2e-4 and rel(dbe, ber.grad) < 2e-4
+
+
+def test_supcon_batches_beyond_128_match_oracle(dev):
+    """The reference has no batch limit (nn.DataParallel hands Model.loss the gathered batch of all GPUs: 8 x 64 = 512 rows at
+    BASELINE configs[2] / [3]; a 12-pack step is 132 utterances).  Above 128 utterances the loss takes a wave per row with S in global
+    memory; GEMM form (bz, K multiples of 4) and the scalar fall-backs (ragged bz / K) against supcon_loss (loss_metrics.py:85-209)."""
+    from oracle import head as OH
+    for bz, T2, d, seed in ((192, 49, 128, 0), (512, 199, 128, 1), (132, 199, 128, 2), (130, 7, 16, 3), (257, 5, 3, 4), (512, 128, 1, 5)):
+        torch.manual_seed(seed)
+        f = torch.randn(bz, 1, T2, d)
+        lab = torch.tensor(([1] * ((5 * bz + 10) // 11) + [0] * bz)[:bz])
+        fr = f.clone().requires_grad_(True)
+        ref = OH.supcon_loss(fr, lab)
+        (ref * 0.37).backward()
+        K = T2 * d
+        Fd = f.view(bz, K).to(dev).contiguous()
+        ws = torch.empty(ops.supcon_ws_floats(bz, K), device=dev)
+        G = torch.empty(2 * bz * bz, device=dev); loss = torch.empty(1, device=dev)
+        S = torch.empty(bz, bz, device=dev)
+        ops.supcon_fwd(Fd, lab.to(dev), bz, K, K, T2, 0.07, ws, G, loss, S_out=S)
+        Sref = (f.view(bz, K).double() @ f.view(bz, K).double().t()) / (T2 * 0.07)
+        assert rel(S, Sref.float()) < 1e-5, (bz, T2, d)
+        assert abs(loss.item() - ref.item()) <= 5e-5 * max(1.0, abs(ref.item())), (bz, T2, d, loss.item(), ref.item())
+        loss2 = torch.empty(1, device=dev); G2 = torch.empty(2 * bz * bz, device=dev)
+        ops.supcon_fwd(Fd, lab.to(dev), bz, K, K, T2, 0.07, ws, G2, loss2)          # S parked in the G buffer's scratch half
+        assert torch.equal(loss2, loss) and torch.equal(G2[: bz * bz], G[: bz * bz])
+        dF = torch.empty(bz, K, device=dev)
+        up = torch.tensor([0.37], device=dev)
+        ops.supcon_bwd(Fd, G2, up, 1.0, bz, K, K, T2, 0.07, dF)
+        assert rel(dF, fr.grad.view(bz, K)) < 3e-4, (bz, T2, d, rel(dF, fr.grad.view(bz, K)))
+    with pytest.raises(SclError):
+        bz = 1028
+        ops.supcon_fwd(torch.zeros(bz, 64, device=dev), torch.zeros(bz, dtype=torch.int64, device=dev), bz, 64, 64, 8, 0.07,
+                       torch.empty(ops.supcon_nchunks(64) * bz * bz + bz, device=dev), torch.empty(2 * bz * bz, device=dev), torch.empty(1, device=dev))
 
 
 def test_supcon_and_nll_match_oracle(dev):
