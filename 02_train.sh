@@ -3,12 +3,12 @@
 #   bash 02_train.sh <seed> <config.yaml> <data_path> <comment> [n_gpus]
 # One anchor pack per optimizer step (--batch_size 1, the reference's recipe: /root/reference 02_train.sh:50-57), 80 epochs max, repeat padding.
 #
-# Throughput note (one MI355X, profiles/r4_pack11_probe.txt): an 11-view pack is M = 2189 encoder rows — 16.3 ms per step = 675 utterances/s,
-# under half of what the chip does on a full batch, because its GEMM launches are ~35 us each.  PACKS=k puts k anchor packs into one
-# optimizer step (main.py --batch_size k: SupCon positives / negatives stay inside their pack, the CE / SupCon terms are averaged over the
-# packs; the reference's reshape only works for k = 1): k = 2 -> 909 utterances/s (24.2 ms), k = 3 -> 1109 (29.8 ms).  k = 3 is the
-# recommended setting when the learning-rate schedule is re-tuned for the 3x larger step; the default stays 1 so that the recipe is the
-# reference's own.
+# Throughput note (one MI355X, round 6: profiles/r6_upload_stream_final.txt, r6_pack11_gemm_classes.txt): an 11-view pack is M = 2189 encoder rows —
+# 14.3 ms per step = 770 utterances/s (14.4 ms end to end from FLAC files), half of what the chip does on a full batch: the step is kernel-bound
+# and its GEMM launches are 21 - 36 us each.  PACKS=k puts k anchor packs into one optimizer step (main.py --batch_size k: SupCon positives /
+# negatives stay inside their pack, the CE / SupCon terms are averaged over the packs; the reference's reshape only works for k = 1):
+# k = 3 -> 1240 utterances/s end to end (26.7 ms per step), k = 6 -> 1495 (44.1 ms).  k = 3 .. 6 is the recommended setting when the
+# learning-rate schedule is re-tuned for the larger step; the default stays 1 so that the recipe is the reference's own.
 set -e
 if [ "$#" -lt 4 ]; then
     echo "usage: bash 02_train.sh <seed> <config> <data_path> <comment> [n_gpus]"; exit 1
