@@ -325,6 +325,39 @@ def test_forward_matches_oracle_on_fresh_input_and_eval_scores(dev):
     m.is_train = True
 
 
+def test_frozen_ssl_trains_the_head_only(dev):
+    """flag_fix_ssl: true (xlsr.py:31-38 runs the encoder under no_grad in eval mode; wav2vec2_linear_nll.py:120-137): same outputs as the
+    trainable model in eval mode, head gradients identical, the encoder receives no gradient and AdamW leaves every encoder weight as it was."""
+    cfg = W.W2VConfig.tiny()
+    ssl, head = W.init_state(cfg, seed=61), OH.init_head(cfg.embed, seed=62)
+    sd = {"ssl_model.model." + k: v for k, v in ssl.items()}
+    sd.update(head)
+    x = (0.1 * torch.randn(4, 4000, generator=torch.Generator().manual_seed(2))).to(dev)
+    y = torch.tensor([1, 1, 0, 0], device=dev)
+    res = {}
+    for frozen in (False, True):
+        m = Model(dict(ARGS, flag_fix_ssl=frozen), dev, w2v_cfg=W2VConfig.tiny())
+        m.load_state_dict(sd, strict=False)
+        m.eval()                                    # dropout off everywhere: the two models differ only in where the backward stops
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-2)
+        before = m.P.flat[: m.P.n_train].clone()
+        out, feats, emb = m(x)
+        opt.zero_grad()
+        sum(m.loss(out, feats, emb, y, CONF).values()).backward()
+        torch.cuda.synchronize()
+        grad = m.P.grad[: m.P.n_train].clone()
+        opt.step()
+        torch.cuda.synchronize()
+        res[frozen] = (out, feats, emb, grad, m.P.flat[: m.P.n_train] - before, m.P.off("LL.weight"))
+    lo = res[True][5]
+    for a, b in zip(res[False][:3], res[True][:3]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][3][lo:], res[False][3][lo:]) and res[False][3][:lo].abs().max().item() > 0
+    assert res[True][3][:lo].abs().max().item() == 0.0
+    assert res[True][4][:lo].abs().max().item() == 0.0 and res[True][4][lo:].abs().max().item() > 0      # no weight decay on frozen weights either
+    assert torch.equal(res[True][4][lo:], res[False][4][lo:])
+
+
 def test_train_mode_dropout_is_applied_and_backward_consistent(dev):
     cfg = W.W2VConfig.tiny()
     m = build(dev, W.init_state(cfg, seed=31), OH.init_head(cfg.embed, seed=32))
