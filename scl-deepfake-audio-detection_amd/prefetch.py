@@ -34,7 +34,7 @@ def default_workers():
     """ONE builder thread by default.  Measured on MI355X boxes (profiles/r6_pack_builder.txt): with no host <-> device synchronisation
     left in the builder, the fast RawBoost sampler, the round-6 FLAC decoder and the files decoded ahead on decoder threads, one thread
     builds 227 - 256 packs/s of 11 views = 2500 - 2800 utterances/s — the GPU trains 1580 - 1640 at 6 packs per step — and end to end
-    main.run_epoch runs at 1.03 - 1.13 x the resident-batch step.  More builder threads share the interpreter lock with the launch thread
+    main.run_epoch runs at 1.03 - 1.05 x the resident-batch step (profiles/r6_upload_stream_final.txt).  More builder threads share the interpreter lock with the launch thread
     (~760 C calls per step) and never beat one inside a training run (1.05 - 1.27 x).  SCL_PREFETCH_THREADS=<n> to try it anyway."""
     try:
         return max(1, int(os.environ.get("SCL_PREFETCH_THREADS", "1")))
