@@ -616,6 +616,32 @@ def test_fp32_scoring_path_matches_oracle_to_1e3_at_xlsr_shape(dev):
     assert (out.argmax(1).cpu() == ro.argmax(1)).all()
 
 
+def test_fp32_scoring_path_on_confident_scores(dev):
+    """The same bar on scores that look like a trained model's: the utterance-level layer amplified until the widest margin is ~8 nats, so
+    that the log-probs spread over 0 ... -8 instead of sitting at log 0.5 (random-init weights say little about the tails, where EER is decided).  Six clips of different
+    loudness; the error of every log-prob against the fp32 CPU oracle within 1e-3 of the largest |log-prob|, decisions identical."""
+    m, ssl, head, ocfg = _full_size_model(dev, 73, 74)
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(6, 64600, generator=g) * torch.tensor([0.02, 0.05, 0.1, 0.2, 0.4, 0.8])[:, None]
+    with torch.no_grad():
+        _, _, re = OH.full_forward(ssl, head, ocfg, x)
+        w, b = head["backend.m_utt_level.weight"], head["backend.m_utt_level.bias"]
+        margin = (re @ (w[0] - w[1])) + (b[0] - b[1])
+        amp = 8.0 / (margin - margin.mean()).abs().max().item()          # the widest margin becomes ~8 nats around the mean
+        head = dict(head)
+        head["backend.m_utt_level.weight"] = w * amp
+        head["backend.m_utt_level.bias"] = b * amp - torch.stack([margin.mean() * amp / 2, -margin.mean() * amp / 2])
+        m.load_state_dict({k: head[k] for k in ("backend.m_utt_level.weight", "backend.m_utt_level.bias")}, strict=False)
+        ro = torch.log_softmax(torch.nn.functional.linear(re, head["backend.m_utt_level.weight"], head["backend.m_utt_level.bias"]), 1)
+        out, feats, emb = m(x.to(dev))
+    spread = ro.abs().max().item()
+    err = (out.float().cpu() - ro).abs().max().item()
+    print("confident scores: log-probs\n", ro.numpy().round(4), "\nmax abs err %.2e (spread %.2f)" % (err, spread))
+    assert spread > 2.0, spread                              # the amplification did produce tails
+    assert err < 1e-3 * spread
+    assert (out.argmax(1).cpu() == ro.argmax(1)).all()
+
+
 @pytest.mark.parametrize("layerdrop", [0.0, 0.35])
 def test_carried_over_weight_gradient_launches_equal_the_split_k_path(dev, layerdrop):
     """The grouped weight-gradient launches with carry-over (scl_amd/encoder.py::_flush_slabs: tile ranges of several layers' problems
