@@ -7,7 +7,7 @@ from scl_amd.optim import FusedAdamW
 
 dev = torch.device("cuda:0")
 conf = {"model": {"contra_mode": "all", "loss_type": 1}}
-for name in ("linear", "aasist", "resnet"):
+for name, nsteps, lr in (("linear", 40, 2e-5), ("aasist", 40, 2e-5), ("resnet", 40, 2e-5), ("linear", 240, 1e-4)):      # the last: long enough for the CE term to move
     if name == "linear":
         from scl_amd.model_linear import Model
     elif name == "aasist":
@@ -16,7 +16,7 @@ for name in ("linear", "aasist", "resnet"):
         from scl_amd.model_resnet import Model
     m = Model({"flag_fix_ssl": False, "contra_mode": "all", "loss_type": 1}, dev, seed=0)
     m.train()
-    opt = FusedAdamW(m, lr=2e-5, weight_decay=1e-4)
+    opt = FusedAdamW(m, lr=lr, weight_decay=1e-4)
     g = torch.Generator().manual_seed(3)
     B = 8
     t = torch.arange(64000) / 16000.0
@@ -25,17 +25,17 @@ for name in ("linear", "aasist", "resnet"):
                      for i in range(B)]).to(dev)
     y = torch.tensor([1, 1, 1, 1, 0, 0, 0, 0], device=dev)
     hist = []
-    for step in range(40):
+    for step in range(nsteps):
         out, feats, emb = m(x)
         losses = m.loss(out, feats, emb, y, conf)
         tot = sum(losses.values())
         opt.zero_grad()
         tot.backward()
         opt.step()
-        if step % 5 == 0 or step == 39:
+        if step % max(5, nsteps // 8) == 0 or step == nsteps - 1:
             acc = (out.argmax(1) == y).float().mean().item()
-            hist.append((step, round(float(tot), 4), round(float(losses["L_CE"]), 4), acc))
-    print(name, hist)
+            hist.append((step, round(tot.item(), 4), round(losses["L_CE"].item(), 4), acc))
+    print(name, "%d steps lr %g" % (nsteps, lr), hist)
     assert all(torch.isfinite(torch.tensor(h[1])) for h in hist) and hist[-1][1] < hist[0][1], name
     del m, opt
     torch.cuda.empty_cache()
