@@ -404,13 +404,16 @@ GLOBAL_SUPCON = os.environ.get("SCL_GLOBAL_SUPCON", "0") == "1"
 
 def loss_custom(output, feats, emb, labels, config):
     """model/loss_metrics.py:498-532 / Model.loss: dict of loss terms selected by loss_type.
-    SCL_GLOBAL_SUPCON=1 under data parallelism (optional): the two SupCon terms see the batch of ALL ranks (features and
-    labels all-gathered, positives / negatives across ranks, 1/bz with the global bz) while the NLL term stays rank-local; default:
-    every term rank-local, the reference's semantics at --batch_size 1."""
+    SCL_GLOBAL_SUPCON=1 under data parallelism (optional): the loss nn.DataParallel computes (main.py:62-66: Model.loss on
+    the outputs of ALL GPUs) — the two SupCon terms see the batch of all ranks (features and labels all-gathered, positives / negatives
+    across ranks, 1/bz with the global bz), and the NLL term, a sum over utterances, is the rank's own share of CE_global / bz_global
+    (= its local term / world size: averaged over the ranks by the gradient exchange it is the global term).  Default: every term
+    rank-local, the reference's semantics at --batch_size 1."""
     L_CE, L_CF1, L_CF2 = _LossFn.apply(output, feats, emb, labels)
     if GLOBAL_SUPCON and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         from .parallel import gather_for_global_loss as gather
         _, L_CF1, L_CF2 = _LossFn.apply(gather(output.detach()), gather(feats), gather(emb), gather(labels))
+        L_CE = L_CE / torch.distributed.get_world_size()
     lt = config["model"]["loss_type"]
     # contra_mode 'one' anchors only the first VIEW (loss_metrics.py:155-157); Model.loss hands supcon_loss exactly one view per
     # utterance (feats.unsqueeze(1), wav2vec2_linear_nll.py:176-180), so anchor_feature == contrast_feature and anchor_count == nv == 1:
