@@ -132,7 +132,7 @@ def seed_fast_sampler(seed):
         _FAST_ROOT.update(seq=np.random.SeedSequence(seed), epoch=_FAST_ROOT["epoch"] + 1, first=True)
 
 
-_COS_TABLES = {}      # (kmax, nfft) -> [kmax + 1, nfft / 2 + 1] float64: cos(2 pi i k / nfft), row 0 halved ... see _cos_table
+_COS_TABLES = {}      # nfft -> [rows, nfft / 2 + 1] float64: 2 cos(2 pi i k / nfft), row 0 = 1 (see _cos_table)
 _HAMMING = {}         # c -> right half (centre first) of the symmetric Hamming window of length c
 
 
@@ -152,16 +152,19 @@ def _matmul_1thread(a, b):
 
 
 def _cos_table(kmax, nfft):
-    t = _COS_TABLES.get((kmax, nfft))
-    if t is None:
-        k = np.arange(kmax + 1)[:, None]
+    """rows 0 .. kmax of the table for this transform size; ONE table per nfft, grown when a longer section turns up (the largest half
+    length differs from call to call — a table per (kmax, nfft) was rebuilt on almost every one-clip call of the pack builder)"""
+    t = _COS_TABLES.get(nfft)
+    if t is None or t.shape[0] < kmax + 1:
+        rows = max(kmax + 1, 64)
+        k = np.arange(rows)[:, None]
         i = np.arange(nfft // 2 + 1)[None, :]
         t = 2.0 * np.cos((2.0 * np.pi / nfft) * ((k * i) % nfft))      # A(w_i) = h[0] + 2 sum_{k >= 1} h[k] cos(w_i k)
         t[0] = 1.0
-        if len(_COS_TABLES) > 8:
+        if len(_COS_TABLES) > 4:
             _COS_TABLES.clear()
-        _COS_TABLES[(kmax, nfft)] = t
-    return t
+        _COS_TABLES[nfft] = t
+    return t[: kmax + 1]
 
 
 def _hamming_half(c, kmax):
@@ -253,24 +256,31 @@ def _design_notch_filters_general(f1, f2, c, G):
     return [b[i, :lens[i]].copy() for i in range(n)]
 
 
-def _fast_notch(a, n, minG, maxG, fs):
+def _fast_notch_params(a, n, minG, maxG):
     r = _fast_rng()
     fc = r.uniform(a.minF, a.maxF, (n, a.nBands))
     bw = r.uniform(a.minBW, a.maxBW, (n, a.nBands))
     c = r.uniform(a.minCoeff, a.maxCoeff, (n, a.nBands)).astype(np.int64)   # int() truncation, then made odd (RawBoost.py:33-36)
     c = np.where(c % 2 == 0, c + 1, c)
     G = minG + (maxG - minG) * r.random(n)     # the reference draws uniform(-5, -20): low > high is legal in legacy numpy
-    return design_notch_filters(fc, bw, c, G, fs)
+    return fc, bw, c, G
+
+
+def _fast_notch(a, n, minG, maxG, fs):
+    return design_notch_filters(*_fast_notch_params(a, n, minG, maxG), fs)
 
 
 def _fast_lnl(a, n, fs):
-    lin = _fast_notch(a, n, a.minG, a.maxG, fs)
-    out = [[lin[i]] for i in range(n)]
-    if a.N_f > 1:
-        nl = _fast_notch(a, n * (a.N_f - 1), a.minG - a.minBiasLinNonLin, a.maxG - a.maxBiasLinNonLin, fs)
-        for i in range(n):
-            out[i] += nl[i * (a.N_f - 1):(i + 1) * (a.N_f - 1)]
-    return out
+    """per clip: the linear branch's filter, then the N_f - 1 non-linear ones (lower gains) — drawn in that order, designed in ONE batch
+    (a one-clip call of the pack builder pays the design's fixed cost once, not twice)"""
+    lin = _fast_notch_params(a, n, a.minG, a.maxG)
+    if a.N_f <= 1:
+        taps = design_notch_filters(*lin, fs)
+        return [[taps[i]] for i in range(n)]
+    nl = _fast_notch_params(a, n * (a.N_f - 1), a.minG - a.minBiasLinNonLin, a.maxG - a.maxBiasLinNonLin)
+    taps = design_notch_filters(*(np.concatenate([p, q]) for p, q in zip(lin, nl)), fs)
+    k = a.N_f - 1
+    return [[taps[i]] + taps[n + i * k: n + (i + 1) * k] for i in range(n)]
 
 
 def _fast_isd(a, n, L):

@@ -107,6 +107,33 @@ def test_batched_notch_design_matches_scipy_per_filter_design(nb, cmax):
         np.testing.assert_allclose(o, g, rtol=0, atol=1e-12)
 
 
+def test_reference_order_sampler_equals_the_oracle_draw_for_draw():
+    """sampler="reference" (what the RawBoost goldens and main.py's SCL_PACK_SAMPLER=reference run): the host draws of scl_amd/augment.py
+    consume the global np.random stream exactly as the oracle's restatement of RawBoost.py:28-97 does — same seed, same parameters, the
+    batched closed-form filter design within 1e-12 of the per-filter scipy chain — for the LnL, ISD and SSI stages in sequence."""
+    from oracle import rawboost as RB
+    from scl_amd import augment
+    a = RB.RawBoostArgs()
+    for seed in (3, 4):
+        np.random.seed(seed)
+        ref_taps = RB.lnl_draw(a.N_f, a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff, a.minG, a.maxG, a.minBiasLinNonLin,
+                               a.maxBiasLinNonLin, 16000)
+        ref_p, ref_f = RB.isd_draw(64000, a.P)
+        ref_noise, ref_b, ref_snr = RB.ssi_draw(64000, a.SNRmin, a.SNRmax, a.nBands, a.minF, a.maxF, a.minBW, a.maxBW, a.minCoeff, a.maxCoeff,
+                                                a.minG, a.maxG, 16000)
+        np.random.seed(seed)
+        taps = augment._draw_lnl(a, 16000)
+        p, f = augment._draw_isd(a, 64000)
+        noise, b, snr = augment._draw_ssi(a, 64000, 16000)
+        assert len(taps) == len(ref_taps) == a.N_f
+        for t, r in zip(taps, ref_taps):
+            assert t.shape == r.shape
+            np.testing.assert_allclose(t, r, rtol=0, atol=1e-12)
+        assert np.array_equal(p, np.asarray(ref_p).astype(np.int32)) and np.allclose(f, np.asarray(ref_f, dtype=np.float32), rtol=0, atol=0)
+        assert np.array_equal(noise, np.asarray(ref_noise, dtype=np.float32)) and abs(snr - float(ref_snr)) == 0.0
+        np.testing.assert_allclose(b, ref_b, rtol=0, atol=1e-12)
+
+
 def test_fast_sampler_statistics():
     from scl_amd import augment
     from scl_amd.datautils_common import default_rawboost_args
