@@ -160,7 +160,7 @@ if "3" not in PARTS:
     shutil.rmtree(tmp, ignore_errors=True)
     sys.exit(0)
 print("== 3. scoring end to end: main.produce_evaluation_file over FLAC files vs the forward alone on a resident batch")
-NEVAL = 256 if QUICK else 2048
+NEVAL = int(os.environ.get("PROBE_NEVAL", "256" if QUICK else "2048"))
 evdir = os.path.join(root, "eval")
 os.makedirs(evdir, exist_ok=True)
 t0 = time.time()
@@ -182,7 +182,7 @@ with torch.no_grad():
         model(xb)
     torch.cuda.synchronize()
 t_fwd = time.time() - t0
-for thr in ("1", "8"):
+for thr in os.environ.get("PROBE_EVAL_THREADS", "1,8").split(","):
     os.environ["SCL_EVAL_THREADS"] = thr
     out = os.path.join(tmp, "scores_%s.txt" % thr)
     torch.cuda.synchronize(); t0 = time.time()
@@ -192,6 +192,6 @@ for thr in ("1", "8"):
     nl = sum(1 for _ in open(out))
     print("%d files, batch %d: forward alone %.2f s = %5.0f utt/s | produce_evaluation_file, SCL_EVAL_THREADS=%s: %.2f s = %5.0f utt/s (%.2f x), %d score lines"
           % (NEVAL, B, t_fwd, NEVAL / t_fwd, thr, dt, NEVAL / dt, dt / t_fwd, nl), flush=True)
-a, b = open(os.path.join(tmp, "scores_1.txt")).read(), open(os.path.join(tmp, "scores_8.txt")).read()
-print("score files of the plain loop and the threaded loop identical:", a == b)
+outs = [open(os.path.join(tmp, "scores_%s.txt" % t)).read() for t in os.environ.get("PROBE_EVAL_THREADS", "1,8").split(",")]
+print("score files of every loop identical:", all(o == outs[0] for o in outs))
 shutil.rmtree(tmp, ignore_errors=True)
