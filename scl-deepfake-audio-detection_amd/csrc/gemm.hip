@@ -356,10 +356,12 @@ __global__ __launch_bounds__(256, 2) void scl_gemm_dma_kernel(const GemmK d) {
 // spends it on bytes in flight: S - 1 stages of 32 KiB outstanding behind a counted vmcnt and raw barriers (a __syncthreads() would drain
 // the queue).  Loads past the last K tile are issued out of range (no fetch) so that the count is the same in every iteration.
 // Accumulation order is k ascending as above: results are bit-identical to the two-stage kernel's.
-// MEASURED (profiles/r6_small_m_probe.txt, rings of 3 / 4 / 5 stages): no gain — 18.8 vs 20.3 us at K = 1024, 51 vs 54 us at K = 4096, equal
-// under split-K.  The K step of a lone 4-wave workgroup is not waiting for memory: with ONE wave per SIMD its 16 fragment reads (64 KiB of
-// LDS traffic per step and CU = 512 cycles) and its 32 MFMAs (512 cycles) run one after the other, whatever is in flight.  What the small-M
-// launches lack is a second wave per SIMD, not bytes in flight.  Kept for the record behind SCL_EXPERIMENTS (SCL_GEMM_DEEP=1 selects it).
+// MEASURED (profiles/r6_small_m_probe.txt, rings of 3 / 5 stages, kernel time from the dispatch stamps): no gain — 17.6 vs 17.9 us at
+// K = 1024, 48.6 vs 52.8 us at K = 4096 (where split-K 3 takes 31 + 8), equal under split-K.  The launch is 6 us of fixed cost + 0.73 us per
+// K step: a lone 4-wave workgroup is not waiting for memory, with ONE wave per SIMD its 16 fragment reads (64 KiB of LDS traffic per step
+// and CU = 512 cycles) and its 32 MFMAs (512 cycles) run one after the other, whatever is in flight.  Two co-resident workgroups (split-K 2:
+// 1.02 us per step each) reach 1.43 x that throughput — which also bounds what an 8-wave K-split tile could gain (2.6 us at K = 1024,
+// nothing against split-K 3 at K >= 3072).  Kept for the record behind SCL_EXPERIMENTS (SCL_GEMM_DEEP=1 selects it).
 #ifndef SCL_DEEP_STAGES
 #define SCL_DEEP_STAGES 5
 #endif

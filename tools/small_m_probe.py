@@ -1,6 +1,6 @@
 """Pack-sized linears (M = 11 x 199 rows and its multiples): the two-stage 128 x 128 kernel vs its deep-ring variant (csrc/gemm.hip
 scl_gemm_deep_kernel — an -DSCL_EXPERIMENTS build; SCL_GEMM_DEEP is read per call, ring depth = -DSCL_DEEP_STAGES) with and without split-K,
-and the wide kernel where it qualifies ("auto").  us per product on one stream, slab reduction included.  With the shipped library the
+and the wide kernel where it qualifies ("auto").  us per GEMM launch from the launch's own dispatch stamps (split-K: the partial GEMM only; its slab reduction is a separate ~8-us launch).  With the shipped library the
 "deep" columns repeat the two-stage kernel.  Result (profiles/r6_small_m_probe.txt): the ring depth buys nothing at any of the shapes."""
 import os
 import sys
@@ -9,6 +9,7 @@ import torch
 from scl_amd import ops
 from scl_amd.ops import Op
 dev = torch.device("cuda:0")
+KID_GEMM = 0
 Ms = [int(a) for a in sys.argv[1:]] or [2189]
 ops._AUTO_SPLITK = False
 for M in Ms:
@@ -43,11 +44,18 @@ for M in Ms:
                     ref = got
                 elif not torch.equal(ref, got):
                     res.append("MISMATCH")
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(); e0.record()
-            for i in range(60):
+            # kernel time from the launches' own dispatch stamps (the library's profiling scope, as bench.py's roofline uses it): a Python
+            # loop of launches this short is HOST-bound (~18 us per ops.gemm call), wall time per iteration says nothing about the kernel
+            torch.cuda.synchronize()
+            ops.prof_reserve(KID_GEMM, 64)
+            ops.prof_read(KID_GEMM)
+            ops.prof_enable(KID_GEMM, True)
+            for i in range(30):
                 run(i)
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1000 / 60
+            torch.cuda.synchronize()
+            ops.prof_enable(KID_GEMM, False)
+            ms = [m for m, _ in ops.prof_read_launches(KID_GEMM)]
+            ops.prof_read(KID_GEMM)
+            us = 1e3 * sum(ms) / max(1, len(ms))
             res.append("%ssk%d%s %.1f" % ("deep " if deep else "", sk, "" if no_w8 else " auto", us))
         print("M=%d %-10s N=%d K=%d: %s" % (M, name, N, K, " | ".join(res)))
