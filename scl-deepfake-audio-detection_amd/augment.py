@@ -144,10 +144,13 @@ except Exception:      # noqa: BLE001 - optional
     _BLAS_CTL = None
 
 
+_BLAS_LOCK = threading.Lock()      # the limit is process-wide state: two threads entering / leaving it out of order would leave it changed
+
+
 def _matmul_1thread(a, b):
     if _BLAS_CTL is None:
         return a @ b
-    with _BLAS_CTL.limit(limits=1, user_api="blas"):
+    with _BLAS_LOCK, _BLAS_CTL.limit(limits=1, user_api="blas"):
         return a @ b
 
 
